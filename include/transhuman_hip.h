@@ -1,0 +1,211 @@
+/*
+ * transhuman_hip.h -- C ABI of libtranshuman_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (pansanity666/TransHuman) is 100 % Python; its "native" hot
+ * path is a sequence of torch / pytorch3d kernels launched from
+ *   lib/networks/renderer/if_clight_renderer.py  (Renderer.render_fast/_render/batchify_rays)
+ *   lib/networks/cross_transformer.py            (Network.forward and helpers)
+ *   lib/networks/vision_transformer.py           (VisionTransformer.forward)
+ *   lib/networks/renderer/nerf_net_utils.py      (raw2outputs)
+ *   lib/networks/renderer/if_mesh_renderer.py    (Renderer.render)
+ * Each entry point below names the reference lines it replaces.  The Python
+ * classes in transhuman_amd/networks/ keep the reference's operator API and
+ * bind these symbols with ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host;
+ *  - all floating point data is fp32 unless stated (blend matrices: f64);
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *  - functions return 0 on success, <0 on error; th_last_error() gives the text;
+ *  - no function allocates device memory: scratch comes from the caller via
+ *    (workspace, workspace_bytes), sized with the matching *_workspace_bytes();
+ *  - a th_ctx is bound to one device and must be used from one thread at a time.
+ */
+#ifndef TRANSHUMAN_HIP_H
+#define TRANSHUMAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TH_ABI_VERSION 1
+
+typedef struct th_ctx th_ctx;
+typedef void* th_stream;
+
+/* ---- library / context ------------------------------------------------ */
+int         th_abi_version(void);
+const char* th_last_error(void);
+int         th_ctx_create(int device, th_ctx** out);
+void        th_ctx_destroy(th_ctx* ctx);
+
+/* ---- weights ----------------------------------------------------------- */
+/* One dense layer: weight row-major [out_f][in_f] (a Conv1d(k=1)/Linear
+ * weight with the trailing 1 squeezed), bias [out_f] or NULL. */
+typedef struct {
+    const float* w;
+    const float* b;
+    int out_f;
+    int in_f;
+} th_linear;
+
+/* Per-point MLP of Network (cross_transformer.py:96-126). */
+typedef struct {
+    th_linear fc_0, alpha_res_0;
+    th_linear key0, val0;          /* spatial_key_value_0 (pixel branch)  */
+    th_linear key1, val1;          /* spatial_key_value_1 (token branch)  */
+    th_linear fc_1, fc_2, fc_3, alpha_fc;
+    th_linear feature_fc, rgb_res_0, view_fc, rgb_res_1, fc_4, rgb_fc;
+} th_mlp_weights;
+
+/* One transformer block (vision_transformer.py:285-307). */
+typedef struct {
+    const float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    th_linear qkv, proj, fc1, fc2;
+} th_vit_block;
+
+/* Copies + re-packs the weights into the MFMA operand layout owned by ctx.
+ * `dparf_alpha`/`n_freq`/`knn` = cfg.KNN_DIST_ALPHA / KNN_FREQ / KNN. */
+int th_set_mlp_weights(th_ctx* ctx, const th_mlp_weights* w, th_stream stream);
+int th_set_vit_weights(th_ctx* ctx, int depth, int dim, int heads, const th_vit_block* blocks,
+                       const float* norm_w, const float* norm_b, th_stream stream);
+
+/* ---- generic dense layer on the fp32 MFMA pipe (building block) -------- */
+/* C[M, out_f] = act(A[M, in_f] * W^T + b);  act: 0 none, 1 relu, 2 gelu(erf).
+ * lda/ldc in floats.  Packs W on the fly into `workspace`. */
+size_t th_linear_workspace_bytes(int out_f, int in_f);
+int th_linear_forward(th_ctx* ctx, const float* A, int lda, int M, const th_linear* lin, int act,
+                      float* C, int ldc, void* workspace, size_t workspace_bytes, th_stream stream);
+
+/* ---- K1: sample placement + SMPL-hull mask ------------------------------ */
+/* if_clight_renderer.py:271-287 (get_sampling_points) + :440-444
+ * (knn_points K=1, sqrt, < 0.1, per-ray any) and if_mesh_renderer.py:53-56.
+ * Points come either from rays (pts==NULL: p = o + d*(near*(1-t)+far*t),
+ * t_vals/one_minus_t are the S linspace values) or explicitly (pts[P,3]).
+ * mask_out: uint8[P] (P = R*S or P); ray_hit_out: int32[R] or NULL. */
+typedef struct {
+    const float* pts;          /* explicit points [P,3] or NULL            */
+    const float* ray_o;        /* [R,3]                                    */
+    const float* ray_d;        /* [R,3]                                    */
+    const float* near;         /* [R]                                      */
+    const float* far;          /* [R]                                      */
+    const float* t_vals;       /* [S] torch.linspace(0,1,S)                */
+    const float* one_minus_t;  /* [S] 1 - t_vals                           */
+    int R, S;                  /* rays, samples per ray (S=1 with pts)     */
+} th_points;
+
+size_t th_hull_workspace_bytes(int n_verts);
+int th_hull_mask(th_ctx* ctx, const th_points* p, const float* verts_world, int n_verts, float thresh,
+                 uint8_t* mask_out, int32_t* ray_hit_out, void* workspace, size_t workspace_bytes,
+                 th_stream stream);
+
+/* ---- K2: paint SMPL vertices + cluster mean pooling --------------------- */
+/* paint_neural_human :95-184 (project, bilinear grid_sample(align_corners,
+ * border) of the NCHW holder map, zero invisible vertices) followed by
+ * voxelization/can_body_grouping :356-371,:415-427 (CSR segmented mean).
+ * cams: per view R[9], T[3], K[9] row-major = 21 floats.  scale_xy: the two
+ * floats of sample_from_feature_map :193.  tokens_out [V,N_c,C]. */
+int th_paint_group(th_ctx* ctx, const float* holder_map_nchw, int V, int C, int H, int W,
+                   const float* verts_world, int n_verts, const float* cams, const float* scale_xy,
+                   const uint8_t* vizmap, const int32_t* csr_offsets, const int32_t* csr_members,
+                   int n_clusters, float* painted_out /* [V,n_verts,C] or NULL */, float* tokens_out,
+                   th_stream stream);
+/* voxelization of per-vertex rows: fp32 [n_verts,width] -> [N_c,width] */
+int th_segment_mean_f32(th_ctx* ctx, const float* src, int width, const int32_t* csr_offsets,
+                        const int32_t* csr_members, int n_clusters, float* out, th_stream stream);
+/* blend matrices: f64 [n_verts,16] -> mean in f64 -> top-left 3x3 as fp32
+ * [N_c,9] (cross_transformer.py:185) */
+int th_segment_mean_rot_f64(th_ctx* ctx, const double* blend, const int32_t* csr_offsets,
+                            const int32_t* csr_members, int n_clusters, float* rot_out,
+                            th_stream stream);
+
+/* ---- K3: TransHE (ViT-tiny) ---------------------------------------------- */
+/* VisionTransformer.forward, vision_transformer.py:371-383.  x [V,N,dim]
+ * tokens, pe [V,N,dim] sin-cos table (host-built, see vision_transformer.py),
+ * out [V,N,dim]. */
+size_t th_vit_workspace_bytes(int V, int N, int dim, int heads);
+int th_vit_forward(th_ctx* ctx, const float* x, const float* pe, int V, int N, float* out,
+                   void* workspace, size_t workspace_bytes, th_stream stream);
+
+/* ---- K4: DPaRF encoding --------------------------------------------------- */
+/* Network.get_human_representation, cross_transformer.py:158-205.
+ * pts_smpl [P,3]; centres [N_c,3]; rot [N_c,9]; tokens [V,N_c,192];
+ * sel: int32[P] indices into pts or NULL (identity).
+ * out: [P, V, 256] row-major (255 features + one zero pad column). */
+int th_dparf_encode(th_ctx* ctx, const float* pts_smpl, const int32_t* sel, int P, const float* centres,
+                    const float* rot, const float* tokens, int V, int n_clusters, float* out,
+                    th_stream stream);
+
+/* ---- K5: pixel-aligned feature gather -------------------------------------- */
+/* get_pixel_aligned_feature :210-269 on a channels-last map
+ * pixel_map_nhwc [V,H,W,C]; pts_world [P,3]; out [P,V,C]. */
+int th_nchw_to_nhwc(th_ctx* ctx, const float* src, int V, int C, int H, int W, float* dst, th_stream stream);
+int th_pixel_gather(th_ctx* ctx, const float* pixel_map_nhwc, int V, int C, int H, int W,
+                    const float* pts_world, const int32_t* sel, int P, const float* cams,
+                    const float* scale_xy, float* out, th_stream stream);
+
+/* ---- K6: per-point multi-view MLP ------------------------------------------ */
+/* Network.forward, cross_transformer.py:207-353, on already-gathered inputs.
+ * pixel_feat [V,384,P] (the reference's channel-major layout); viewdir [P,27];
+ * pts_smpl [P,3]; mask uint8[P] or NULL.  raw_out [P,4] (rgb logits, sigma).
+ * With a mask: progressive RGB (sigma>0 only) and zero rows where masked out;
+ * without: RGB everywhere (MLP_forward_ori :280-289). */
+size_t th_network_workspace_bytes(int V, int P);
+int th_network_forward(th_ctx* ctx, const float* pixel_feat, const float* viewdir, const float* pts_smpl,
+                       const uint8_t* mask, int P, const float* centres, const float* rot,
+                       const float* tokens, int V, int n_clusters, float* raw_out, void* workspace,
+                       size_t workspace_bytes, th_stream stream);
+
+/* ---- K7: alpha compositing --------------------------------------------------- */
+/* raw2outputs, nerf_net_utils.py:14-59.  raw [R,S,4]; z [R,S] or NULL (then
+ * recomputed from near/far/t_vals); ray_d [R,3].  Outputs rgb [R,3], acc [R],
+ * depth [R]; weights_out [R,S] or NULL. */
+int th_composite(th_ctx* ctx, const float* raw, const float* z, const th_points* rays, int white_bkgd,
+                 float* rgb, float* acc, float* depth, float* weights_out, th_stream stream);
+
+/* view-direction embedding, if_clight_renderer.py:525-526 + embedder.py:9-35:
+ * ray_d [R,3] -> [R, 3 + 6*view_res] */
+int th_view_embed(th_ctx* ctx, const float* ray_d, int R, int view_res, float* out, th_stream stream);
+
+/* ---- frame-level entry points -------------------------------------------------- */
+/* Per-frame constants produced by th_paint_group / th_vit_forward / the
+ * segment means, consumed by the per-sample stage. */
+typedef struct {
+    const float* verts_world;      /* [n_verts,3] tar_smpl_vertice            */
+    int          n_verts;
+    const float* Rh;               /* [9]                                     */
+    const float* Th;               /* [3]                                     */
+    const float* cams;             /* [V,21]                                  */
+    const float* scale_xy;         /* [2]                                     */
+    const float* pixel_map_nhwc;   /* [V,H,W,384]                             */
+    int          V, H, W;
+    const float* tokens;           /* [V,N_c,192] ViT output                  */
+    const float* centres;          /* [N_c,3]                                 */
+    const float* rot;              /* [N_c,9]                                 */
+    int          n_clusters;
+    float        hull_thresh;      /* 0.1                                     */
+    int          small_frame_rays; /* 2400: R' <= this -> un-masked branch    */
+} th_frame;
+
+/* Renderer.render_fast :429-484 incl. _render/batchify_rays/raw2outputs for a
+ * range of rays (the unit that is sharded across GPUs).  Outputs are dense
+ * over the R rays (zeros for rays that miss the hull).
+ * stats_host (optional, int64[4]): hit rays, valid samples, sigma>0 samples, mode. */
+size_t th_render_workspace_bytes(const th_frame* f, int R, int S);
+int th_render_rays(th_ctx* ctx, const th_frame* f, const th_points* rays, float* rgb, float* acc,
+                   float* depth, int white_bkgd, void* workspace, size_t workspace_bytes,
+                   int64_t* stats_host, th_stream stream);
+
+/* if_mesh_renderer.Renderer.render :46-100 up to `cube`: sigma_raw per grid
+ * point (0 outside the hull).  pts [P,3] world space. */
+size_t th_sigma_grid_workspace_bytes(const th_frame* f, int P);
+int th_eval_sigma_grid(th_ctx* ctx, const th_frame* f, const float* pts, int P, float* sigma_out,
+                       void* workspace, size_t workspace_bytes, int64_t* stats_host, th_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRANSHUMAN_HIP_H */

@@ -1,0 +1,450 @@
+"""CPU ORACLE for the TransHuman rendering hot path -- TEST INFRASTRUCTURE ONLY.
+
+This file is a from-scratch CPU (torch fp32 / numpy) restatement of the
+reference's algorithm for the path named by BASELINE.json:north_star.  It is
+the checker for the HIP kernels and the timed "cpu_baseline" in bench.py.
+Nothing under ``transhuman_amd/`` (the product) may import it: only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg do.
+
+Parity pinning: every function below is checked in tests/test_oracle_golden.py
+against golden vectors produced by importing the *real* reference modules in
+the survey container (oracle/gen_golden.py -> tests/golden/*.npz).
+The one place the reference's own arithmetic is NOT available is
+``pytorch3d.ops.knn_points`` (third-party, un-vendored, version unpinned,
+/root/reference/README.md:63-64): its semantics are restated from its
+documented contract (squared L2, K smallest ascending, ties -> lower index)
+in ``knn_points_exact`` and the goldens use that same stand-in, so parity at
+the KNN boundary is "unpinned by the reference" (DESIGN.md section 3).
+
+All file:line citations are relative to /root/reference/.
+Weights are addressed by the reference's state-dict key names.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ---------------------------------------------------------------------------
+# a-1  sample placement   lib/networks/renderer/if_clight_renderer.py:271-287
+# ---------------------------------------------------------------------------
+def sampling_points(ray_o, ray_d, near, far, n_samples):
+    """ray_o,ray_d [R,3]; near,far [R] -> pts [R,S,3], z [R,S] (no perturb)."""
+    t = torch.linspace(0.0, 1.0, steps=n_samples).to(near)
+    z = near[..., None] * (1.0 - t) + far[..., None] * t          # :274
+    pts = ray_o[:, None] + ray_d[:, None] * z[..., None]          # :285
+    return pts, z
+
+
+# ---------------------------------------------------------------------------
+# third-party boundary: pytorch3d.ops.knn_points  (call sites
+# if_clight_renderer.py:440, if_mesh_renderer.py:53, cross_transformer.py:170)
+# ---------------------------------------------------------------------------
+def knn_points_exact(p, q, K, chunk=4096):
+    """Exact brute force.  p [P,3], q [N,3] fp32 -> (d2 [P,K] ascending squared
+    L2 computed as (dx*dx + dy*dy) + dz*dz in fp32, idx [P,K] int64; ties go to
+    the lower index)."""
+    P = p.shape[0]
+    d2o = torch.empty((P, K), dtype=torch.float32)
+    ido = torch.empty((P, K), dtype=torch.int64)
+    for s in range(0, P, chunk):
+        pp = p[s:s + chunk]
+        dx = pp[:, None, 0] - q[None, :, 0]
+        dy = pp[:, None, 1] - q[None, :, 1]
+        dz = pp[:, None, 2] - q[None, :, 2]
+        d2 = dx * dx + dy * dy
+        d2 = d2 + dz * dz
+        if K == 1:
+            v, i = d2.min(dim=1)                # first occurrence on CPU
+            d2o[s:s + chunk, 0] = v
+            ido[s:s + chunk, 0] = i
+        else:
+            v, i = torch.sort(d2, dim=1, stable=True)
+            d2o[s:s + chunk] = v[:, :K]
+            ido[s:s + chunk] = i[:, :K]
+    return d2o, ido
+
+
+def hull_mask(pts, verts, thresh=0.1):
+    """if_clight_renderer.py:440-442 -- sqrt(min d2) < 0.1 per sample.
+    pts [P,3], verts [NV,3] (both world space) -> bool [P]."""
+    d2, _ = knn_points_exact(pts, verts, 1)
+    return d2[:, 0].sqrt() < thresh
+
+
+# ---------------------------------------------------------------------------
+# a-3 helpers
+# ---------------------------------------------------------------------------
+def world2smpl(pts, Rh, Th):
+    """if_clight_renderer.py:289-295: q = (p - Th) @ Rh.  pts [...,3], Rh [3,3], Th [1,3]."""
+    sh = pts.shape
+    return torch.matmul(pts.reshape(-1, 3) - Th.reshape(1, 3), Rh).reshape(sh)
+
+
+def view_embed(ray_d, view_res=4):
+    """if_clight_renderer.py:525-526 + lib/networks/embedder.py:9-35:
+    v=d/|d|; [v, sin(2^k v), cos(2^k v)] k<view_res -> [R, 3+6*view_res]."""
+    v = ray_d / torch.norm(ray_d, dim=-1, keepdim=True)
+    out = [v]
+    freqs = 2.0 ** torch.linspace(0.0, view_res - 1, steps=view_res)
+    for f in freqs:
+        out.append(torch.sin(v * f))
+        out.append(torch.cos(v * f))
+    return torch.cat(out, -1)
+
+
+def pe_encode(x, num_freqs, include_input=True):
+    """pixelNeRF PE, lib/networks/vision_transformer.py:100-136.
+    x [N,3] -> [N, 6F (+3)]; arg = addcmul(phase, x, freq) (single-rounding
+    FMA), layout per octave: sin(f x) xyz, cos(f x) xyz."""
+    freqs = np.pi * 2.0 ** torch.arange(0, num_freqs)             # :109 (fp32 tensor)
+    _freqs = torch.repeat_interleave(freqs, 2).view(1, -1, 1)     # :116
+    _phases = torch.zeros(2 * num_freqs)
+    _phases[1::2] = np.pi * 0.5                                   # :121
+    _phases = _phases.view(1, -1, 1)
+    e = x.unsqueeze(1).repeat(1, num_freqs * 2, 1)
+    e = torch.sin(torch.addcmul(_phases, e, _freqs))              # :132
+    e = e.view(x.shape[0], -1)
+    if include_input:
+        e = torch.cat((x, e), dim=-1)
+    return e
+
+
+def normalize_pe(pe, cr=(-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)):
+    """if_clight_renderer.py:373-383 (float64 in, float32 out)."""
+    cr = torch.tensor(cr)
+    mn, mx = cr[:3][None, None, :], cr[3:][None, None, :]
+    out = (((pe - mn) / (mx - mn)) - 0.5) * 2
+    return out.type(torch.float32)
+
+
+# ---------------------------------------------------------------------------
+# a-4 / a-9  projection + bilinear sampling
+# ---------------------------------------------------------------------------
+def project_uv(x, R, T, K):
+    """if_clight_renderer.py:123-126 / :228-232.  x [N,3]; R [V,3,3]; T [V,3,1];
+    K [V,3,3] -> uv [V,N,2]."""
+    rot = torch.matmul(R[:, None], x[None, :, :, None])[..., 0]
+    cam = rot + T[:, None, :3, 0]
+    pix = torch.matmul(K[:, None], cam.unsqueeze(-1))[..., 0]
+    return pix[:, :, :2] / pix[:, :, 2:]
+
+
+def feat_scale(H, W):
+    """lib/networks/encoder.py:148-153 then if_clight_renderer.py:193-195:
+    scale = [W,H]/([W,H]-1)*2 / [H,W] as float32 (note the H/W mix of the
+    reference, harmless for square images)."""
+    s = np.array([W, H]) / (np.array([W, H]) - 1) * 2.0
+    s = s / np.array([H, W])
+    return torch.tensor(s).to(dtype=torch.float32)
+
+
+def bilinear_border(feat, uv, scale):
+    """Explicit restatement of F.grid_sample(bilinear, align_corners=True,
+    padding_mode='border') as used at if_clight_renderer.py:197-206.
+    feat [V,C,H,W]; uv [V,N,2] pixel coords; scale [2] -> [V,C,N]."""
+    V, C, H, W = feat.shape
+    g = uv * scale - 1.0                                          # :197
+    ix = ((g[..., 0] + 1.0) / 2.0) * (W - 1)
+    iy = ((g[..., 1] + 1.0) / 2.0) * (H - 1)
+    ix = ix.clamp(0.0, float(W - 1))
+    iy = iy.clamp(0.0, float(H - 1))
+    x0 = torch.floor(ix); y0 = torch.floor(iy)
+    x1 = x0 + 1; y1 = y0 + 1
+    w_nw = (x1 - ix) * (y1 - iy)
+    w_ne = (ix - x0) * (y1 - iy)
+    w_sw = (x1 - ix) * (iy - y0)
+    w_se = (ix - x0) * (iy - y0)
+    out = torch.zeros((V, C, uv.shape[1]), dtype=feat.dtype)
+    fl = feat.reshape(V, C, H * W)
+    for (xx, yy, ww) in ((x0, y0, w_nw), (x1, y0, w_ne), (x0, y1, w_sw), (x1, y1, w_se)):
+        inb = (xx >= 0) & (xx <= W - 1) & (yy >= 0) & (yy <= H - 1)
+        lin = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).long()
+        val = torch.gather(fl, 2, lin[:, None, :].expand(V, C, -1))
+        out = out + val * (ww * inb.to(ww.dtype))[:, None, :]
+    return out
+
+
+def paint(holder_feat_map, verts_w, in_R, in_T, in_K, vizmap):
+    """paint_neural_human, if_clight_renderer.py:95-184 (rasterize=True path).
+    holder_feat_map [V,192,H,W]; verts_w [NV,3]; vizmap bool [V,NV]
+    -> big_holder [V,NV,192] with invisible vertices zeroed (:181-182)."""
+    V, C, H, W = holder_feat_map.shape
+    uv = project_uv(verts_w, in_R, in_T, in_K)
+    lat = bilinear_border(holder_feat_map, uv, feat_scale(H, W)).permute(0, 2, 1)
+    return lat * vizmap[..., None].to(lat.dtype)
+
+
+def segment_mean(src, offsets, members):
+    """voxelization, if_clight_renderer.py:356-371: per-cluster arithmetic mean
+    over the member list in stored order.  src [NV,...] -> [N_c,...] (dtype kept)."""
+    out = []
+    for c in range(len(offsets) - 1):
+        idx = torch.as_tensor(members[offsets[c]:offsets[c + 1]], dtype=torch.long)
+        out.append(src[idx].mean(0))
+    return torch.stack(out)
+
+
+# ---------------------------------------------------------------------------
+# a-6  TransHE  lib/networks/vision_transformer.py:257-383
+# ---------------------------------------------------------------------------
+def vit_forward(x, pe_xyz, sd, depth, prefix="ViT.", heads=3):
+    """x [V,N,192] tokens; pe_xyz [V,N,3] normalised canonical centres."""
+    V, N, C = x.shape
+    pe = pe_encode(pe_xyz.reshape(-1, 3), C // 6, include_input=False).view(V, N, C)
+    x = x + pe                                                     # :366-367
+    hd = C // heads
+    for i in range(depth):
+        p = f"{prefix}blocks.{i}."
+        y = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6)
+        qkv = F.linear(y, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"])
+        qkv = qkv.reshape(V, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        a = (q @ k.transpose(-2, -1)) * (hd ** -0.5)               # :274
+        a = a.softmax(dim=-1)
+        y = (a @ v).transpose(1, 2).reshape(V, N, C)
+        y = F.linear(y, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+        x = x + y
+        y = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
+        y = F.linear(y, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"])
+        y = F.gelu(y)                                              # nn.GELU (erf)
+        y = F.linear(y, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+        x = x + y
+    return F.layer_norm(x, (C,), sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-6)
+
+
+# ---------------------------------------------------------------------------
+# a-7  DPaRF  lib/networks/cross_transformer.py:151-205
+# ---------------------------------------------------------------------------
+def dparf(pts_s, centres, blend, tokens, K=7, n_freq=10, alpha=0.5):
+    """pts_s [P,3] (SMPL coords); centres [N_c,3]; blend [N_c,4,4] (any float
+    dtype, cast to fp32 like :185); tokens [V,N_c,192]
+    -> human_rep [P,V,255] (token part then PE part, as torch.cat at :199)."""
+    d2, idx = knn_points_exact(pts_s, centres, K)
+    d = d2.sqrt()                                                  # :171
+    w = F.softmax(-d / alpha, dim=1)                               # :153-154
+    rel = pts_s.unsqueeze(1) - centres[idx]                        # :183-184
+    rot = blend[..., :3, :3].type(torch.float32)[idx]              # :185-186
+    de = torch.matmul(rel.unsqueeze(-2), rot).squeeze(-2)          # :187-188
+    P = pts_s.shape[0]
+    pe = pe_encode(de.reshape(-1, 3), n_freq, True).view(P, K, -1)
+    out = []
+    for v in range(tokens.shape[0]):
+        f = torch.cat([tokens[v][idx], pe], dim=-1)                # :198-199
+        out.append(torch.sum(w.unsqueeze(-1) * f, dim=1))          # :200
+    return torch.stack(out, dim=1)
+
+
+# ---------------------------------------------------------------------------
+# a-8  per-point MLP  lib/networks/cross_transformer.py:128-149, 273-353
+# ---------------------------------------------------------------------------
+def _lin(sd, name, x):
+    w = sd[name + ".weight"]
+    return F.linear(x, w.reshape(w.shape[0], -1), sd[name + ".bias"])
+
+
+def multiview_agg(sd, h, f):
+    """h [P,V,255] human rep, f [P,V,384] pixel feats -> inter [P,V,256]."""
+    s = F.relu(_lin(sd, "fc_0", h))                                # :315
+    p = F.relu(_lin(sd, "alpha_res_0", f))                         # :316
+    kp = _lin(sd, "spatial_key_value_0.key_embed", p)              # :134
+    vp = _lin(sd, "spatial_key_value_0.value_embed", p)
+    ks = _lin(sd, "spatial_key_value_1.key_embed", s)              # :137
+    vs = _lin(sd, "spatial_key_value_1.value_embed", s)
+    A = torch.einsum("pjc,pic->pji", kp, ks) / math.sqrt(kp.shape[-1])   # :141-142
+    A = F.softmax(A, dim=1)                                        # :144 (over pixel views j)
+    n = vs + torch.einsum("pjc,pji->pic", vp, A)                   # :145-147
+    n = F.relu(_lin(sd, "fc_1", n))
+    return F.relu(_lin(sd, "fc_2", n))                             # :319-320
+
+
+def alpha_forward(sd, inter):
+    o = F.relu(_lin(sd, "fc_3", inter.mean(dim=1)))                # :325-326
+    return _lin(sd, "alpha_fc", o)                                 # [P,1]
+
+
+def rgb_forward(sd, inter, f, viewdir):
+    """inter [P,V,256]; f [P,V,384]; viewdir [P,27] -> [P,3]."""
+    V = inter.shape[1]
+    feat = _lin(sd, "feature_fc", inter) + _lin(sd, "rgb_res_0", f)   # :333-335
+    feat = torch.cat([feat, viewdir[:, None, :].expand(-1, V, -1)], dim=-1)
+    net = F.relu(_lin(sd, "view_fc", feat)) + _lin(sd, "rgb_res_1", f)   # :341-344
+    net = F.relu(_lin(sd, "fc_4", net.mean(dim=1)))                # :347-350
+    return _lin(sd, "rgb_fc", net)
+
+
+def network_forward(sd, pixel_feat, viewdir, pts_s, centres, blend, tokens, pts_mask=None,
+                    K=7, n_freq=10, alpha=0.5):
+    """Network.forward, cross_transformer.py:207-311.
+    pixel_feat [V,384,P]; viewdir [P,27]; pts_s [P,3]; pts_mask bool [P] | None
+    -> raw [P,4] (rgb logits, sigma_raw).  With a mask: progressive RGB (only
+    sigma_raw > 0, :298) and zeros on masked-out points (:231,:268)."""
+    P = pts_s.shape[0]
+    f_all = pixel_feat.permute(2, 0, 1)
+    if pts_mask is not None:
+        raw = torch.zeros((P, 4))
+        if pts_mask.sum() == 0:
+            return raw
+        sel = pts_mask
+    else:
+        sel = torch.ones(P, dtype=torch.bool)
+    ps, f, vd = pts_s[sel], f_all[sel], viewdir[sel]
+    h = dparf(ps, centres, blend, tokens, K, n_freq, alpha)
+    inter = multiview_agg(sd, h, f)
+    sig = alpha_forward(sd, inter)
+    if pts_mask is not None:
+        rgb = torch.zeros((ps.shape[0], 3))
+        dm = sig[:, 0] > 0
+        if dm.sum() > 0:
+            rgb[dm] = rgb_forward(sd, inter[dm], f[dm], vd[dm])
+        raw[sel] = torch.cat([rgb, sig], dim=1)
+        return raw
+    return torch.cat([rgb_forward(sd, inter, f, vd), sig], dim=1)
+
+
+# ---------------------------------------------------------------------------
+# a-10  compositing  lib/networks/renderer/nerf_net_utils.py:14-59
+# ---------------------------------------------------------------------------
+def raw2outputs(raw, z, ray_d, white_bkgd=False):
+    """raw [R,S,4]; z [R,S]; ray_d [R,3] -> rgb [R,3], acc [R], depth [R], weights [R,S]."""
+    d = z[..., 1:] - z[..., :-1]
+    d = torch.cat([d, torch.full_like(d[..., :1], 1e10)], -1)      # :31-35
+    d = d * torch.norm(ray_d[..., None, :], dim=-1)                # :37
+    c = torch.sigmoid(raw[..., :3])
+    a = 1.0 - torch.exp(-F.relu(raw[..., 3]) * d)                  # :27-28,:44
+    T = torch.cumprod(torch.cat([torch.ones((a.shape[0], 1)), 1.0 - a + 1e-10], -1), -1)[:, :-1]
+    w = a * T                                                      # :46-49
+    rgb = torch.sum(w[..., None] * c, -2)
+    depth = torch.sum(w * z, -1)
+    acc = torch.sum(w, -1)
+    if white_bkgd:
+        rgb = rgb + (1.0 - acc[..., None])
+    return rgb, acc, depth, w
+
+
+# ---------------------------------------------------------------------------
+# frame constants shared by render_fast and the mesh renderer
+# ---------------------------------------------------------------------------
+def frame_constants(sd, batch, holder_feat_map, offsets, members, can_centres64, vit_depth):
+    """if_clight_renderer.py:531-547: paint -> group -> ViT, plus DPaRF tables.
+    can_centres64: float64 [N_c,3] cluster means of the canonical template
+    (Renderer.__init__ :73)."""
+    t = 0
+    V = holder_feat_map.shape[0]
+    big = paint(holder_feat_map, batch["input_smpl_vertice"][t][0],
+                batch["input_R"][t].reshape(-1, 3, 3), batch["input_T"][t].reshape(-1, 3, 1),
+                batch["input_K"][t].reshape(-1, 3, 3), batch["input_vizmaps"][t][0])
+    grouped = torch.stack([segment_mean(big[v], offsets, members) for v in range(V)])
+    pe_xyz = normalize_pe(can_centres64.unsqueeze(0).repeat(V, 1, 1))
+    tokens = vit_forward(grouped, pe_xyz, sd, vit_depth)
+    centres = segment_mean(batch["tar_smpl_vertice_smplcoord"][0], offsets, members)
+    blend = segment_mean(batch["blend_mtx"][0], offsets, members)
+    return dict(grouped=grouped, tokens=tokens, centres=centres, blend=blend)
+
+
+def pixel_aligned(pixel_feat_map, xyz_w, batch):
+    """get_pixel_aligned_feature, if_clight_renderer.py:210-269 -> [V,384,P]."""
+    t = 0
+    V, C, H, W = pixel_feat_map.shape
+    uv = project_uv(xyz_w, batch["input_R"][t].reshape(-1, 3, 3),
+                    batch["input_T"][t].reshape(-1, 3, 1), batch["input_K"][t].reshape(-1, 3, 3))
+    return bilinear_border(pixel_feat_map, uv, feat_scale(H, W))
+
+
+def render_fast(sd, batch, holder_feat_map, pixel_feat_map, offsets, members, can_centres64,
+                n_samples=64, vit_depth=12, small_frame_rays=2400, hull=0.1, chunk=32768):
+    """Renderer.render_fast, if_clight_renderer.py:429-484 (+ _render :500-605,
+    batchify_rays :607-656).  Encoder outputs are inputs here.
+    Returns dict rgb_map [1,R,3], acc_map [1,R], depth_map [1,R]."""
+    ray_o, ray_d = batch["ray_o"][0], batch["ray_d"][0]
+    near, far = batch["near"][0], batch["far"][0]
+    R = ray_o.shape[0]
+    pts, z = sampling_points(ray_o, ray_d, near, far, n_samples)
+    vm = hull_mask(pts.reshape(-1, 3), batch["tar_smpl_vertice"][0], hull).view(R, n_samples)
+    hit = vm.sum(-1) > 0                                           # :443
+    out = dict(rgb_map=torch.zeros(1, R, 3), acc_map=torch.zeros(1, R), depth_map=torch.zeros(1, R))
+    Rp = int(hit.sum())
+    fc = frame_constants(sd, batch, holder_feat_map, offsets, members, can_centres64, vit_depth)
+    if Rp == 0:
+        return out, fc
+    o, d, zz, pw, m = ray_o[hit], ray_d[hit], z[hit], pts[hit], vm[hit]
+    ps = world2smpl(pw, batch["Rh"][0], batch["Th"][0]).reshape(-1, 3)
+    vd = view_embed(d)[:, None, :].expand(-1, n_samples, -1).reshape(-1, 27)
+    xyz = pw.reshape(-1, 3)
+    if Rp <= small_frame_rays:                                     # :551 un-masked branch
+        pf = pixel_aligned(pixel_feat_map, xyz, batch)
+        raw = network_forward(sd, pf, vd, ps, fc["centres"], fc["blend"], fc["tokens"], None)
+    else:
+        mm = m.reshape(-1)
+        raws = []
+        for s in range(0, xyz.shape[0], chunk):
+            pf = pixel_aligned(pixel_feat_map, xyz[s:s + chunk], batch)
+            raws.append(network_forward(sd, pf, vd[s:s + chunk], ps[s:s + chunk], fc["centres"],
+                                        fc["blend"], fc["tokens"], mm[s:s + chunk]))
+        raw = torch.cat(raws, 0)
+    rgb, acc, depth, _ = raw2outputs(raw.view(Rp, n_samples, 4), zz, d)
+    out["rgb_map"][0, hit] = rgb
+    out["acc_map"][0, hit] = acc
+    out["depth_map"][0, hit] = depth
+    return out, fc
+
+
+def render_sigma_grid(sd, batch, pts_grid, holder_feat_map, pixel_feat_map, offsets, members,
+                      can_centres64, vit_depth=12, hull=0.1, chunk=32768):
+    """if_mesh_renderer.Renderer.render :46-100 up to ``cube`` (before np.pad
+    and marching cubes).  pts_grid [1,X,Y,Z,3] -> sigma_raw cube [X,Y,Z]."""
+    sh = pts_grid.shape
+    xyz = pts_grid.reshape(-1, 3)
+    m = hull_mask(xyz, batch["tar_smpl_vertice"][0], hull)
+    ps = world2smpl(xyz, batch["Rh"][0], batch["Th"][0])
+    vd = torch.zeros((xyz.shape[0], 27))                           # :62
+    fc = frame_constants(sd, batch, holder_feat_map, offsets, members, can_centres64, vit_depth)
+    raws = []
+    for s in range(0, xyz.shape[0], chunk):
+        pf = pixel_aligned(pixel_feat_map, xyz[s:s + chunk], batch)
+        raws.append(network_forward(sd, pf, vd[s:s + chunk], ps[s:s + chunk], fc["centres"],
+                                    fc["blend"], fc["tokens"], m[s:s + chunk]))
+    raw = torch.cat(raws, 0)
+    return raw[:, 3].view(*sh[1:4])
+
+
+# ---------------------------------------------------------------------------
+# f-1 (feeds the path)  SpatialEncoder.forward  lib/networks/encoder.py:97-155
+# ---------------------------------------------------------------------------
+def _bn_train(x, w, b, eps=1e-5):
+    """BatchNorm2d in *train mode* (run.py:29 leaves the net in train())."""
+    return F.batch_norm(x, None, None, w, b, True, 0.0, eps)
+
+
+def _basic_block(sd, p, x, stride, has_down):
+    idt = x
+    y = F.conv2d(x, sd[p + "conv1.weight"], None, stride, 1)
+    y = F.relu(_bn_train(y, sd[p + "bn1.weight"], sd[p + "bn1.bias"]))
+    y = F.conv2d(y, sd[p + "conv2.weight"], None, 1, 1)
+    y = _bn_train(y, sd[p + "bn2.weight"], sd[p + "bn2.bias"])
+    if has_down:
+        idt = F.conv2d(x, sd[p + "downsample.0.weight"], None, stride, 0)
+        idt = _bn_train(idt, sd[p + "downsample.1.weight"], sd[p + "downsample.1.bias"])
+    return F.relu(y + idt)
+
+
+def encoder_forward(sd, images, prefix="encoder."):
+    """images [V,3,H,W] -> holder_feat_map [V,192,H,W], pixel_feat_map [V,384,H,W]."""
+    m = prefix + "model."
+    H, W = images.shape[2:]
+    x = F.conv2d(images, sd[m + "conv1.weight"], None, 2, 3)
+    x = F.relu(_bn_train(x, sd[m + "bn1.weight"], sd[m + "bn1.bias"]))
+    lat = [x]
+    x = F.max_pool2d(x, 3, 2, 1)
+    x = _basic_block(sd, m + "layer1.0.", x, 1, False)
+    x = _basic_block(sd, m + "layer1.1.", x, 1, False)
+    lat.append(x)
+    x = _basic_block(sd, m + "layer2.0.", x, 2, True)
+    x = _basic_block(sd, m + "layer2.1.", x, 1, False)
+    lat.append(x)
+    lat = [F.interpolate(l, (H, W), mode="bilinear", align_corners=True) for l in lat]
+    pix = torch.cat(lat, dim=1)
+    col = F.conv2d(images, sd[prefix + "upsample_color.weight"], sd[prefix + "upsample_color.bias"])
+    pix = torch.cat([pix, col], dim=1)
+    hol = F.conv2d(pix, sd[prefix + "reduction_layer.weight"], sd[prefix + "reduction_layer.bias"])
+    return hol, pix

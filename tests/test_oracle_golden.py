@@ -1,0 +1,183 @@
+"""CPU: the oracle (oracle/th_oracle.py) against golden vectors produced by the
+REAL reference modules (oracle/gen_golden.py).  This is what pins the oracle."""
+import numpy as np
+import torch
+
+from oracle import th_oracle as O
+from transhuman_amd import synth
+from util import gold, make_sd, synth_assign, real_assign, csr, can_centres64, can64, maxdiff, body
+
+
+def test_g1_sampling_bit_exact():
+    g = gold("g1_sampling")
+    pts, z = O.sampling_points(g["ray_o"], g["ray_d"], g["near"], g["far"], 32)
+    assert torch.equal(pts, g["pts"]) and torch.equal(z, g["z"])
+
+
+def _paint_inputs():
+    b = synth.make_batch(32, 32, 3, seed=0)
+    hol = torch.from_numpy(synth.smooth_noise((3, 192, 32, 32), 21))
+    return b, hol
+
+
+def test_g45_paint_and_group():
+    g = gold("g45_paint_group")
+    b, hol = _paint_inputs()
+    big = O.paint(hol, b["input_smpl_vertice"][0][0], b["input_R"][0][0], b["input_T"][0][0], b["input_K"][0][0],
+                  b["input_vizmaps"][0][0])
+    assert maxdiff(big[:, :96], g["big_head"]) < 2e-6
+    assert maxdiff(big.double().sum((0, 1)), g["big_sum"]) < 1e-3
+    off, mem = csr(synth_assign(300))
+    grouped = torch.stack([O.segment_mean(big[v], off, mem) for v in range(3)])
+    assert maxdiff(grouped, g["grouped"]) < 2e-6
+
+
+def test_bilinear_matches_grid_sample():
+    import torch.nn.functional as F
+    rs = np.random.RandomState(0)
+    feat = torch.from_numpy(rs.normal(size=(2, 5, 9, 13)).astype(np.float32))
+    uv = torch.from_numpy(rs.uniform(-3, 16, size=(2, 200, 2)).astype(np.float32))
+    uv[0, :4] = torch.tensor([[0.0, 0.0], [12.0, 8.0], [12.0, 0.0], [6.5, 8.0]])
+    scale = O.feat_scale(9, 13)
+    mine = O.bilinear_border(feat, uv, scale)
+    ref = F.grid_sample(feat, (uv * scale - 1.0).unsqueeze(2), align_corners=True, mode="bilinear",
+                        padding_mode="border")[:, :, :, 0]
+    assert maxdiff(mine, ref) < 2e-6
+
+
+def test_g5_grouping_real_dicts():
+    b, hol = _paint_inputs()
+    big = O.paint(hol, b["input_smpl_vertice"][0][0], b["input_R"][0][0], b["input_T"][0][0], b["input_K"][0][0],
+                  b["input_vizmaps"][0][0])
+    for k in (500, 1500):
+        g = gold(f"g5_group_real{k}")
+        off, mem = csr(real_assign(k))
+        assert len(off) == k + 1
+        assert maxdiff(O.segment_mean(big[0], off, mem)[None], g["grouped"]) < 2e-6
+        pe_can = O.segment_mean(can64(), off, mem)
+        assert pe_can.dtype == torch.float64 and maxdiff(pe_can, g["pe_can"]) < 1e-14
+        assert torch.equal(O.normalize_pe(pe_can[None]), g["pe_norm"])
+
+
+def test_g6_vit():
+    g = gold("g6_vit")
+    sd = make_sd()
+    grouped = gold("g45_paint_group")["grouped"]
+    pe_norm = O.normalize_pe(can_centres64(synth_assign(300))[None].repeat(3, 1, 1))
+    assert torch.equal(pe_norm[0], g["pe_norm"])
+    tab = O.pe_encode(pe_norm[0], 32, include_input=False)
+    assert torch.equal(tab, g["pe_table"])          # 32-octave table must be bit-exact (hard part 1)
+    out = O.vit_forward(grouped, pe_norm, sd, 12)
+    assert maxdiff(out, g["out"]) < 2e-5
+
+
+def test_g6_vit_n500_v1():
+    g = gold("g6_vit_n500_v1")
+    x = torch.from_numpy(synth.smooth_noise((1, 500, 192), 22, passes=0))
+    pe_norm = O.normalize_pe(can_centres64(synth_assign(500))[None])
+    out = O.vit_forward(x, pe_norm, make_sd(), 12)
+    assert maxdiff(out, g["out"]) < 2e-5
+
+
+def _frame_consts():
+    b = synth.make_batch(32, 32, 3, seed=0)
+    off, mem = csr(synth_assign(300))
+    centres = O.segment_mean(b["tar_smpl_vertice_smplcoord"][0], off, mem)
+    blend = O.segment_mean(b["blend_mtx"][0], off, mem)
+    return b, centres, blend
+
+
+def test_g7_dparf():
+    g = gold("g7_dparf")
+    b, centres, blend = _frame_consts()
+    assert maxdiff(centres, g["centres"]) < 1e-7 and maxdiff(blend, g["blend"]) < 1e-14
+    tok = gold("g6_vit")["out"]
+    hr = O.dparf(g["pts_s"], centres, blend, tok)             # [P,V,255]
+    assert maxdiff(hr.permute(1, 2, 0), g["human_rep"]) < 1e-6
+
+
+def test_g8_network_forward():
+    g = gold("g8_forward")
+    b, centres, blend = _frame_consts()
+    tok = gold("g6_vit")["out"]
+    sd = make_sd()
+    pf = torch.from_numpy(synth.smooth_noise((3, 384, 1024), 23, passes=0))
+    for tag, mask in (("none", None), ("rand", g["mask"]), ("zero", torch.zeros_like(g["mask"]))):
+        raw = O.network_forward(sd, pf, g["viewdir"], g["pts_s"], centres, blend, tok, mask)
+        assert maxdiff(raw, g["raw_" + tag]) < 2e-5, tag
+    raw = O.network_forward(sd, pf[:1], g["viewdir"], g["pts_s"], centres, blend, tok[:1], g["mask"])
+    assert maxdiff(raw, g["raw_v1_rand"]) < 2e-5
+    raw = O.network_forward(sd, pf[:1], g["viewdir"], g["pts_s"], centres, blend, tok[:1], None)
+    assert maxdiff(raw, g["raw_v1_none"]) < 2e-5
+    # sanity of the fixture itself: both sigma signs and the progressive zeros are exercised
+    s = g["raw_rand"][:, 3]
+    assert (s > 0).sum() > 50 and (s < 0).sum() > 50
+    assert (g["raw_rand"][(s <= 0)][:, :3] == 0).all()
+
+
+def test_g9_pixel_aligned():
+    g = gold("g9_pixel_aligned")
+    b = synth.make_batch(32, 32, 3, seed=0)
+    pix = torch.from_numpy(synth.smooth_noise((3, 384, 32, 32), 24))
+    f = O.pixel_aligned(pix, g["xyz"], b)
+    assert maxdiff(f, g["feat"]) < 2e-6
+
+
+def test_g10_raw2outputs():
+    g = gold("g10_raw2outputs")
+    rgb, acc, depth, w = O.raw2outputs(g["raw"], g["z"], g["ray_d"])
+    for a, k in ((rgb, "rgb"), (acc, "acc"), (depth, "depth"), (w, "weights")):
+        assert maxdiff(a, g[k]) < 1e-6, k
+    assert float(acc[5]) == 0.0 and float(acc[6]) == 0.0       # all-zero raw / negative sigma rays
+
+
+def test_g13_encoder():
+    g = gold("g13_encoder")
+    b = synth.make_batch(32, 32, 3, seed=0)
+    hol, pix = O.encoder_forward(make_sd(), b["input_imgs"][0][0])
+    assert maxdiff(hol[:, :, ::8, ::8], g["holder_px"]) < 5e-5
+    assert maxdiff(pix[:, :, ::8, ::8], g["pixel_px"]) < 5e-5
+
+
+def _render_case(tag, H, focal):
+    g = gold(f"g11_render_{tag}")
+    b = synth.make_batch(H, H, 3, seed=0, focal=focal)
+    sd = make_sd()
+    hol, pix = O.encoder_forward(sd, b["input_imgs"][0][0])
+    off, mem = csr(synth_assign(300))
+    out, _ = O.render_fast(sd, b, hol, pix, off, mem, can_centres64(synth_assign(300)), n_samples=32)
+    return g, b, out
+
+
+def test_g11_render_fast_small_frame_branch():
+    g, b, out = _render_case("small", 32, None)
+    assert int(g["hit_rays"]) <= 2400
+    assert maxdiff(out["rgb_map"][0], g["rgb"]) < 2e-5
+    assert maxdiff(out["acc_map"][0], g["acc"]) < 2e-5
+    assert maxdiff(out["depth_map"][0], g["depth"]) < 1e-4
+
+
+def test_g11_render_fast_large_frame_branch():
+    g, b, out = _render_case("large", 64, 210.0)
+    assert int(g["hit_rays"]) > 2400
+    assert maxdiff(out["rgb_map"][0], g["rgb"]) < 2e-5
+    assert maxdiff(out["acc_map"][0], g["acc"]) < 2e-5
+    assert maxdiff(out["depth_map"][0], g["depth"]) < 1e-4
+    # hull mask of the hit rays, bit for bit
+    pts, z = O.sampling_points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], 32)
+    vm = O.hull_mask(pts.reshape(-1, 3), b["tar_smpl_vertice"][0]).view(-1, 32)
+    hit = vm.sum(-1) > 0
+    assert int(hit.sum()) == int(g["hit_rays"])
+    assert np.array_equal(np.packbits(vm[hit].numpy()), g["mask_bits"])
+
+
+def test_g12_mesh_cube():
+    g = gold("g12_mesh_cube")
+    b = synth.make_batch(32, 32, 3, seed=0)
+    grid = synth.make_grid_pts(b, 20)
+    sd = make_sd()
+    hol, pix = O.encoder_forward(sd, b["input_imgs"][0][0])
+    off, mem = csr(synth_assign(300))
+    cube = O.render_sigma_grid(sd, b, grid, hol, pix, off, mem, can_centres64(synth_assign(300)))
+    assert maxdiff(cube, g["cube"]) < 2e-5
+    assert int((g["cube"] != 0).sum()) > 500

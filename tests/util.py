@@ -1,0 +1,75 @@
+"""Shared helpers for the test-suite (golden loading, deterministic weights)."""
+import functools
+import os
+
+import numpy as np
+import torch
+
+from transhuman_amd import synth
+from transhuman_amd.config import get_cfg
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SIGMA_BIAS = -1.7         # must match oracle/gen_golden.py
+
+
+def gold(name):
+    d = np.load(os.path.join(GOLD, name + ".npz"))
+    return {k: (torch.from_numpy(d[k]) if d[k].dtype != np.uint8 or d[k].ndim == 0 else d[k]) for k in d.files}
+
+
+@functools.lru_cache(maxsize=None)
+def body():
+    v, _ = synth.make_body(0)
+    return v
+
+
+def can64():
+    return torch.from_numpy(body().astype(np.float64) * 1.02 + 0.001)
+
+
+@functools.lru_cache(maxsize=None)
+def synth_assign(k):
+    d = np.load(os.path.join(GOLD, "synth_assign.npz"))
+    return d[f"assign_{k}"].astype(np.int64)
+
+
+@functools.lru_cache(maxsize=None)
+def real_assign(k):
+    d = np.load(os.path.join(GOLD, "kmeans_pc2voxel.npz"))
+    return d[f"pc2voxel_{k}"].astype(np.int64)
+
+
+def csr(assign):
+    return synth.csr_from_assign(assign)
+
+
+def can_centres64(assign):
+    off, mem = csr(assign)
+    c = can64()
+    return torch.stack([c[torch.as_tensor(mem[off[i]:off[i + 1]], dtype=torch.long)].mean(0) for i in range(len(off) - 1)])
+
+
+@functools.lru_cache(maxsize=None)
+def _net_cached(depth):
+    from transhuman_amd.networks.cross_transformer import Network
+    cfg = get_cfg()
+    cfg.vit_depth = depth
+    torch.manual_seed(0)
+    net = Network()
+    sd = synth.det_state_dict(net.state_dict(), seed=0, sigma_bias=SIGMA_BIAS)
+    net.load_state_dict(sd)
+    net.train()
+    return net
+
+
+def make_net(depth=12):
+    """Product Network with the deterministic weights the goldens were made with."""
+    return _net_cached(depth)
+
+
+def make_sd(depth=12):
+    return {k: v.clone() for k, v in make_net(depth).state_dict().items()}
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max())

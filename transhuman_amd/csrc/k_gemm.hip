@@ -1,0 +1,207 @@
+// Dense layer on the fp32 matrix pipe: C[M,N] = act(A[M,K] W^T + b) (+C).
+//
+// Replaces every torch Conv1d(k=1)/Linear GEMM of the hot path
+// (cross_transformer.py:315-351 and vision_transformer.py:271-279,250-253).
+// Numerics: v_mfma_f32_16x16x4_f32 is bit-for-bit an fp32 fmaf chain, i.e. the
+// same precision class as the reference's cuBLAS/cuDNN fp32 GEMMs (no TF32
+// exists on gfx950).  Roofline: fp32 MFMA, 157.3 TFLOP/s.
+//
+// Tiling (wave64, 4 waves / workgroup):
+//   workgroup tile 64 rows x (4 waves * NT * 16) columns, K in chunks of 128;
+//   each wave owns 4 row tiles x NT column tiles of 16x16 (f32x4 accumulators);
+//   A chunk  [64][128] staged in LDS with a +4 float row pad (b128 fragment
+//   reads, <=2-way bank conflicts);
+//   B (weights) pre-packed by th_pack_linear into the exact per-lane fragment
+//   image, so one coalesced 1 KiB global_load_dwordx4 per wave fetches a whole
+//   16(k) x 16(n) block straight into the MFMA operand registers (weights are
+//   <= 1.2 MB per layer and stay L2-resident; no LDS round trip for them).
+#include "th_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define GEMM_BM 64
+#define GEMM_KC 128
+#define GEMM_LDS_STRIDE (GEMM_KC + 4)
+
+__global__ void pack_linear_kernel(const float* __restrict__ W, const float* __restrict__ b, int N, int K, int NB,
+                                   int KB, float* __restrict__ wp, float* __restrict__ bp) {
+    long long total = (long long)NB * KB * 256;
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        int e = (int)(o & 3);
+        int lane = (int)((o >> 2) & 63);
+        long long blk = o >> 8;
+        int kb = (int)(blk % KB);
+        int nb = (int)(blk / KB);
+        int n = nb * 16 + (lane & 15);
+        int k = kb * 16 + 4 * (lane >> 4) + e;
+        wp[o] = (n < N && k < K) ? W[(long long)n * K + k] : 0.0f;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < NB * 16; i += gridDim.x * blockDim.x)
+        bp[i] = (b != nullptr && i < N) ? b[i] : 0.0f;
+}
+
+int th_pack_linear(const th_linear& lin, void* storage, ThPacked* out, hipStream_t s) {
+    TH_REQUIRE(lin.w != nullptr && lin.out_f > 0 && lin.in_f > 0, "bad layer");
+    out->N = lin.out_f;
+    out->K = lin.in_f;
+    out->NB = (lin.out_f + 15) / 16;
+    out->KB = (lin.in_f + 15) / 16;
+    out->w = (float*)storage;
+    out->b = (float*)((char*)storage + th_align((size_t)out->NB * out->KB * 256 * sizeof(float)));
+    long long total = (long long)out->NB * out->KB * 256;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_linear_kernel, dim3(blocks), dim3(256), 0, s, lin.w, lin.b, lin.out_f, lin.in_f, out->NB,
+                       out->KB, out->w, out->b);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+__device__ __forceinline__ float th_gelu_erf(float x) {
+    // nn.GELU (exact): x * 0.5 * (1 + erf(x / sqrt(2)))
+    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, int lda, int M, int Kreal,
+                                                            const float* __restrict__ Wp,
+                                                            const float* __restrict__ bias, int N, int NB, int KB,
+                                                            float* __restrict__ C, int ldc, int flags) {
+    extern __shared__ __attribute__((aligned(16))) float As[];   // [64][GEMM_LDS_STRIDE]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int m0 = blockIdx.x * GEMM_BM;
+    const int nb0 = (blockIdx.y * 4 + wave) * NT;       // first 16-col tile of this wave
+    const bool wave_active = nb0 < NB;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = (KB * 16 + GEMM_KC - 1) / GEMM_KC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = ch * GEMM_KC;
+        // ---- stage A[m0:m0+64, k0:k0+128] -> LDS (zero fill outside M x Kreal) ----
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int idx = tid + 256 * i;
+            int row = idx >> 5;
+            int c4 = idx & 31;
+            int gm = m0 + row;
+            int gk = k0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gm < M) {
+                const float* src = A + (long long)gm * lda + gk;
+                if (gk + 3 < Kreal) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (gk < Kreal) v.x = src[0];
+                    if (gk + 1 < Kreal) v.y = src[1];
+                    if (gk + 2 < Kreal) v.z = src[2];
+                }
+            }
+            *reinterpret_cast<float4*>(&As[row * GEMM_LDS_STRIDE + 4 * c4]) = v;
+        }
+        __syncthreads();
+        if (wave_active) {
+            int kb_lo = ch * (GEMM_KC / 16);
+            int kb_hi = kb_lo + GEMM_KC / 16;
+            if (kb_hi > KB) kb_hi = KB;
+            f32x4 bcur[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                int nb = nb0 + j;
+                bcur[j] = (nb < NB) ? *reinterpret_cast<const f32x4*>(Wp + ((long long)nb * KB + kb_lo) * 256 + lane * 4)
+                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            for (int kb = kb_lo; kb < kb_hi; ++kb) {
+                f32x4 bnext[NT];
+                const bool more = (kb + 1 < kb_hi);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    int nb = nb0 + j;
+                    bnext[j] = (more && nb < NB)
+                                   ? *reinterpret_cast<const f32x4*>(Wp + ((long long)nb * KB + kb + 1) * 256 + lane * 4)
+                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                f32x4 a[4];
+                const int kl = (kb - kb_lo) * 16 + 4 * (lane >> 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    a[i] = *reinterpret_cast<const f32x4*>(&As[(i * 16 + (lane & 15)) * GEMM_LDS_STRIDE + kl]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], bcur[j][e], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bcur[j] = bnext[j];
+            }
+        }
+        __syncthreads();
+    }
+
+    if (!wave_active) return;
+    const int act = flags & 15;
+    const bool accum = (flags & TH_GEMM_ACCUM) != 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int col = (nb0 + j) * 16 + (lane & 15);
+        if (col >= N) continue;
+        float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = m0 + i * 16 + 4 * (lane >> 4) + r;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (act == TH_ACT_RELU) v = fmaxf(v, 0.0f);
+                    else if (act == TH_ACT_GELU) v = th_gelu_erf(v);
+                    float* dst = C + (long long)row * ldc + col;
+                    if (accum) v = *dst + v;
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+static int pick_nt(int NB) {
+    // columns per workgroup = 4 waves * NT tiles; minimise padded tiles, prefer big NT
+    int best = 1, best_waste = 1 << 30;
+    for (int nt = 4; nt >= 1; --nt) {
+        int per = 4 * nt;
+        int blocks = (NB + per - 1) / per;
+        int waste = blocks * per - NB;
+        if (waste < best_waste) { best_waste = waste; best = nt; }
+    }
+    return best;
+}
+
+int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float* C, int ldc, hipStream_t s) {
+    if (M <= 0) return 0;
+    TH_REQUIRE((lda & 3) == 0 && (((uintptr_t)A) & 15) == 0, "A must be 16-byte aligned with lda % 4 == 0");
+    TH_REQUIRE(W.w != nullptr, "weights not packed");
+    int nt = pick_nt(W.NB);
+    dim3 grid(th_cdiv(M, GEMM_BM), th_cdiv(W.NB, 4 * nt));
+    size_t lds = GEMM_BM * GEMM_LDS_STRIDE * sizeof(float);
+#define LAUNCH(NT_)                                                                                             \
+    hipLaunchKernelGGL(gemm_f32_mfma_kernel<NT_>, grid, dim3(256), lds, s, A, lda, M, W.K, W.w, W.b, W.N, W.NB, \
+                       W.KB, C, ldc, flags)
+    switch (nt) {
+        case 4: LAUNCH(4); break;
+        case 3: LAUNCH(3); break;
+        case 2: LAUNCH(2); break;
+        default: LAUNCH(1); break;
+    }
+#undef LAUNCH
+    TH_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,87 @@
+// K5: pixel-aligned feature gather.
+//
+// get_pixel_aligned_feature (if_clight_renderer.py:210-269): project a world
+// point into the V reference cameras and bilinearly sample the 384-channel
+// pixel_feat_map (grid_sample, align_corners=True, border).  The reference
+// samples an NCHW map for *all* chunk points (384 strided cache lines per
+// corner) and masks afterwards (cross_transformer.py:235); here the map is
+// channels-last (th_nchw_to_nhwc, once per frame) so each corner is one
+// contiguous 1.5 KB read, and only hull-valid samples are gathered.
+// One wave per (sample, view) row; lanes span channels (float2 x 3 per lane).
+// Bound: L2/HBM gather, 4 * 1536 B per (sample, view) in, 1536 B out.
+#include "th_internal.h"
+
+__global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict__ map, int V, int C, int H, int W,
+                                                        const float* __restrict__ pts_world, ThPointSrc ps,
+                                                        const int32_t* __restrict__ sel, int P,
+                                                        const float* __restrict__ cams,
+                                                        const float* __restrict__ scale, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);     // (sample, view)
+    if (row >= (long long)P * V) return;
+    int p = (int)(row / V), v = (int)(row % V);
+    long long q = sel ? sel[p] : p;
+    float x, y, z;
+    if (pts_world) { x = pts_world[3 * q]; y = pts_world[3 * q + 1]; z = pts_world[3 * q + 2]; }
+    else th_get_point(ps, q, x, y, z);
+    float uu, vv;
+    th_project(cams + 21 * v, x, y, z, uu, vv);
+    Bilin b = th_bilinear_setup(uu, vv, scale[0], scale[1], H, W);
+    const float* m = map + (long long)v * H * W * C;
+    const float2* p00 = reinterpret_cast<const float2*>(m + (long long)b.i00 * C);
+    const float2* p01 = reinterpret_cast<const float2*>(m + (long long)b.i01 * C);
+    const float2* p10 = reinterpret_cast<const float2*>(m + (long long)b.i10 * C);
+    const float2* p11 = reinterpret_cast<const float2*>(m + (long long)b.i11 * C);
+    float2* o = reinterpret_cast<float2*>(out + row * C);
+    for (int c2 = lane; c2 < C / 2; c2 += 64) {
+        float2 a = p00[c2], bb = p01[c2], cc = p10[c2], d = p11[c2];
+        float2 r;
+        r.x = a.x * b.w00; r.x = r.x + bb.x * b.w01; r.x = r.x + cc.x * b.w10; r.x = r.x + d.x * b.w11;
+        r.y = a.y * b.w00; r.y = r.y + bb.y * b.w01; r.y = r.y + cc.y * b.w10; r.y = r.y + d.y * b.w11;
+        o[c2] = r;
+    }
+}
+
+int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world, const ThPointSrc* ps,
+                        const int32_t* sel, int P, const float* cams, const float* scale, float* out,
+                        hipStream_t s) {
+    if (P <= 0) return 0;
+    TH_REQUIRE((C & 1) == 0, "channel count must be even");
+    ThPointSrc src = ps ? *ps : ThPointSrc{};
+    long long rows = (long long)P * V;
+    hipLaunchKernelGGL(pixgather_kernel, dim3(th_cdiv(rows, 4)), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel,
+                       P, cams, scale, out);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+// Network.forward drop-in path: the caller already sampled pixel_feat as
+// [V, C, Pall] (channel-major, cross_transformer.py:235 masks it).  Gather the
+// selected points and transpose to rows [P][V][C] through LDS tiles.
+__global__ __launch_bounds__(256) void gather_chan_major_kernel(const float* __restrict__ pf, int V, int C,
+                                                                long long Pall, const int32_t* __restrict__ sel,
+                                                                int P, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    int v = blockIdx.z;
+    int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    int p = p0 + tx;
+    long long q = (p < P) ? (sel ? (long long)sel[p] : (long long)p) : -1;
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r;
+        tile[r][tx] = (q >= 0 && c < C) ? pf[((long long)v * C + c) * Pall + q] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int pp = p0 + r, c = c0 + tx;
+        if (pp < P && c < C) out[((long long)pp * V + v) * C + c] = tile[tx][r];
+    }
+}
+int th_gather_chan_major_launch(const float* pf, int V, int C, long long Pall, const int32_t* sel, int P, float* out,
+                                hipStream_t s) {
+    if (P <= 0) return 0;
+    hipLaunchKernelGGL(gather_chan_major_kernel, dim3(th_cdiv(P, 32), th_cdiv(C, 32), V), dim3(256), 0, s, pf, V, C,
+                       Pall, sel, P, out);
+    TH_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,442 @@
+// C-ABI of libtranshuman_hip.so: context, weight packing, per-kernel entry
+// points and the frame-level orchestration (th_render_rays /
+// th_eval_sigma_grid / th_network_forward).  See include/transhuman_hip.h.
+#include <string.h>
+
+#include <vector>
+
+#include "th_internal.h"
+
+static thread_local std::string g_err;
+void th_set_error(const std::string& msg) { g_err = msg; }
+
+extern "C" {
+
+int th_abi_version(void) { return TH_ABI_VERSION; }
+const char* th_last_error(void) { return g_err.c_str(); }
+
+int th_ctx_create(int device, th_ctx** out) {
+    TH_REQUIRE(out != nullptr, "null out");
+    int count = 0;
+    TH_HIP(hipGetDeviceCount(&count));
+    TH_REQUIRE(device >= 0 && device < count, "no such device");
+    TH_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    TH_HIP(hipGetDeviceProperties(&prop, device));
+    TH_REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0,
+               std::string("libtranshuman_hip is built for gfx950 only, device is ") + prop.gcnArchName);
+    th_ctx* c = new th_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount;
+    TH_HIP(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(int32_t), hipHostMallocDefault));
+    *out = c;
+    return 0;
+}
+
+void th_ctx_destroy(th_ctx* c) {
+    if (!c) return;
+    if (c->mlp_store) (void)hipFree(c->mlp_store);
+    if (c->vit_store) (void)hipFree(c->vit_store);
+    if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    delete[] c->vit.blocks;
+    delete c;
+}
+
+// ---------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------
+static bool lin_ok(const th_linear& l, int out_f, int in_f) {
+    return l.w != nullptr && l.out_f == out_f && l.in_f == in_f;
+}
+
+int th_set_mlp_weights(th_ctx* c, const th_mlp_weights* w, th_stream stream) {
+    TH_REQUIRE(c && w, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    // shapes of cross_transformer.py:96-126
+    TH_REQUIRE(lin_ok(w->fc_0, 256, 255) && lin_ok(w->alpha_res_0, 256, 384) && lin_ok(w->key0, 128, 256) &&
+                   lin_ok(w->val0, 256, 256) && lin_ok(w->key1, 128, 256) && lin_ok(w->val1, 256, 256) &&
+                   lin_ok(w->fc_1, 256, 256) && lin_ok(w->fc_2, 256, 256) && lin_ok(w->fc_3, 256, 256) &&
+                   lin_ok(w->alpha_fc, 1, 256) && lin_ok(w->feature_fc, 256, 256) &&
+                   lin_ok(w->rgb_res_0, 256, 384) && lin_ok(w->view_fc, 128, 283) &&
+                   lin_ok(w->rgb_res_1, 128, 384) && lin_ok(w->fc_4, 128, 128) && lin_ok(w->rgb_fc, 3, 128),
+               "unexpected layer shape (expects the reference Network of cross_transformer.py:96-126)");
+    struct Item { const th_linear* l; ThPacked* dst; int out_f, in_f; };
+    ThMlpPacked& M = c->mlp;
+    size_t total = 0;
+    Item items[] = {{&w->fc_0, &M.fc_0, 256, 255},          {&w->alpha_res_0, &M.alpha_res_0, 256, 384},
+                    {nullptr, &M.kv0, 384, 256},            {nullptr, &M.kv1, 384, 256},
+                    {&w->fc_1, &M.fc_1, 256, 256},          {&w->fc_2, &M.fc_2, 256, 256},
+                    {&w->fc_3, &M.fc_3, 256, 256},          {&w->feature_fc, &M.feature_fc, 256, 256},
+                    {&w->rgb_res_0, &M.rgb_res_0, 256, 384}, {&w->view_fc, &M.view_fc, 128, 283},
+                    {&w->rgb_res_1, &M.rgb_res_1, 128, 384}, {&w->fc_4, &M.fc_4, 128, 128}};
+    for (auto& it : items) total += ThPacked::bytes(it.out_f, it.in_f);
+    size_t heads_off = total;
+    total += th_align((256 + 1 + 3 * 128 + 3) * sizeof(float));
+    size_t tmp_off = total;
+    total += 2 * th_align((size_t)(384 * 256 + 384) * sizeof(float));   // concat scratch for kv0 / kv1
+    if (c->mlp_store) { TH_HIP(hipFree(c->mlp_store)); c->mlp_store = nullptr; }
+    TH_HIP(hipMalloc(&c->mlp_store, total));
+    char* base = (char*)c->mlp_store;
+    size_t off = 0;
+    int kv_i = 0;
+    for (auto& it : items) {
+        th_linear src;
+        if (it.l) src = *it.l;
+        else {
+            // [key_embed ; value_embed] stacked along out_f -> one 256 -> 384 layer
+            const th_linear& k = kv_i == 0 ? w->key0 : w->key1;
+            const th_linear& v = kv_i == 0 ? w->val0 : w->val1;
+            float* tw = (float*)(base + tmp_off + kv_i * th_align((size_t)(384 * 256 + 384) * sizeof(float)));
+            float* tb = tw + 384 * 256;
+            TH_HIP(hipMemcpyAsync(tw, k.w, 128 * 256 * 4, hipMemcpyDeviceToDevice, s));
+            TH_HIP(hipMemcpyAsync(tw + 128 * 256, v.w, 256 * 256 * 4, hipMemcpyDeviceToDevice, s));
+            if (k.b) TH_HIP(hipMemcpyAsync(tb, k.b, 128 * 4, hipMemcpyDeviceToDevice, s));
+            else TH_HIP(hipMemsetAsync(tb, 0, 128 * 4, s));
+            if (v.b) TH_HIP(hipMemcpyAsync(tb + 128, v.b, 256 * 4, hipMemcpyDeviceToDevice, s));
+            else TH_HIP(hipMemsetAsync(tb + 128, 0, 256 * 4, s));
+            src.w = tw; src.b = tb; src.out_f = 384; src.in_f = 256;
+            ++kv_i;
+        }
+        TH_TRY(th_pack_linear(src, base + off, it.dst, s));
+        off += ThPacked::bytes(it.out_f, it.in_f);
+    }
+    float* hd = (float*)(base + heads_off);
+    M.alpha_w = hd; M.alpha_b = hd + 256; M.rgb_w = hd + 257; M.rgb_b = hd + 257 + 384;
+    TH_HIP(hipMemcpyAsync(M.alpha_w, w->alpha_fc.w, 256 * 4, hipMemcpyDeviceToDevice, s));
+    TH_HIP(hipMemcpyAsync(M.rgb_w, w->rgb_fc.w, 384 * 4, hipMemcpyDeviceToDevice, s));
+    if (w->alpha_fc.b) TH_HIP(hipMemcpyAsync(M.alpha_b, w->alpha_fc.b, 4, hipMemcpyDeviceToDevice, s));
+    else TH_HIP(hipMemsetAsync(M.alpha_b, 0, 4, s));
+    if (w->rgb_fc.b) TH_HIP(hipMemcpyAsync(M.rgb_b, w->rgb_fc.b, 12, hipMemcpyDeviceToDevice, s));
+    else TH_HIP(hipMemsetAsync(M.rgb_b, 0, 12, s));
+    TH_HIP(hipStreamSynchronize(s));
+    M.ready = true;
+    return 0;
+}
+
+int th_set_vit_weights(th_ctx* c, int depth, int dim, int heads, const th_vit_block* blocks, const float* norm_w,
+                       const float* norm_b, th_stream stream) {
+    TH_REQUIRE(c && blocks && norm_w && norm_b, "null argument");
+    TH_REQUIRE(depth > 0 && dim == heads * 64, "ViT must have head_dim 64");
+    hipStream_t s = (hipStream_t)stream;
+    size_t per = ThPacked::bytes(3 * dim, dim) + ThPacked::bytes(dim, dim) + ThPacked::bytes(4 * dim, dim) +
+                 ThPacked::bytes(dim, 4 * dim) + th_align(4 * dim * sizeof(float));
+    size_t total = per * depth + th_align(2 * dim * sizeof(float));
+    if (c->vit_store) { TH_HIP(hipFree(c->vit_store)); c->vit_store = nullptr; }
+    TH_HIP(hipMalloc(&c->vit_store, total));
+    delete[] c->vit.blocks;
+    c->vit.blocks = new ThVitBlockPacked[depth];
+    c->vit.depth = depth; c->vit.dim = dim; c->vit.heads = heads;
+    char* base = (char*)c->vit_store;
+    size_t off = 0;
+    for (int b = 0; b < depth; ++b) {
+        const th_vit_block& B = blocks[b];
+        ThVitBlockPacked& P = c->vit.blocks[b];
+        TH_REQUIRE(lin_ok(B.qkv, 3 * dim, dim) && lin_ok(B.proj, dim, dim) && lin_ok(B.fc1, 4 * dim, dim) &&
+                       lin_ok(B.fc2, dim, 4 * dim) && B.ln1_w && B.ln1_b && B.ln2_w && B.ln2_b,
+                   "unexpected ViT block shape");
+        TH_TRY(th_pack_linear(B.qkv, base + off, &P.qkv, s)); off += ThPacked::bytes(3 * dim, dim);
+        TH_TRY(th_pack_linear(B.proj, base + off, &P.proj, s)); off += ThPacked::bytes(dim, dim);
+        TH_TRY(th_pack_linear(B.fc1, base + off, &P.fc1, s)); off += ThPacked::bytes(4 * dim, dim);
+        TH_TRY(th_pack_linear(B.fc2, base + off, &P.fc2, s)); off += ThPacked::bytes(dim, 4 * dim);
+        float* ln = (float*)(base + off); off += th_align(4 * dim * sizeof(float));
+        P.ln1_w = ln; P.ln1_b = ln + dim; P.ln2_w = ln + 2 * dim; P.ln2_b = ln + 3 * dim;
+        TH_HIP(hipMemcpyAsync(P.ln1_w, B.ln1_w, dim * 4, hipMemcpyDeviceToDevice, s));
+        TH_HIP(hipMemcpyAsync(P.ln1_b, B.ln1_b, dim * 4, hipMemcpyDeviceToDevice, s));
+        TH_HIP(hipMemcpyAsync(P.ln2_w, B.ln2_w, dim * 4, hipMemcpyDeviceToDevice, s));
+        TH_HIP(hipMemcpyAsync(P.ln2_b, B.ln2_b, dim * 4, hipMemcpyDeviceToDevice, s));
+    }
+    float* nf = (float*)(base + off);
+    c->vit.norm_w = nf; c->vit.norm_b = nf + dim;
+    TH_HIP(hipMemcpyAsync(c->vit.norm_w, norm_w, dim * 4, hipMemcpyDeviceToDevice, s));
+    TH_HIP(hipMemcpyAsync(c->vit.norm_b, norm_b, dim * 4, hipMemcpyDeviceToDevice, s));
+    TH_HIP(hipStreamSynchronize(s));
+    c->vit.ready = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// building blocks
+// ---------------------------------------------------------------------------
+size_t th_linear_workspace_bytes(int out_f, int in_f) { return ThPacked::bytes(out_f, in_f); }
+
+int th_linear_forward(th_ctx* c, const float* A, int lda, int M, const th_linear* lin, int act, float* C, int ldc,
+                      void* ws, size_t ws_bytes, th_stream stream) {
+    TH_REQUIRE(c && A && lin && C && ws, "null argument");
+    TH_REQUIRE(ws_bytes >= ThPacked::bytes(lin->out_f, lin->in_f), "workspace too small");
+    TH_REQUIRE(act >= 0 && act <= 2, "act must be 0 (none), 1 (relu) or 2 (gelu)");
+    ThPacked P;
+    TH_TRY(th_pack_linear(*lin, ws, &P, (hipStream_t)stream));
+    return th_gemm(A, lda, M, P, act, C, ldc, (hipStream_t)stream);
+}
+
+size_t th_hull_workspace_bytes(int n_verts) { return th_hull_ws(n_verts); }
+
+int th_hull_mask(th_ctx* c, const th_points* p, const float* verts, int nv, float thresh, uint8_t* mask,
+                 int32_t* ray_hit, void* ws, size_t ws_bytes, th_stream stream) {
+    TH_REQUIRE(c && p && verts && mask && ws, "null argument");
+    TH_REQUIRE(p->pts || (p->ray_o && p->ray_d && p->near && p->far && p->t_vals && p->one_minus_t),
+               "need explicit pts or a complete ray description");
+    ThPointSrc ps = th_src(p);
+    long long P = (long long)p->R * p->S;
+    return th_hull_mask_launch(ps, P, verts, nv, thresh, mask, ray_hit, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int th_paint_group(th_ctx* c, const float* map, int V, int C, int H, int W, const float* verts, int nv,
+                   const float* cams, const float* scale, const uint8_t* viz, const int32_t* off, const int32_t* mem,
+                   int nc, float* painted, float* tokens, th_stream stream) {
+    TH_REQUIRE(c && map && verts && cams && scale && off && mem && tokens, "null argument");
+    TH_REQUIRE(painted != nullptr, "painted_out scratch [V,n_verts,C] is required");
+    hipStream_t s = (hipStream_t)stream;
+    TH_TRY(th_paint_launch(map, V, C, H, W, verts, nv, cams, scale, viz, painted, s));
+    return th_segmean_launch(painted, V, (long long)nv * C, C, off, mem, nc, tokens, s);
+}
+
+int th_segment_mean_f32(th_ctx* c, const float* src, int width, const int32_t* off, const int32_t* mem, int nc,
+                        float* out, th_stream stream) {
+    TH_REQUIRE(c && src && off && mem && out, "null argument");
+    return th_segmean_launch(src, 1, 0, width, off, mem, nc, out, (hipStream_t)stream);
+}
+
+int th_segment_mean_rot_f64(th_ctx* c, const double* blend, const int32_t* off, const int32_t* mem, int nc,
+                            float* rot, th_stream stream) {
+    TH_REQUIRE(c && blend && off && mem && rot, "null argument");
+    return th_segmean_rot_launch(blend, off, mem, nc, rot, (hipStream_t)stream);
+}
+
+size_t th_vit_workspace_bytes(int V, int N, int dim, int heads) { return th_vit_ws(V, N, dim, heads); }
+
+int th_vit_forward(th_ctx* c, const float* x, const float* pe, int V, int N, float* out, void* ws, size_t ws_bytes,
+                   th_stream stream) {
+    TH_REQUIRE(c && x && pe && out && ws, "null argument");
+    return th_vit_launch(c->vit, x, pe, V, N, out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int th_dparf_encode(th_ctx* c, const float* pts, const int32_t* sel, int P, const float* centres, const float* rot,
+                    const float* tokens, int V, int nc, float* out, th_stream stream) {
+    TH_REQUIRE(c && pts && centres && rot && tokens && out, "null argument");
+    return th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, P, centres, rot, tokens, V, nc, 0.5f, out,
+                           (hipStream_t)stream);
+}
+
+int th_nchw_to_nhwc(th_ctx* c, const float* src, int V, int C, int H, int W, float* dst, th_stream stream) {
+    TH_REQUIRE(c && src && dst, "null argument");
+    return th_nchw_to_nhwc_launch(src, V, C, H, W, dst, (hipStream_t)stream);
+}
+
+int th_pixel_gather(th_ctx* c, const float* map, int V, int C, int H, int W, const float* pts, const int32_t* sel,
+                    int P, const float* cams, const float* scale, float* out, th_stream stream) {
+    TH_REQUIRE(c && map && pts && cams && scale && out, "null argument");
+    return th_pixgather_launch(map, V, C, H, W, pts, nullptr, sel, P, cams, scale, out, (hipStream_t)stream);
+}
+
+int th_composite(th_ctx* c, const float* raw, const float* z, const th_points* rays, int white, float* rgb,
+                 float* acc, float* depth, float* wout, th_stream stream) {
+    TH_REQUIRE(c && raw && rays && rgb && acc && depth, "null argument");
+    TH_REQUIRE(rays->ray_d != nullptr, "ray_d required");
+    TH_REQUIRE(z || (rays->near && rays->far && rays->t_vals && rays->one_minus_t), "need z or near/far/t_vals");
+    return th_composite_launch(raw, z, th_src(rays), white, rgb, acc, depth, wout, (hipStream_t)stream);
+}
+
+int th_view_embed(th_ctx* c, const float* d, int R, int res, float* out, th_stream stream) {
+    TH_REQUIRE(c && d && out, "null argument");
+    return th_view_embed_launch(d, R, res, out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// chunked per-sample stage shared by the three frame-level entry points
+// ---------------------------------------------------------------------------
+static const int TH_CHUNK = 32768;   // samples per MLP pass (same as batchify_rays chunk, :575)
+
+struct ChunkBufs {
+    float *h, *f, *vdc, *raw_c;
+    void* mlp_ws;
+    size_t mlp_ws_bytes;
+};
+static size_t chunk_bytes(int V, int CH) {
+    size_t rows = (size_t)V * CH;
+    return th_align(rows * 256 * 4) + th_align(rows * 384 * 4) + th_align((size_t)CH * 27 * 4) +
+           th_align((size_t)CH * 4 * 4) + th_mlp_ws(V, CH);
+}
+static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
+    size_t rows = (size_t)V * CH;
+    b->h = ar.take<float>(rows * 256);
+    b->f = ar.take<float>(rows * 384);
+    b->vdc = ar.take<float>((size_t)CH * 27);
+    b->raw_c = ar.take<float>((size_t)CH * 4);
+    b->mlp_ws_bytes = th_mlp_ws(V, CH);
+    b->mlp_ws = ar.take<char>(b->mlp_ws_bytes);
+    TH_REQUIRE(b->mlp_ws != nullptr, "workspace too small");
+    return 0;
+}
+
+size_t th_network_workspace_bytes(int V, int P) {
+    int CH = P < TH_CHUNK ? (P > 0 ? P : 1) : TH_CHUNK;
+    return chunk_bytes(V, CH) + th_align((size_t)P * 4) + th_compact_ws(P) + th_align(64);
+}
+
+int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir, const float* pts_smpl,
+                       const uint8_t* mask, int P, const float* centres, const float* rot, const float* tokens,
+                       int V, int nc, float* raw_out, void* ws, size_t ws_bytes, th_stream stream) {
+    TH_REQUIRE(c && pixel_feat && viewdir && pts_smpl && centres && rot && tokens && raw_out && ws, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (P <= 0) return 0;
+    TH_REQUIRE(ws_bytes >= th_network_workspace_bytes(V, P), "workspace too small");
+    ThArena ar(ws, ws_bytes);
+    int CH = P < TH_CHUNK ? P : TH_CHUNK;
+    ChunkBufs cb;
+    TH_TRY(chunk_carve(ar, V, CH, &cb));
+    int32_t* idx = nullptr;
+    int n = P;
+    if (mask) {
+        idx = ar.take<int32_t>((size_t)P);
+        void* cws = ar.take<char>(th_compact_ws(P));
+        int32_t* dcount = ar.take<int32_t>(16);
+        TH_REQUIRE(dcount != nullptr, "workspace too small");
+        TH_TRY(th_compact_mask(mask, P, idx, dcount, cws, th_compact_ws(P), s));
+        TH_HIP(hipMemsetAsync(raw_out, 0, (size_t)P * 16, s));     // raw_temp zeros, :231
+        TH_HIP(hipMemcpyAsync(c->host_pinned, dcount, 4, hipMemcpyDeviceToHost, s));
+        TH_HIP(hipStreamSynchronize(s));                           // the reference syncs here too (:232)
+        n = c->host_pinned[0];
+    }
+    for (int o = 0; o < n; o += CH) {
+        int m = (n - o) < CH ? (n - o) : CH;
+        const int32_t* sel = idx ? idx + o : nullptr;
+        const float* pts = idx ? pts_smpl : pts_smpl + 3LL * o;
+        TH_TRY(th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, m, centres, rot, tokens, V, nc, 0.5f, cb.h, s));
+        if (idx) {
+            TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, s));
+            TH_TRY(th_gather_rows_launch(viewdir, 27, sel, 1, m, cb.vdc, s));
+        } else {
+            TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, s));
+            TH_TRY(th_gather_rows_launch(viewdir + 27LL * o, 27, nullptr, 1, m, cb.vdc, s));
+        }
+        TH_TRY(th_mlp_forward(c->mlp, V, m, cb.h, cb.f, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s));
+        if (idx) TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, 0, raw_out, s));
+        else TH_TRY(th_scatter_raw_launch(cb.raw_c, nullptr, m, 1, raw_out + 4LL * o, s));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// frame-level
+// ---------------------------------------------------------------------------
+static int frame_ok(const th_frame* f) {
+    TH_REQUIRE(f->verts_world && f->Rh && f->Th && f->cams && f->scale_xy && f->pixel_map_nhwc && f->tokens &&
+                   f->centres && f->rot,
+               "incomplete th_frame");
+    TH_REQUIRE(f->V >= 1 && f->V <= 4, "supported reference-view counts: 1..4");
+    return 0;
+}
+
+static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
+    int CH = P < TH_CHUNK ? (int)(P > 0 ? P : 1) : TH_CHUNK;
+    return th_align((size_t)P) + th_align((size_t)R * 4) + th_hull_ws(f->n_verts) + th_compact_ws(P) +
+           th_align((size_t)P * 4) + th_align(64) + th_align((size_t)R * 27 * 4) + th_align((size_t)P * 16) +
+           chunk_bytes(f->V, CH);
+}
+
+// hull mask -> (small-frame rule) -> compaction -> chunked DPaRF + gather + MLP -> dense raw[P,4]
+static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long long P, bool ray_mode, ThArena& ar,
+                        float** raw_out, int64_t* stats_host, hipStream_t s) {
+    const int R = ps.R, S = ps.S, V = f->V;
+    uint8_t* mask = ar.take<uint8_t>((size_t)P);
+    int32_t* ray_hit = ar.take<int32_t>((size_t)R);
+    size_t hws_b = th_hull_ws(f->n_verts);
+    void* hws = ar.take<char>(hws_b);
+    size_t cws_b = th_compact_ws(P);
+    void* cws = ar.take<char>(cws_b);
+    int32_t* idx = ar.take<int32_t>((size_t)P);
+    int32_t* info = ar.take<int32_t>(16);
+    float* vd_all = ar.take<float>((size_t)R * 27);
+    float* raw = ar.take<float>((size_t)P * 4);
+    int CH = P < TH_CHUNK ? (int)P : TH_CHUNK;
+    ChunkBufs cb;
+    TH_REQUIRE(raw != nullptr, "workspace too small");
+    TH_TRY(chunk_carve(ar, V, CH, &cb));
+
+    TH_HIP(hipMemsetAsync(info, 0, 16 * 4, s));
+    const bool no_hull = f->hull_thresh < 0.f;   // Renderer.render (:486-498): every sample shaded, RGB everywhere
+    if (no_hull) {
+        TH_HIP(hipMemsetAsync(mask, 1, (size_t)P, s));
+        if (ray_mode) TH_HIP(hipMemsetAsync(ray_hit, 1, (size_t)R * 4, s));   // any non-zero marks a hit
+    } else {
+        TH_TRY(th_hull_mask_launch(ps, P, f->verts_world, f->n_verts, f->hull_thresh, mask,
+                                   ray_mode ? ray_hit : nullptr, hws, hws_b, s));
+    }
+    if (ray_mode) {
+        // no_hull: threshold R makes the rule fire -> un-masked mode (rgb for all samples)
+        TH_TRY(th_small_frame_rule(mask, ray_hit, R, S, no_hull ? R : f->small_frame_rays, info, s));
+        TH_TRY(th_view_embed_launch(ps.ray_d, R, 4, vd_all, s));
+    }
+    TH_TRY(th_compact_mask(mask, P, idx, info + 2, cws, cws_b, s));
+    TH_HIP(hipMemsetAsync(raw, 0, (size_t)P * 16, s));
+    TH_HIP(hipMemcpyAsync(c->host_pinned, info, 4 * 4, hipMemcpyDeviceToHost, s));
+    TH_HIP(hipStreamSynchronize(s));
+    const int hit_rays = c->host_pinned[0], unmasked = c->host_pinned[1], n = c->host_pinned[2];
+    if (stats_host) { stats_host[0] = hit_rays; stats_host[1] = n; stats_host[2] = -1; stats_host[3] = unmasked; }
+    if (!ray_mode) TH_HIP(hipMemsetAsync(cb.vdc, 0, (size_t)CH * 27 * 4, s));   // zero view dirs, if_mesh_renderer.py:62
+    for (int o = 0; o < n; o += CH) {
+        int m = (n - o) < CH ? (n - o) : CH;
+        const int32_t* sel = idx + o;
+        TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, sel, m, f->centres, f->rot, f->tokens, V, f->n_clusters,
+                               0.5f, cb.h, s));
+        TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, 384, f->H, f->W, nullptr, &ps, sel, m, f->cams, f->scale_xy,
+                                   cb.f, s));
+        if (ray_mode) TH_TRY(th_gather_rows_launch(vd_all, 27, sel, S, m, cb.vdc, s));
+        TH_TRY(th_mlp_forward(c->mlp, V, m, cb.h, cb.f, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s));
+        TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));
+    }
+    *raw_out = raw;
+    return 0;
+}
+
+size_t th_render_workspace_bytes(const th_frame* f, int R, int S) {
+    return shade_ws_bytes(f, (long long)R * S, R);
+}
+
+int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* rgb, float* acc, float* depth,
+                   int white_bkgd, void* ws, size_t ws_bytes, int64_t* stats_host, th_stream stream) {
+    TH_REQUIRE(c && f && rays && rgb && acc && depth && ws, "null argument");
+    TH_TRY(frame_ok(f));
+    TH_REQUIRE(rays->pts == nullptr && rays->ray_o && rays->ray_d && rays->near && rays->far && rays->t_vals &&
+                   rays->one_minus_t,
+               "th_render_rays needs a complete ray description");
+    hipStream_t s = (hipStream_t)stream;
+    const int R = rays->R, S = rays->S;
+    if (R <= 0) return 0;
+    long long P = (long long)R * S;
+    TH_REQUIRE(P < (1LL << 31), "R*S must fit in int32");
+    TH_REQUIRE(ws_bytes >= shade_ws_bytes(f, P, R), "workspace too small");
+    ThArena ar(ws, ws_bytes);
+    ThPointSrc ps = th_src(rays);
+    float* raw = nullptr;
+    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, stats_host, s));
+    return th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, s);
+}
+
+__global__ void extract_sigma_kernel(const float4* __restrict__ raw, long long P, float* __restrict__ out) {
+    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < P) out[i] = raw[i].w;
+}
+
+size_t th_sigma_grid_workspace_bytes(const th_frame* f, int P) { return shade_ws_bytes(f, P, P); }
+
+int th_eval_sigma_grid(th_ctx* c, const th_frame* f, const float* pts, int P, float* sigma_out, void* ws,
+                       size_t ws_bytes, int64_t* stats_host, th_stream stream) {
+    TH_REQUIRE(c && f && pts && sigma_out && ws, "null argument");
+    TH_TRY(frame_ok(f));
+    hipStream_t s = (hipStream_t)stream;
+    if (P <= 0) return 0;
+    TH_REQUIRE(ws_bytes >= shade_ws_bytes(f, P, P), "workspace too small");
+    ThArena ar(ws, ws_bytes);
+    ThPointSrc ps{};
+    ps.pts = pts; ps.R = P; ps.S = 1;
+    float* raw = nullptr;
+    TH_TRY(shade_points(c, f, ps, P, false, ar, &raw, stats_host, s));
+    hipLaunchKernelGGL(extract_sigma_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, (const float4*)raw, (long long)P,
+                       sigma_out);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

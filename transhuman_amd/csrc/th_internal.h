@@ -1,0 +1,236 @@
+// Internal declarations shared by the HIP translation units of
+// libtranshuman_hip.so (gfx950 only).  Public ABI: include/transhuman_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+
+#include "transhuman_hip.h"
+
+#define TH_WAVE 64
+
+// ---- error plumbing ---------------------------------------------------------
+void th_set_error(const std::string& msg);
+#define TH_FAIL(msg)                                                                \
+    do {                                                                            \
+        th_set_error(std::string(__func__) + ": " + (msg));                         \
+        return -1;                                                                  \
+    } while (0)
+#define TH_REQUIRE(cond, msg)                                                       \
+    do {                                                                            \
+        if (!(cond)) TH_FAIL(msg);                                                  \
+    } while (0)
+#define TH_HIP(call)                                                                \
+    do {                                                                            \
+        hipError_t e__ = (call);                                                    \
+        if (e__ != hipSuccess) {                                                    \
+            th_set_error(std::string(__func__) + ": " #call " -> " + hipGetErrorString(e__)); \
+            return -2;                                                              \
+        }                                                                           \
+    } while (0)
+#define TH_LAUNCH_CHECK() TH_HIP(hipGetLastError())
+#define TH_TRY(call)                                                                \
+    do {                                                                            \
+        int r__ = (call);                                                           \
+        if (r__ != 0) return r__;                                                   \
+    } while (0)
+
+static inline size_t th_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int th_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Bump allocator over the caller-supplied workspace.
+struct ThArena {
+    char* base;
+    size_t cap, off;
+    ThArena(void* p, size_t n) : base((char*)p), cap(n), off(0) {}
+    template <typename T>
+    T* take(size_t count) {
+        size_t bytes = th_align(count * sizeof(T));
+        if (off + bytes > cap) return nullptr;
+        T* r = (T*)(base + off);
+        off += bytes;
+        return r;
+    }
+};
+
+// ---- packed dense layer (MFMA 16x16x4 f32 B-operand image) --------------------
+// w: [NB][KB][64 lanes][4] with lane = (kq<<4)|j, value = W[nb*16+j][kb*16+4*kq+e]
+// (zero padded); b: [NB*16] zero padded.
+struct ThPacked {
+    float* w = nullptr;
+    float* b = nullptr;
+    int N = 0, K = 0, NB = 0, KB = 0;
+    static size_t bytes(int out_f, int in_f) {
+        size_t nb = (out_f + 15) / 16, kb = (in_f + 15) / 16;
+        return th_align(nb * kb * 256 * sizeof(float)) + th_align(nb * 16 * sizeof(float));
+    }
+};
+
+enum { TH_ACT_NONE = 0, TH_ACT_RELU = 1, TH_ACT_GELU = 2, TH_GEMM_ACCUM = 16 };
+
+int th_pack_linear(const th_linear& lin, void* storage, ThPacked* out, hipStream_t s);
+// C[M,N] = act(A[M,K] W^T + b) (+ C if TH_GEMM_ACCUM)
+int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float* C, int ldc, hipStream_t s);
+
+// ---- point source ---------------------------------------------------------------
+struct ThPointSrc {
+    const float* pts;
+    const float* ray_o;
+    const float* ray_d;
+    const float* near;
+    const float* far;
+    const float* tv;
+    const float* omt;
+    int R, S;
+};
+static inline ThPointSrc th_src(const th_points* p) {
+    ThPointSrc s;
+    s.pts = p->pts; s.ray_o = p->ray_o; s.ray_d = p->ray_d; s.near = p->near; s.far = p->far;
+    s.tv = p->t_vals; s.omt = p->one_minus_t; s.R = p->R; s.S = p->S;
+    return s;
+}
+
+#ifdef __HIPCC__
+// z = near*(1-t) + far*t ; p = o + d*z  -- separate roundings like the torch
+// elementwise ops of if_clight_renderer.py:274,285 (contraction is disabled
+// for the whole library with -ffp-contract=off).
+__device__ __forceinline__ float th_sample_z(const ThPointSrc& ps, int ray, int s) {
+    return ps.near[ray] * ps.omt[s] + ps.far[ray] * ps.tv[s];
+}
+__device__ __forceinline__ void th_get_point(const ThPointSrc& ps, long long i, float& x, float& y, float& z) {
+    if (ps.pts) {
+        x = ps.pts[3 * i]; y = ps.pts[3 * i + 1]; z = ps.pts[3 * i + 2];
+    } else {
+        int ray = (int)(i / ps.S), s = (int)(i % ps.S);
+        float t = th_sample_z(ps, ray, s);
+        x = ps.ray_o[3 * ray] + ps.ray_d[3 * ray] * t;
+        y = ps.ray_o[3 * ray + 1] + ps.ray_d[3 * ray + 1] * t;
+        z = ps.ray_o[3 * ray + 2] + ps.ray_d[3 * ray + 2] * t;
+    }
+}
+
+// ---- projection + bilinear set-up shared by K2 (paint) and K5 (pixel gather) ----
+struct Bilin {
+    int i00, i01, i10, i11;     // linear y*W+x of nw, ne, sw, se (clamped)
+    float w00, w01, w10, w11;   // weights (0 where the corner is out of range)
+};
+
+// uv -> corner indices/weights exactly as torch's grid_sampler_2d does for
+// bilinear / align_corners=True / border padding:
+//   g = uv*scale - 1 ; ix = ((g+1)/2)*(W-1) ; clamp to [0,W-1] ; floor ; weights.
+__device__ __forceinline__ Bilin th_bilinear_setup(float u, float v, float sx, float sy, int H, int W) {
+    float gx = u * sx - 1.0f, gy = v * sy - 1.0f;
+    float ix = ((gx + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((gy + 1.0f) / 2.0f) * (float)(H - 1);
+    ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1));
+    iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+    float x0 = floorf(ix), y0 = floorf(iy);
+    float x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    Bilin b;
+    b.w00 = (x1 - ix) * (y1 - iy);
+    b.w01 = (ix - x0) * (y1 - iy);
+    b.w10 = (x1 - ix) * (iy - y0);
+    b.w11 = (ix - x0) * (iy - y0);
+    int xi0 = (int)x0, yi0 = (int)y0, xi1 = xi0 + 1, yi1 = yi0 + 1;
+    bool bx1 = xi1 <= W - 1, by1 = yi1 <= H - 1;
+    if (!bx1) { b.w01 = 0.f; b.w11 = 0.f; xi1 = W - 1; }
+    if (!by1) { b.w10 = 0.f; b.w11 = 0.f; yi1 = H - 1; }
+    b.i00 = yi0 * W + xi0; b.i01 = yi0 * W + xi1; b.i10 = yi1 * W + xi0; b.i11 = yi1 * W + xi1;
+    return b;
+}
+
+// cams: per view 21 floats  R[9] T[3] K[9]
+__device__ __forceinline__ void th_project(const float* __restrict__ cam, float x, float y, float z, float& u,
+                                           float& v) {
+    float cx = fmaf(cam[2], z, fmaf(cam[1], y, cam[0] * x)) + cam[9];
+    float cy = fmaf(cam[5], z, fmaf(cam[4], y, cam[3] * x)) + cam[10];
+    float cz = fmaf(cam[8], z, fmaf(cam[7], y, cam[6] * x)) + cam[11];
+    const float* K = cam + 12;
+    float px = fmaf(K[2], cz, fmaf(K[1], cy, K[0] * cx));
+    float py = fmaf(K[5], cz, fmaf(K[4], cy, K[3] * cx));
+    float pz = fmaf(K[8], cz, fmaf(K[7], cy, K[6] * cx));
+    u = px / pz;
+    v = py / pz;
+}
+
+#endif
+
+// ---- context ----------------------------------------------------------------------
+struct ThMlpPacked {
+    ThPacked fc_0, alpha_res_0, kv0, kv1, fc_1, fc_2, fc_3, feature_fc, rgb_res_0, view_fc, rgb_res_1, fc_4;
+    // tiny heads kept as plain rows
+    float *alpha_w = nullptr, *alpha_b = nullptr;   // [256], [1]
+    float *rgb_w = nullptr, *rgb_b = nullptr;       // [3*128], [3]
+    bool ready = false;
+};
+struct ThVitBlockPacked {
+    float *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    ThPacked qkv, proj, fc1, fc2;
+};
+struct ThVitPacked {
+    int depth = 0, dim = 0, heads = 0;
+    ThVitBlockPacked* blocks = nullptr;   // host array
+    float *norm_w = nullptr, *norm_b = nullptr;
+    bool ready = false;
+};
+
+struct th_ctx {
+    int device = 0;
+    void* mlp_store = nullptr;
+    void* vit_store = nullptr;
+    ThMlpPacked mlp;
+    ThVitPacked vit;
+    int32_t* host_pinned = nullptr;   // small pinned read-back buffer
+    int n_cu = 256;
+};
+
+// ---- launchers (one group per .hip file) -------------------------------------------
+// k_hull.hip
+size_t th_hull_ws(int n_verts);
+int th_hull_mask_launch(const ThPointSrc& ps, long long P, const float* verts, int nv, float thresh,
+                        uint8_t* mask, int32_t* ray_hit, void* ws, size_t ws_bytes, hipStream_t s);
+// compaction helpers (k_hull.hip)
+size_t th_compact_ws(long long P);
+// counts[0]=n_valid written to dev_count; idx_out ascending
+int th_compact_mask(const uint8_t* mask, long long P, int32_t* idx_out, int32_t* dev_count, void* ws,
+                    size_t ws_bytes, hipStream_t s);
+// small-frame rule: if #hit rays <= thr, mask := ray_hit (all samples of hit rays); dev_info[0]=hit rays, [1]=mode
+int th_small_frame_rule(uint8_t* mask, const int32_t* ray_hit, int R, int S, int thr, int32_t* dev_info,
+                        hipStream_t s);
+
+// k_pool.hip
+int th_paint_launch(const float* map, int V, int C, int H, int W, const float* verts, int nv, const float* cams,
+                    const float* scale, const uint8_t* viz, float* painted, hipStream_t s);
+int th_segmean_launch(const float* src, int batch, long long batch_stride, int width, const int32_t* off,
+                      const int32_t* mem, int nc, float* out, hipStream_t s);
+int th_segmean_rot_launch(const double* blend, const int32_t* off, const int32_t* mem, int nc, float* rot,
+                          hipStream_t s);
+int th_nchw_to_nhwc_launch(const float* src, int V, int C, int H, int W, float* dst, hipStream_t s);
+
+// k_dparf.hip
+int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh, const float* Th,
+                    const int32_t* sel, int P, const float* centres, const float* rot, const float* tokens,
+                    int V, int nc, float alpha, float* out, hipStream_t s);
+// k_pixfeat.hip
+int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world,
+                        const ThPointSrc* ps, const int32_t* sel, int P, const float* cams, const float* scale,
+                        float* out, hipStream_t s);
+int th_gather_chan_major_launch(const float* pf /*[V,C,Pall]*/, int V, int C, long long Pall, const int32_t* sel,
+                                int P, float* out /*[P,V,C]*/, hipStream_t s);
+// k_mlp.hip
+size_t th_mlp_ws(int V, int P);
+// h [P*V,256], f [P*V,384], vd rows [P,27] (gathered), -> raw_c [P,4]
+int th_mlp_forward(const ThMlpPacked& W, int V, int P, const float* h, const float* f, const float* vd,
+                   float* raw_c, void* ws, size_t ws_bytes, hipStream_t s);
+int th_gather_rows_launch(const float* src, int width, const int32_t* sel, int div, int P, float* out, hipStream_t s);
+// raw[sel[p]] = raw_c[p] (rgb zeroed where sigma<=0 unless rgb_all)
+int th_scatter_raw_launch(const float* raw_c, const int32_t* sel, int P, int rgb_all, float* raw, hipStream_t s);
+// k_composite.hip
+int th_composite_launch(const float* raw, const float* z, const ThPointSrc& ps, int white, float* rgb, float* acc,
+                        float* depth, float* wout, hipStream_t s);
+int th_view_embed_launch(const float* d, int R, int res, float* out, hipStream_t s);
+// k_vit.hip
+size_t th_vit_ws(int V, int N, int dim, int heads);
+int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
+                  size_t ws_bytes, hipStream_t s);

@@ -1,0 +1,454 @@
+"""ctypes binding of libtranshuman_hip.so (include/transhuman_hip.h).
+
+PyTorch is used for device memory, streams and nothing else: every function
+here takes CUDA(=HIP) tensors, hands raw device pointers + the current stream
+to the C ABI and returns freshly allocated tensors.  There is NO fallback: if
+the shared library is missing or a call fails this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtranshuman_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class ThLinear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("out_f", C.c_int), ("in_f", C.c_int)]
+
+
+class ThMlpWeights(C.Structure):
+    _names = ["fc_0", "alpha_res_0", "key0", "val0", "key1", "val1", "fc_1", "fc_2", "fc_3", "alpha_fc",
+              "feature_fc", "rgb_res_0", "view_fc", "rgb_res_1", "fc_4", "rgb_fc"]
+    _fields_ = [(n, ThLinear) for n in _names]
+
+
+class ThVitBlock(C.Structure):
+    _fields_ = [("ln1_w", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p),
+                ("qkv", ThLinear), ("proj", ThLinear), ("fc1", ThLinear), ("fc2", ThLinear)]
+
+
+class ThPoints(C.Structure):
+    _fields_ = [("pts", C.c_void_p), ("ray_o", C.c_void_p), ("ray_d", C.c_void_p), ("near", C.c_void_p),
+                ("far", C.c_void_p), ("t_vals", C.c_void_p), ("one_minus_t", C.c_void_p), ("R", C.c_int),
+                ("S", C.c_int)]
+
+
+class ThFrame(C.Structure):
+    _fields_ = [("verts_world", C.c_void_p), ("n_verts", C.c_int), ("Rh", C.c_void_p), ("Th", C.c_void_p),
+                ("cams", C.c_void_p), ("scale_xy", C.c_void_p), ("pixel_map_nhwc", C.c_void_p), ("V", C.c_int),
+                ("H", C.c_int), ("W", C.c_int), ("tokens", C.c_void_p), ("centres", C.c_void_p),
+                ("rot", C.c_void_p), ("n_clusters", C.c_int), ("hull_thresh", C.c_float),
+                ("small_frame_rays", C.c_int)]
+
+
+# every symbol include/transhuman_hip.h declares (tests/test_cabi.py checks the export table)
+SYMBOLS = {
+    "th_abi_version": (C.c_int, []),
+    "th_last_error": (C.c_char_p, []),
+    "th_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "th_ctx_destroy": (None, [C.c_void_p]),
+    "th_set_mlp_weights": (C.c_int, [C.c_void_p, C.POINTER(ThMlpWeights), C.c_void_p]),
+    "th_set_vit_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(ThVitBlock), C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "th_linear_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "th_linear_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(ThLinear), C.c_int,
+                                    C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "th_hull_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "th_hull_mask": (C.c_int, [C.c_void_p, C.POINTER(ThPoints), C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "th_paint_group": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "th_segment_mean_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p]),
+    "th_segment_mean_rot_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_void_p]),
+    "th_vit_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "th_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_size_t, C.c_void_p]),
+    "th_dparf_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "th_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p]),
+    "th_pixel_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "th_network_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "th_network_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                                     C.c_void_p]),
+    "th_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ThPoints), C.c_int, C.c_void_p,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "th_view_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "th_render_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int, C.c_int]),
+    "th_render_rays": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
+    "th_sigma_grid_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int]),
+    "th_eval_sigma_grid": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                     C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
+}
+
+_lib = None
+_ctx = {}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen the in-tree library and bind prototypes.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipError(f"{LIB_PATH} not found: build it with `python -m transhuman_amd.build` "
+                       "(there is no CPU/torch fallback for the rendering hot path)")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.th_abi_version() != 1:
+        raise HipError("ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise HipError(_lib.th_last_error().decode())
+
+
+def ctx(device=None):
+    lib = load_library()
+    if not torch.cuda.is_available():
+        raise HipError("no HIP device visible: the TransHuman hot path needs an MI355X (gfx950)")
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index or 0
+    if dev not in _ctx:
+        h = C.c_void_p()
+        _check(lib.th_ctx_create(dev, C.byref(h)))
+        _ctx[dev] = h
+    return _ctx[dev]
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _f32(t):
+    assert t.is_cuda, "expected a device tensor"
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def _linear(w, b):
+    w2 = _f32(w).reshape(w.shape[0], -1)
+    b2 = _f32(b) if b is not None else None
+    keep = (w2, b2)
+    return ThLinear(_p(w2), _p(b2), w2.shape[0], w2.shape[1]), keep
+
+
+# ---------------------------------------------------------------------------
+# weights
+# ---------------------------------------------------------------------------
+def set_mlp_weights(net):
+    """Upload + repack the per-point MLP of a Network (cross_transformer.py:96-126)."""
+    lib = load_library()
+    keep = []
+    W = ThMlpWeights()
+    pairs = {"fc_0": net.fc_0, "alpha_res_0": net.alpha_res_0, "key0": net.spatial_key_value_0.key_embed,
+             "val0": net.spatial_key_value_0.value_embed, "key1": net.spatial_key_value_1.key_embed,
+             "val1": net.spatial_key_value_1.value_embed, "fc_1": net.fc_1, "fc_2": net.fc_2, "fc_3": net.fc_3,
+             "alpha_fc": net.alpha_fc, "feature_fc": net.feature_fc, "rgb_res_0": net.rgb_res_0,
+             "view_fc": net.view_fc, "rgb_res_1": net.rgb_res_1, "fc_4": net.fc_4, "rgb_fc": net.rgb_fc}
+    for name, mod in pairs.items():
+        lin, k = _linear(mod.weight, mod.bias)
+        keep.append(k)
+        setattr(W, name, lin)
+    _check(lib.th_set_mlp_weights(ctx(net.fc_0.weight.device), C.byref(W), _stream()))
+
+
+def set_vit_weights(vit):
+    lib = load_library()
+    keep = []
+    blocks = (ThVitBlock * len(vit.blocks))()
+    for i, blk in enumerate(vit.blocks):
+        b = blocks[i]
+        for name, t in (("ln1_w", blk.norm1.weight), ("ln1_b", blk.norm1.bias), ("ln2_w", blk.norm2.weight),
+                        ("ln2_b", blk.norm2.bias)):
+            tt = _f32(t)
+            keep.append(tt)
+            setattr(b, name, tt.data_ptr())
+        for name, mod in (("qkv", blk.attn.qkv), ("proj", blk.attn.proj), ("fc1", blk.mlp.fc1), ("fc2", blk.mlp.fc2)):
+            lin, k = _linear(mod.weight, mod.bias)
+            keep.append(k)
+            setattr(b, name, lin)
+    nw, nb = _f32(vit.norm.weight), _f32(vit.norm.bias)
+    _check(lib.th_set_vit_weights(ctx(nw.device), len(vit.blocks), vit.embed_dim, vit.num_heads, blocks, _p(nw), _p(nb),
+                                  _stream()))
+
+
+_weight_versions = {}
+
+
+def _sync_weights(mod, kind):
+    """Re-upload when any parameter changed (load_state_dict, .cuda(), optimiser step)."""
+    key = (id(mod), kind)
+    ver = tuple((p.data_ptr(), p._version) for p in mod.parameters())
+    if _weight_versions.get(key) != ver:
+        (set_mlp_weights if kind == "mlp" else set_vit_weights)(mod)
+        _weight_versions[key] = ver
+
+
+# ---------------------------------------------------------------------------
+# building blocks (used by tests and by the Network/Renderer classes)
+# ---------------------------------------------------------------------------
+def linear(x, weight, bias=None, act=0):
+    """C = act(x @ W^T + b) on the fp32 MFMA pipe.  x [M,K] (row stride % 4 == 0)."""
+    lib = load_library()
+    x = _f32(x)
+    assert x.dim() == 2
+    if x.shape[1] % 4:
+        x = torch.nn.functional.pad(x, (0, 4 - x.shape[1] % 4))
+    lin, keep = _linear(weight, bias)
+    out = torch.empty((x.shape[0], lin.out_f), dtype=torch.float32, device=x.device)
+    ws = _ws(lib.th_linear_workspace_bytes(lin.out_f, lin.in_f), x.device)
+    _check(lib.th_linear_forward(ctx(x.device), _p(x), x.stride(0), x.shape[0], C.byref(lin), act, _p(out),
+                                 out.stride(0), _p(ws), ws.numel(), _stream()))
+    return out
+
+
+class Points:
+    """Host-side holder of a th_points (keeps the tensors alive)."""
+
+    def __init__(self, ray_o=None, ray_d=None, near=None, far=None, n_samples=1, pts=None):
+        if pts is not None:
+            self.pts = _f32(pts).reshape(-1, 3)
+            self.R, self.S = self.pts.shape[0], 1
+            self.keep = (self.pts,)
+            self.c = ThPoints(_p(self.pts), None, None, None, None, None, None, self.R, 1)
+            return
+        self.ray_o, self.ray_d = _f32(ray_o).reshape(-1, 3), _f32(ray_d).reshape(-1, 3)
+        self.near, self.far = _f32(near).reshape(-1), _f32(far).reshape(-1)
+        dev = self.ray_o.device
+        # t_vals exactly as torch.linspace builds them (if_clight_renderer.py:273-274)
+        t = torch.linspace(0.0, 1.0, steps=n_samples)
+        self.t = t.to(dev)
+        self.omt = (1.0 - t).to(dev)
+        self.R, self.S = self.ray_o.shape[0], n_samples
+        self.c = ThPoints(None, _p(self.ray_o), _p(self.ray_d), _p(self.near), _p(self.far), _p(self.t), _p(self.omt),
+                          self.R, self.S)
+
+
+def hull_mask(points, verts_world, thresh=0.1):
+    lib = load_library()
+    v = _f32(verts_world).reshape(-1, 3)
+    P = points.R * points.S
+    mask = torch.empty(P, dtype=torch.uint8, device=v.device)
+    hit = torch.empty(points.R, dtype=torch.int32, device=v.device)
+    ws = _ws(lib.th_hull_workspace_bytes(v.shape[0]), v.device)
+    _check(lib.th_hull_mask(ctx(v.device), C.byref(points.c), _p(v), v.shape[0], thresh, _p(mask), _p(hit), _p(ws),
+                            ws.numel(), _stream()))
+    return mask.view(points.R, points.S).bool(), hit.bool()
+
+
+def pack_cams(R, T, K):
+    """[V,3,3],[V,3,1],[V,3,3] -> [V,21] fp32 (R | T | K row-major)."""
+    V = R.shape[0]
+    return torch.cat([_f32(R).reshape(V, 9), _f32(T).reshape(V, 3), _f32(K).reshape(V, 9)], dim=1).contiguous()
+
+
+def feat_scale(scale_np, image_shape, device):
+    """sample_from_feature_map, if_clight_renderer.py:193-195 (float64 divide, cast to fp32)."""
+    import numpy as np
+    s = np.asarray(scale_np, dtype=np.float64) / np.asarray(image_shape, dtype=np.float64)
+    return torch.tensor(s).to(dtype=torch.float32, device=device)
+
+
+def csr_to_device(offsets, members, device):
+    return (torch.as_tensor(offsets, dtype=torch.int32, device=device).contiguous(),
+            torch.as_tensor(members, dtype=torch.int32, device=device).contiguous())
+
+
+def paint_group(holder_map, verts_world, cams, scale_xy, vizmap, off, mem, return_painted=False):
+    lib = load_library()
+    m = _f32(holder_map)
+    V, Cc, H, W = m.shape
+    v = _f32(verts_world).reshape(-1, 3)
+    nc = off.numel() - 1
+    viz = vizmap.to(torch.uint8).contiguous() if vizmap is not None else None
+    painted = torch.empty((V, v.shape[0], Cc), dtype=torch.float32, device=m.device)
+    tokens = torch.empty((V, nc, Cc), dtype=torch.float32, device=m.device)
+    _check(lib.th_paint_group(ctx(m.device), _p(m), V, Cc, H, W, _p(v), v.shape[0], _p(cams), _p(scale_xy), _p(viz),
+                              _p(off), _p(mem), nc, _p(painted), _p(tokens), _stream()))
+    return (tokens, painted) if return_painted else tokens
+
+
+def segment_mean(src, off, mem):
+    lib = load_library()
+    s = _f32(src)
+    width = int(s[0].numel())
+    s2 = s.reshape(s.shape[0], width)
+    nc = off.numel() - 1
+    out = torch.empty((nc, width), dtype=torch.float32, device=s.device)
+    _check(lib.th_segment_mean_f32(ctx(s.device), _p(s2), width, _p(off), _p(mem), nc, _p(out), _stream()))
+    return out.reshape(nc, *s.shape[1:])
+
+
+def segment_mean_rot(blend, off, mem):
+    """blend [n_verts,4,4] (float64 kept as is) -> fp32 [N_c,3,3]."""
+    lib = load_library()
+    b = blend.detach().to(torch.float64).contiguous().reshape(-1, 16)
+    nc = off.numel() - 1
+    out = torch.empty((nc, 9), dtype=torch.float32, device=b.device)
+    _check(lib.th_segment_mean_rot_f64(ctx(b.device), _p(b), _p(off), _p(mem), nc, _p(out), _stream()))
+    return out
+
+
+def vit_forward(vit, x, pe):
+    lib = load_library()
+    _sync_weights(vit, "vit")
+    x, pe = _f32(x), _f32(pe)
+    V, N, D = x.shape
+    out = torch.empty_like(x)
+    ws = _ws(lib.th_vit_workspace_bytes(V, N, D, vit.num_heads), x.device)
+    _check(lib.th_vit_forward(ctx(x.device), _p(x), _p(pe), V, N, _p(out), _p(ws), ws.numel(), _stream()))
+    return out
+
+
+def dparf_encode(pts_smpl, centres, rot, tokens, sel=None):
+    lib = load_library()
+    p, c, r, t = _f32(pts_smpl).reshape(-1, 3), _f32(centres).reshape(-1, 3), _f32(rot).reshape(-1, 9), _f32(tokens)
+    P = p.shape[0] if sel is None else sel.numel()
+    V, nc = t.shape[0], t.shape[1]
+    out = torch.empty((P, V, 256), dtype=torch.float32, device=p.device)
+    _check(lib.th_dparf_encode(ctx(p.device), _p(p), _p(sel), P, _p(c), _p(r), _p(t), V, nc, _p(out), _stream()))
+    return out
+
+
+def nchw_to_nhwc(m):
+    lib = load_library()
+    m = _f32(m)
+    V, Cc, H, W = m.shape
+    out = torch.empty((V, H, W, Cc), dtype=torch.float32, device=m.device)
+    _check(lib.th_nchw_to_nhwc(ctx(m.device), _p(m), V, Cc, H, W, _p(out), _stream()))
+    return out
+
+
+def pixel_gather(map_nhwc, pts_world, cams, scale_xy, sel=None):
+    lib = load_library()
+    V, H, W, Cc = map_nhwc.shape
+    p = _f32(pts_world).reshape(-1, 3)
+    P = p.shape[0] if sel is None else sel.numel()
+    out = torch.empty((P, V, Cc), dtype=torch.float32, device=p.device)
+    _check(lib.th_pixel_gather(ctx(p.device), _p(map_nhwc), V, Cc, H, W, _p(p), _p(sel), P, _p(cams), _p(scale_xy),
+                               _p(out), _stream()))
+    return out
+
+
+def network_forward(net, pixel_feat, viewdir, pts_smpl, centres, rot, tokens, mask=None):
+    """Network.forward on gathered inputs -> raw [P,4]."""
+    lib = load_library()
+    _sync_weights(net, "mlp")
+    pf, vd, ps = _f32(pixel_feat), _f32(viewdir).reshape(-1, 27), _f32(pts_smpl).reshape(-1, 3)
+    V, Cc, P = pf.shape
+    assert Cc == 384 and vd.shape[0] == P and ps.shape[0] == P
+    c, r, t = _f32(centres).reshape(-1, 3), _f32(rot).reshape(-1, 9), _f32(tokens)
+    m = mask.reshape(-1).to(torch.uint8).contiguous() if mask is not None else None
+    raw = torch.empty((P, 4), dtype=torch.float32, device=pf.device)
+    ws = _ws(lib.th_network_workspace_bytes(V, P), pf.device)
+    _check(lib.th_network_forward(ctx(pf.device), _p(pf), _p(vd), _p(ps), _p(m), P, _p(c), _p(r), _p(t), V, t.shape[1],
+                                  _p(raw), _p(ws), ws.numel(), _stream()))
+    return raw
+
+
+def composite(raw, z, ray_d, white_bkgd=False, return_weights=False):
+    lib = load_library()
+    raw, z, d = _f32(raw), _f32(z), _f32(ray_d).reshape(-1, 3)
+    R, S = z.shape
+    pts = ThPoints(None, None, _p(d), None, None, None, None, R, S)
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=raw.device)
+    acc = torch.empty(R, dtype=torch.float32, device=raw.device)
+    dep = torch.empty(R, dtype=torch.float32, device=raw.device)
+    w = torch.empty((R, S), dtype=torch.float32, device=raw.device) if return_weights else None
+    _check(lib.th_composite(ctx(raw.device), _p(raw), _p(z), C.byref(pts), int(white_bkgd), _p(rgb), _p(acc), _p(dep),
+                            _p(w), _stream()))
+    return (rgb, acc, dep, w) if return_weights else (rgb, acc, dep)
+
+
+def view_embed(ray_d, view_res=4):
+    lib = load_library()
+    d = _f32(ray_d).reshape(-1, 3)
+    out = torch.empty((d.shape[0], 3 + 6 * view_res), dtype=torch.float32, device=d.device)
+    _check(lib.th_view_embed(ctx(d.device), _p(d), d.shape[0], view_res, _p(out), _stream()))
+    return out
+
+
+class Frame:
+    """Per-frame constants of the per-sample stage (th_frame) + owners."""
+
+    def __init__(self, verts_world, Rh, Th, cams, scale_xy, pixel_map_nhwc, tokens, centres, rot,
+                 hull_thresh=0.1, small_frame_rays=2400):
+        self.verts = _f32(verts_world).reshape(-1, 3)
+        self.Rh, self.Th = _f32(Rh).reshape(9), _f32(Th).reshape(3)
+        self.cams, self.scale = cams, scale_xy
+        self.map = pixel_map_nhwc
+        self.tokens, self.centres, self.rot = _f32(tokens), _f32(centres).reshape(-1, 3), _f32(rot).reshape(-1, 9)
+        V, H, W, Cc = pixel_map_nhwc.shape
+        assert Cc == 384
+        self.c = ThFrame(_p(self.verts), self.verts.shape[0], _p(self.Rh), _p(self.Th), _p(self.cams), _p(self.scale),
+                         _p(self.map), V, H, W, _p(self.tokens), _p(self.centres), _p(self.rot),
+                         self.tokens.shape[1], hull_thresh, small_frame_rays)
+
+
+_ws_cache = {}
+
+
+def _cached_ws(nbytes, device):
+    key = str(device)
+    cur = _ws_cache.get(key)
+    if cur is None or cur.numel() < nbytes:
+        _ws_cache[key] = None
+        cur = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _ws_cache[key] = cur
+    return cur
+
+
+def render_rays(net, frame, points, white_bkgd=False):
+    """th_render_rays: rays -> (rgb [R,3], acc [R], depth [R], stats)."""
+    lib = load_library()
+    _sync_weights(net, "mlp")
+    dev = frame.verts.device
+    R = points.R
+    rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+    acc = torch.empty(R, dtype=torch.float32, device=dev)
+    dep = torch.empty(R, dtype=torch.float32, device=dev)
+    ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(frame.c), R, points.S), dev)
+    stats = (C.c_int64 * 4)()
+    _check(lib.th_render_rays(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(rgb), _p(acc), _p(dep), int(white_bkgd),
+                              _p(ws), ws.numel(), stats, _stream()))
+    return rgb, acc, dep, dict(hit_rays=stats[0], valid_samples=stats[1], unmasked=stats[3])
+
+
+def eval_sigma_grid(net, frame, pts):
+    lib = load_library()
+    _sync_weights(net, "mlp")
+    p = _f32(pts).reshape(-1, 3)
+    P = p.shape[0]
+    out = torch.empty(P, dtype=torch.float32, device=p.device)
+    ws = _cached_ws(lib.th_sigma_grid_workspace_bytes(C.byref(frame.c), P), p.device)
+    stats = (C.c_int64 * 4)()
+    _check(lib.th_eval_sigma_grid(ctx(p.device), C.byref(frame.c), _p(p), P, _p(out), _p(ws), ws.numel(), stats,
+                                  _stream()))
+    return out, dict(valid_samples=stats[1])

@@ -1,0 +1,106 @@
+"""SpatialEncoder -- feeds the hot path, itself outside the HIP scope.
+
+Mirrors /root/reference/lib/networks/encoder.py:50-155: torchvision-ResNet18
+stem (conv1/bn1/relu, maxpool, layer1, layer2), each latent bilinearly
+upsampled (align_corners=True) to HxW, concatenated with a 1x1 colour lift
+(-> 384 ch ``pixel_feat_map``) and reduced by a 1x1 conv to the 192-ch
+``holder_feat_map``.  torchvision is not installed in this image, so the trunk
+is restated here with torchvision's parameter names (``encoder.model.*``,
+including the never-executed layer3/layer4) to stay ``strict=True``
+checkpoint-compatible.  Runs as stock PyTorch-ROCm (MIOpen) ops.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..config import get_cfg
+
+
+class _PEBuffers(nn.Module):
+    """Buffer-only twin of the reference's PositionalEncoding
+    (lib/networks/vision_transformer.py:100-122): keeps the `_freqs` /
+    `_phases` state-dict entries."""
+
+    def __init__(self, num_freqs, d_in=3, include_input=True):
+        super().__init__()
+        self.num_freqs = num_freqs
+        self.d_out = num_freqs * 2 * d_in + (d_in if include_input else 0)
+        self.include_input = include_input
+        freqs = np.pi * 2.0 ** torch.arange(0, num_freqs)
+        self.register_buffer("_freqs", torch.repeat_interleave(freqs, 2).view(1, -1, 1))
+        ph = torch.zeros(2 * num_freqs)
+        ph[1::2] = np.pi * 0.5
+        self.register_buffer("_phases", ph.view(1, -1, 1))
+
+    def forward(self, x):
+        e = x.unsqueeze(1).repeat(1, self.num_freqs * 2, 1)
+        e = torch.sin(torch.addcmul(self._phases, e, self._freqs)).view(x.shape[0], -1)
+        return torch.cat((x, e), dim=-1) if self.include_input else e
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride=1, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = norm_layer(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = norm_layer(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), norm_layer(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        return self.relu(y + idt)
+
+
+class ResNet18Trunk(nn.Module):
+    """torchvision.models.resnet18 parameter layout (conv1, bn1, layer1..4)."""
+
+    def __init__(self, pretrained=False, norm_layer=None, **_):
+        super().__init__()
+        norm_layer = norm_layer or nn.BatchNorm2d
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        self.layer1 = nn.Sequential(BasicBlock(64, 64, 1, norm_layer), BasicBlock(64, 64, 1, norm_layer))
+        self.layer2 = nn.Sequential(BasicBlock(64, 128, 2, norm_layer), BasicBlock(128, 128, 1, norm_layer))
+        self.layer3 = nn.Sequential(BasicBlock(128, 256, 2, norm_layer), BasicBlock(256, 256, 1, norm_layer))
+        self.layer4 = nn.Sequential(BasicBlock(256, 512, 2, norm_layer), BasicBlock(512, 512, 1, norm_layer))
+        self.avgpool = nn.Sequential()
+        self.fc = nn.Sequential()
+
+
+class SpatialEncoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        cfg = get_cfg()
+        self.model = ResNet18Trunk()
+        # encoder.py:85 is built while cfg.img_feat_size is still the YAML's 256
+        # (cross_transformer.py:94 runs before :123) -> 256+128 = 384 inputs
+        self.reduction_layer = nn.Conv2d(256 + 128, cfg.embed_size, 1)
+        self.PE_color = _PEBuffers(10)                                                 # encoder.py:93 (unused)
+        self.upsample_color = nn.Conv2d(3, 128, 1)                                     # encoder.py:95
+
+    def forward(self, x):
+        H, W = x.shape[2:]
+        x_ori = x
+        m = self.model
+        x = m.relu(m.bn1(m.conv1(x)))
+        lat = [x]
+        x = m.layer1(m.maxpool(x))
+        lat.append(x)
+        x = m.layer2(x)
+        lat.append(x)
+        lat = [F.interpolate(l, (H, W), mode="bilinear", align_corners=True) for l in lat]
+        pixel_feat_map = torch.cat(lat + [self.upsample_color(x_ori)], dim=1)
+        holder_feat_map = self.reduction_layer(pixel_feat_map)
+        # "scales used in projection", encoder.py:148-153
+        s = np.array([pixel_feat_map.shape[-1], pixel_feat_map.shape[-2]])
+        s = s / (s - 1) * 2.0
+        return holder_feat_map, s, pixel_feat_map, s.copy()

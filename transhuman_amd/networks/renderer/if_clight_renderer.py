@@ -1,0 +1,142 @@
+"""Renderer -- orchestration of the volumetric rendering hot path on MI355X.
+
+Drop-in for /root/reference/lib/networks/renderer/if_clight_renderer.py
+(`Renderer`, :37-656): ``Renderer(net)``, ``render_fast(batch, is_train)``
+(:429-484) and ``render(batch, is_train)`` (:486-498) return
+``{'rgb_map' [1,R,3], 'acc_map' [1,R], 'depth_map' [1,R]}``.
+
+What runs where
+  * encoder (ResNet18 stem)            stock PyTorch-ROCm ops
+  * paint + cluster pooling            th_paint_group        (K2)
+  * TransHE                            th_vit_forward        (K3)
+  * DPaRF tables (centres, rotations)  th_segment_mean_*     (K2)
+  * sampling, hull mask, compaction,
+    DPaRF, pixel gather, MLP,
+    compositing                        th_render_rays        (K1,K4,K5,K6,K7)
+Unlike the reference nothing here mutates ``batch`` (:459-462).
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from ...config import get_cfg
+from ... import hip, synth
+
+
+class Renderer:
+    def __init__(self, net, vertex_can=None, pc2voxel_ind=None):
+        """``vertex_can`` (float64 [6890,3]) / ``pc2voxel_ind`` (int [6890]) may be
+        injected; otherwise they are read from the reference's cwd-relative files
+        (./data/smplx/smpl/SMPL_NEUTRAL.pkl :43-48, ./kmeans_dict/kmeans_dict_{N}.npy :55)."""
+        cfg = get_cfg()
+        self.net = net
+        self.faces = None
+        if vertex_can is None:
+            with open("./data/smplx/smpl/SMPL_NEUTRAL.pkl", "rb") as f:
+                data = pickle.load(f, encoding="latin1")
+            vertex_can = np.asarray(data["v_template"])
+            self.faces = data["f"]
+        self.vertex_can = torch.as_tensor(np.asarray(vertex_can)).contiguous()      # float64 like :48
+        self.CR = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])                  # :50
+        if pc2voxel_ind is None:
+            num_voxel = cfg.num_class
+            path = f"./kmeans_dict/kmeans_dict_{num_voxel}.npy"
+            d = np.load(path, allow_pickle=True).item()
+            pc2voxel_ind = np.asarray(d["pc2voxel_ind"])
+        self.pc2voxel_ind = torch.as_tensor(np.asarray(pc2voxel_ind)).type(torch.int64)
+        # CSR of the cluster lists: members ascending inside a cluster == the
+        # order of dict_voxel2pc_ind's lists in the reference's files
+        self.csr_offsets, self.csr_members = synth.csr_from_assign(self.pc2voxel_ind.numpy())
+        self.num_clusters = len(self.csr_offsets) - 1
+        self.voxel_PE_can = self._host_segment_mean(self.vertex_can)               # :73  (float64 [N_c,3])
+        self._dev = {}
+
+    # ---- host-side helpers (constants of the renderer) ----------------------------
+    def _host_segment_mean(self, x):
+        out = [x[torch.as_tensor(self.csr_members[self.csr_offsets[c]:self.csr_offsets[c + 1]], dtype=torch.long)].mean(0)
+               for c in range(self.num_clusters)]
+        return torch.stack(out)
+
+    def normalize_PE(self, PE, CR=None):
+        """:373-383 -- float64 in, float32 out."""
+        assert len(PE.shape) == 3
+        CR = self.CR if CR is None else CR
+        mn, mx = CR[:3][None, None, :].to(PE.device), CR[3:][None, None, :].to(PE.device)
+        return ((((PE - mn) / (mx - mn)) - 0.5) * 2).type(torch.float32)
+
+    def voxelization(self, src):
+        """:356-371 on device: per-cluster mean of per-vertex rows."""
+        off, mem = self._csr(src.device)
+        return hip.segment_mean(src, off, mem)
+
+    def _csr(self, device):
+        key = ("csr", str(device))
+        if key not in self._dev:
+            self._dev[key] = hip.csr_to_device(self.csr_offsets, self.csr_members, device)
+        return self._dev[key]
+
+    def _pe_norm(self, V, device):
+        key = ("pe", V, str(device))
+        if key not in self._dev:
+            pe = self.voxel_PE_can.unsqueeze(0).repeat(V, 1, 1)                    # :536
+            self._dev[key] = self.normalize_PE(pe).to(device)
+        return self._dev[key]
+
+    # ---- per-frame constants ---------------------------------------------------------
+    def prepare_frame(self, batch, hull_thresh=None):
+        """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame."""
+        cfg = get_cfg()
+        assert cfg.time_steps == 1                                                  # :412
+        t = 0
+        images = batch["input_imgs"][t]
+        images = images.reshape(-1, *images.shape[2:])                              # :397
+        dev = images.device
+        holder_map, holder_scale, pixel_map, pixel_scale = self.net.encoder(images)  # :399
+        V, _, H, W = pixel_map.shape
+        cams = hip.pack_cams(batch["input_R"][t].reshape(-1, 3, 3), batch["input_T"][t].reshape(-1, 3, 1),
+                             batch["input_K"][t].reshape(-1, 3, 3))
+        image_shape = batch["input_imgs"][t].shape[-2:]
+        off, mem = self._csr(dev)
+        viz = batch["input_vizmaps"][t][0] if cfg.rasterize else None               # :103-119
+        grouped = hip.paint_group(holder_map, batch["input_smpl_vertice"][t][0], cams,
+                                  hip.feat_scale(holder_scale, image_shape, dev), viz, off, mem)
+        tokens = self.net.ViT(grouped, self._pe_norm(V, dev), mask=None)            # :538
+        centres = hip.segment_mean(batch["tar_smpl_vertice_smplcoord"][0], off, mem)   # :543
+        rot = hip.segment_mean_rot(batch["blend_mtx"][0], off, mem)                 # :544 + cross_transformer.py:185
+        frame = hip.Frame(batch["tar_smpl_vertice"][0], batch["Rh"][0], batch["Th"][0], cams,
+                          hip.feat_scale(pixel_scale, image_shape, dev), hip.nchw_to_nhwc(pixel_map), tokens,
+                          centres, rot,
+                          hull_thresh=cfg_hull() if hull_thresh is None else hull_thresh,
+                          small_frame_rays=2400)
+        return frame
+
+    # ---- reference API -------------------------------------------------------------------
+    def render_fast(self, batch, is_train=True, frame=None, ray_slice=None):
+        """:429-484.  ``frame`` lets callers reuse per-frame constants;
+        ``ray_slice`` renders a sub-range of rays (multi-GPU sharding)."""
+        cfg = get_cfg()
+        frame = frame if frame is not None else self.prepare_frame(batch)
+        sl = slice(None) if ray_slice is None else ray_slice
+        pts = hip.Points(batch["ray_o"][0][sl], batch["ray_d"][0][sl], batch["near"][0][sl], batch["far"][0][sl],
+                         n_samples=cfg.N_samples)
+        rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd))
+        self.last_stats = stats
+        return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
+
+    def render(self, batch, is_train=True):
+        """:486-498 -- no hull mask, every sample shaded, RGB everywhere.
+        Forward only (the HIP kernels carry no autograd)."""
+        cfg = get_cfg()
+        frame = self.prepare_frame(batch, hull_thresh=-1.0)
+        pts = hip.Points(batch["ray_o"][0], batch["ray_d"][0], batch["near"][0], batch["far"][0],
+                         n_samples=cfg.N_samples)
+        rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd))
+        self.last_stats = stats
+        return {"rgb_map": rgb[None], "acc_map": acc[None], "depth_map": depth[None]}
+
+
+def cfg_hull():
+    from ...config import cfg_get
+    return float(cfg_get("hull_dist", 0.1))
