@@ -63,12 +63,13 @@ def _net_cached(depth):
 
 
 def make_net(depth=12):
-    """Product Network with the deterministic weights the goldens were made with."""
-    return _net_cached(depth)
+    """Product Network (fresh copy, CPU) with the deterministic weights the goldens were made with."""
+    import copy
+    return copy.deepcopy(_net_cached(depth))
 
 
 def make_sd(depth=12):
-    return {k: v.clone() for k, v in make_net(depth).state_dict().items()}
+    return {k: v.detach().cpu().clone() for k, v in _net_cached(depth).state_dict().items()}
 
 
 def maxdiff(a, b):
