@@ -42,6 +42,15 @@ const char* th_last_error(void);
 int         th_ctx_create(int device, th_ctx** out);
 void        th_ctx_destroy(th_ctx* ctx);
 
+/* ---- stage timing (HIP events on the launch stream) --------------------- */
+/* When enabled, the frame-level entry points bracket their stages with
+ * hipEventRecord on `stream`; th_profile_read drains the accumulated
+ * per-phase milliseconds / launch counts (arrays of TH_PROF_PHASES). */
+enum { TH_PROF_HULL = 0, TH_PROF_DPARF = 1, TH_PROF_GATHER = 2, TH_PROF_MLP = 3, TH_PROF_COMPOSITE = 4,
+       TH_PROF_VIT = 5, TH_PROF_PHASES = 8 };
+int th_profile_enable(th_ctx* ctx, int on);
+int th_profile_read(th_ctx* ctx, double* ms_out, int64_t* count_out);
+
 /* ---- weights ----------------------------------------------------------- */
 /* One dense layer: weight row-major [out_f][in_f] (a Conv1d(k=1)/Linear
  * weight with the trailing 1 squeezed), bias [out_f] or NULL. */

@@ -10,6 +10,36 @@
 static thread_local std::string g_err;
 void th_set_error(const std::string& msg) { g_err = msg; }
 
+// ---------------------------------------------------------------------------
+// stage profiling: HIP events recorded on the stream the kernels are launched
+// on (bench.py reads them back for the live roofline numbers)
+// ---------------------------------------------------------------------------
+struct ThProf {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    struct Span { int phase; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    hipEvent_t get() {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+};
+struct ProfScope {
+    ThProf* p; int phase; hipStream_t s; hipEvent_t a = nullptr;
+    ProfScope(ThProf* p_, int phase_, hipStream_t s_) : p(p_), phase(phase_), s(s_) {
+        if (p && p->on) { a = p->get(); if (a) (void)hipEventRecord(a, s); }
+    }
+    ~ProfScope() {
+        if (a) { hipEvent_t b = p->get(); if (b) { (void)hipEventRecord(b, s); p->spans.push_back({phase, a, b}); } }
+    }
+};
+static ThProf* prof_of(th_ctx* c);
+
 extern "C" {
 
 int th_abi_version(void) { return TH_ABI_VERSION; }
@@ -39,7 +69,36 @@ void th_ctx_destroy(th_ctx* c) {
     if (c->vit_store) (void)hipFree(c->vit_store);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     delete[] c->vit.blocks;
+    if (c->prof) {
+        ThProf* p = (ThProf*)c->prof;
+        for (auto e : p->pool) (void)hipEventDestroy(e);
+        delete p;
+    }
     delete c;
+}
+
+int th_profile_enable(th_ctx* c, int on) {
+    TH_REQUIRE(c, "null ctx");
+    ThProf* p = prof_of(c);
+    p->on = on != 0;
+    p->used = 0;
+    p->spans.clear();
+    return 0;
+}
+
+int th_profile_read(th_ctx* c, double* ms_out, int64_t* count_out) {
+    TH_REQUIRE(c && ms_out && count_out, "null argument");
+    ThProf* p = prof_of(c);
+    for (int i = 0; i < TH_PROF_PHASES; ++i) { ms_out[i] = 0.0; count_out[i] = 0; }
+    for (auto& sp : p->spans) {
+        TH_HIP(hipEventSynchronize(sp.b));
+        float ms = 0.f;
+        TH_HIP(hipEventElapsedTime(&ms, sp.a, sp.b));
+        if (sp.phase >= 0 && sp.phase < TH_PROF_PHASES) { ms_out[sp.phase] += ms; count_out[sp.phase] += 1; }
+    }
+    p->used = 0;
+    p->spans.clear();
+    return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -208,6 +267,7 @@ size_t th_vit_workspace_bytes(int V, int N, int dim, int heads) { return th_vit_
 int th_vit_forward(th_ctx* c, const float* x, const float* pe, int V, int N, float* out, void* ws, size_t ws_bytes,
                    th_stream stream) {
     TH_REQUIRE(c && x && pe && out && ws, "null argument");
+    ProfScope sc(prof_of(c), TH_PROF_VIT, (hipStream_t)stream);
     return th_vit_launch(c->vit, x, pe, V, N, out, ws, ws_bytes, (hipStream_t)stream);
 }
 
@@ -354,6 +414,8 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     TH_REQUIRE(raw != nullptr, "workspace too small");
     TH_TRY(chunk_carve(ar, V, CH, &cb));
 
+    ThProf* pf = prof_of(c);
+    ProfScope* sc = new ProfScope(pf, TH_PROF_HULL, s);
     TH_HIP(hipMemsetAsync(info, 0, 16 * 4, s));
     const bool no_hull = f->hull_thresh < 0.f;   // Renderer.render (:486-498): every sample shaded, RGB everywhere
     if (no_hull) {
@@ -370,6 +432,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     }
     TH_TRY(th_compact_mask(mask, P, idx, info + 2, cws, cws_b, s));
     TH_HIP(hipMemsetAsync(raw, 0, (size_t)P * 16, s));
+    delete sc;
     TH_HIP(hipMemcpyAsync(c->host_pinned, info, 4 * 4, hipMemcpyDeviceToHost, s));
     TH_HIP(hipStreamSynchronize(s));
     const int hit_rays = c->host_pinned[0], unmasked = c->host_pinned[1], n = c->host_pinned[2];
@@ -378,12 +441,22 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     for (int o = 0; o < n; o += CH) {
         int m = (n - o) < CH ? (n - o) : CH;
         const int32_t* sel = idx + o;
-        TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, sel, m, f->centres, f->rot, f->tokens, V, f->n_clusters,
-                               0.5f, cb.h, s));
-        TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, 384, f->H, f->W, nullptr, &ps, sel, m, f->cams, f->scale_xy,
-                                   cb.f, s));
-        if (ray_mode) TH_TRY(th_gather_rows_launch(vd_all, 27, sel, S, m, cb.vdc, s));
-        TH_TRY(th_mlp_forward(c->mlp, V, m, cb.h, cb.f, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s));
+        {
+            ProfScope ps1(pf, TH_PROF_DPARF, s);
+            TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, sel, m, f->centres, f->rot, f->tokens, V,
+                                   f->n_clusters, 0.5f, cb.h, s));
+        }
+        {
+            ProfScope ps2(pf, TH_PROF_GATHER, s);
+            TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, 384, f->H, f->W, nullptr, &ps, sel, m, f->cams,
+                                       f->scale_xy, cb.f, s));
+            if (ray_mode) TH_TRY(th_gather_rows_launch(vd_all, 27, sel, S, m, cb.vdc, s));
+        }
+        {
+            ProfScope ps3(pf, TH_PROF_MLP, s);
+            TH_TRY(th_mlp_forward(c->mlp, V, m, cb.h, cb.f, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s));
+        }
+        ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));
     }
     *raw_out = raw;
@@ -411,6 +484,7 @@ int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* r
     ThPointSrc ps = th_src(rays);
     float* raw = nullptr;
     TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, stats_host, s));
+    ProfScope sc(prof_of(c), TH_PROF_COMPOSITE, s);
     return th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, s);
 }
 
@@ -440,3 +514,8 @@ int th_eval_sigma_grid(th_ctx* c, const th_frame* f, const float* pts, int P, fl
 }
 
 }  // extern "C"
+
+static ThProf* prof_of(th_ctx* c) {
+    if (!c->prof) c->prof = new ThProf();
+    return (ThProf*)c->prof;
+}

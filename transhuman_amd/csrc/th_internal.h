@@ -183,6 +183,7 @@ struct th_ctx {
     ThVitPacked vit;
     int32_t* host_pinned = nullptr;   // small pinned read-back buffer
     int n_cu = 256;
+    void* prof = nullptr;             // ThProf (th_api.hip)
 };
 
 // ---- launchers (one group per .hip file) -------------------------------------------

@@ -1,0 +1,58 @@
+"""Multi-GPU ray sharding: one process per GPU, torch.distributed (RCCL over xGMI).
+
+The reference renders on a single GPU (every script passes `gpus "${CARD},"`);
+its only collectives are DDP training ones.  Rays are independent
+given the per-frame constants, so inference shards them with no data-path
+exchange; the one collective is the image gather (R/N x 5 fp32 per rank,
+655 KB at N=8 for a 512x512 frame -- latency-bound, far below the 153 GB/s of
+an xGMI link).  Hull rays are spatially clustered, hence the interleaved
+8x8-pixel tile deal instead of contiguous row blocks (hard part 8).
+"""
+import torch
+
+
+def shard_ray_indices(H, W, world, rank, tile=8):
+    """Indices (into the row-major H*W ray list) of the rays owned by `rank`:
+    pixel tile t (row-major over the tile grid) belongs to rank t % world."""
+    ty = (H + tile - 1) // tile
+    tx = (W + tile - 1) // tile
+    y = torch.arange(H)
+    x = torch.arange(W)
+    tid = (y[:, None] // tile) * tx + (x[None, :] // tile)
+    own = (tid % world) == rank
+    return torch.nonzero(own.reshape(-1), as_tuple=False).reshape(-1)
+
+
+def shard_lengths(H, W, world, tile=8):
+    return [int(shard_ray_indices(H, W, world, r, tile).numel()) for r in range(world)]
+
+
+def gather_image(local, my_idx, n_rays, world, H=None, W=None, tile=8, group=None):
+    """all_gather the per-rank [n_local, C] results into the dense [n_rays, C] image on
+    every rank.  Shards may differ in length (ragged tile counts): padded to the max."""
+    import torch.distributed as dist
+    C = local.shape[1]
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    lens = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(lens, n_local, group=group)
+    lens = [int(l) for l in lens]
+    mx = max(lens)
+    pad_val = torch.zeros((mx, C), dtype=local.dtype, device=local.device)
+    pad_val[: local.shape[0]] = local
+    pad_idx = torch.full((mx,), -1, dtype=torch.int64, device=local.device)
+    pad_idx[: my_idx.numel()] = my_idx
+    all_val = torch.empty((world * mx, C), dtype=local.dtype, device=local.device)
+    all_idx = torch.empty((world * mx,), dtype=torch.int64, device=local.device)
+    if local.is_cuda:
+        dist.all_gather_into_tensor(all_val, pad_val, group=group)
+        dist.all_gather_into_tensor(all_idx, pad_idx, group=group)
+    else:  # gloo (CPU tests)
+        vs = [torch.empty_like(pad_val) for _ in range(world)]
+        is_ = [torch.empty_like(pad_idx) for _ in range(world)]
+        dist.all_gather(vs, pad_val, group=group)
+        dist.all_gather(is_, pad_idx, group=group)
+        all_val, all_idx = torch.cat(vs), torch.cat(is_)
+    keep = all_idx >= 0
+    img = torch.zeros((n_rays, C), dtype=local.dtype, device=local.device)
+    img[all_idx[keep]] = all_val[keep]
+    return img

@@ -51,6 +51,8 @@ SYMBOLS = {
     "th_last_error": (C.c_char_p, []),
     "th_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "th_ctx_destroy": (None, [C.c_void_p]),
+    "th_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "th_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "th_set_mlp_weights": (C.c_int, [C.c_void_p, C.POINTER(ThMlpWeights), C.c_void_p]),
     "th_set_vit_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(ThVitBlock), C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
@@ -452,3 +454,18 @@ def eval_sigma_grid(net, frame, pts):
     _check(lib.th_eval_sigma_grid(ctx(p.device), C.byref(frame.c), _p(p), P, _p(out), _p(ws), ws.numel(), stats,
                                   _stream()))
     return out, dict(valid_samples=stats[1])
+
+
+PROF_PHASES = ("hull", "dparf", "gather", "mlp", "composite", "vit", "_6", "_7")
+
+
+def profile_enable(on=True, device=None):
+    _check(load_library().th_profile_enable(ctx(device), int(on)))
+
+
+def profile_read(device=None):
+    """-> {phase: (milliseconds, launches)} accumulated since the last read."""
+    ms = (C.c_double * 8)()
+    cnt = (C.c_int64 * 8)()
+    _check(load_library().th_profile_read(ctx(device), ms, cnt))
+    return {PROF_PHASES[i]: (ms[i], cnt[i]) for i in range(6)}
