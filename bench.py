@@ -72,7 +72,9 @@ def cpu_baseline(batch, assign, n_samples, stride=64):
     (frame constants computed once, per-ray part extrapolated linearly)."""
     from oracle import th_oracle as O
     from transhuman_amd.networks.cross_transformer import Network
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling (and thrashes) far below the 256 hardware threads of the
+    # GPU box on these small per-chunk ops: use at most 32 and report that number
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = Network()
@@ -114,7 +116,8 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--nc", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-stride", type=int, default=64)
+    ap.add_argument("--cpu-stride", type=int, default=256)
+    ap.add_argument("--mlp-mode", type=int, default=1, help="1 fused fp16-split MFMA kernel, 0 per-layer fp32 MFMA")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -132,6 +135,7 @@ def main():
 
     from transhuman_amd import hip
     from transhuman_amd.networks.renderer.if_clight_renderer import Renderer
+    hip.set_mlp_mode(args.mlp_mode)
     cfg = get_cfg()
     cfg.N_samples = args.samples
     cfg.num_class = args.nc

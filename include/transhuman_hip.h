@@ -79,6 +79,10 @@ typedef struct {
 /* Copies + re-packs the weights into the MFMA operand layout owned by ctx.
  * `dparf_alpha`/`n_freq`/`knn` = cfg.KNN_DIST_ALPHA / KNN_FREQ / KNN. */
 int th_set_mlp_weights(th_ctx* ctx, const th_mlp_weights* w, th_stream stream);
+/* K6 implementation switch: 1 (default) = one fused kernel per 32-sample tile, dense layers on
+ * v_mfma_f32_32x32x16_f16 with fp16 hi/lo operand splitting (3 products, fp32 accumulate: fp32-class
+ * accuracy); 0 = one fp32-MFMA GEMM launch per layer (exact fp32 products; also the path for V = 4). */
+int th_set_mlp_mode(th_ctx* ctx, int mode);
 int th_set_vit_weights(th_ctx* ctx, int depth, int dim, int heads, const th_vit_block* blocks,
                        const float* norm_w, const float* norm_b, th_stream stream);
 

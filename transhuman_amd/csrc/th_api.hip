@@ -67,6 +67,7 @@ void th_ctx_destroy(th_ctx* c) {
     if (!c) return;
     if (c->mlp_store) (void)hipFree(c->mlp_store);
     if (c->vit_store) (void)hipFree(c->vit_store);
+    if (c->fused_store) (void)hipFree(c->fused_store);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     delete[] c->vit.blocks;
     if (c->prof) {
@@ -169,6 +170,18 @@ int th_set_mlp_weights(th_ctx* c, const th_mlp_weights* w, th_stream stream) {
     else TH_HIP(hipMemsetAsync(M.rgb_b, 0, 12, s));
     TH_HIP(hipStreamSynchronize(s));
     M.ready = true;
+    // fused-kernel image (fp16 hi/lo split, per-wave fragment order)
+    c->fused_ready = false;
+    if (c->fused_store) { TH_HIP(hipFree(c->fused_store)); c->fused_store = nullptr; }
+    TH_HIP(hipMalloc(&c->fused_store, th_fused_pack_bytes()));
+    TH_TRY(th_fused_pack(w, c->fused_store, &c->fused, s));
+    c->fused_ready = true;
+    return 0;
+}
+
+int th_set_mlp_mode(th_ctx* c, int mode) {
+    TH_REQUIRE(c && (mode == 0 || mode == 1), "mode must be 0 (layer-by-layer fp32 MFMA) or 1 (fused fp16-split MFMA)");
+    c->mlp_mode = mode;
     return 0;
 }
 
@@ -329,6 +342,14 @@ static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
     return 0;
 }
 
+// K6 dispatch: fused fp16x3-split kernel (default, V <= 3) or the layer-by-layer fp32 MFMA form
+static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int rgb_all, hipStream_t s) {
+    TH_REQUIRE(c->mlp.ready, "MLP weights not set (th_set_mlp_weights)");
+    if (c->mlp_mode == 1 && c->fused_ready && V <= 3)
+        return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.f, cb.vdc, rgb_all, cb.raw_c, s);
+    return th_mlp_forward(c->mlp, V, m, cb.h, cb.f, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s);
+}
+
 size_t th_network_workspace_bytes(int V, int P) {
     int CH = P < TH_CHUNK ? (P > 0 ? P : 1) : TH_CHUNK;
     return chunk_bytes(V, CH) + th_align((size_t)P * 4) + th_compact_ws(P) + th_align(64);
@@ -370,7 +391,7 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
             TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, s));
             TH_TRY(th_gather_rows_launch(viewdir + 27LL * o, 27, nullptr, 1, m, cb.vdc, s));
         }
-        TH_TRY(th_mlp_forward(c->mlp, V, m, cb.h, cb.f, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s));
+        TH_TRY(mlp_dispatch(c, V, m, cb, idx ? 0 : 1, s));
         if (idx) TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, 0, raw_out, s));
         else TH_TRY(th_scatter_raw_launch(cb.raw_c, nullptr, m, 1, raw_out + 4LL * o, s));
     }
@@ -454,7 +475,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         }
         {
             ProfScope ps3(pf, TH_PROF_MLP, s);
-            TH_TRY(th_mlp_forward(c->mlp, V, m, cb.h, cb.f, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s));
+            TH_TRY(mlp_dispatch(c, V, m, cb, unmasked, s));
         }
         ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));

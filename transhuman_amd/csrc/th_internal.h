@@ -175,7 +175,33 @@ struct ThVitPacked {
     bool ready = false;
 };
 
+// fused MLP image (k_mlp_fused.hip): per layer [wave 4][kb][ct][plane hi/lo][lane 64][8 halves]
+struct FusedLayer {
+    const uint4* w;      // packed fp16 halves
+    const float* bias;   // [N]
+    float inv_scale;     // 2^-scale_log2
+    int CT, KB;
+};
+struct FusedParams {
+    FusedLayer fc_0, kv1, ar0, kv0, fc_1, fc_2, fc_3, feat, rr0, vfc, rr1, fc_4;
+    const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
+    const float* h;     // [P][V][256]
+    const float* f;     // [P][V][384]
+    const float* vd;    // [P][27]
+    float* raw_c;       // [P][4]
+    int P;
+    int rgb_all;
+};
+size_t th_fused_pack_bytes();
+int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStream_t s);
+int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* h,
+                         const float* f, const float* vd, int rgb_all, float* raw_c, hipStream_t s);
+
 struct th_ctx {
+    void* fused_store = nullptr;
+    FusedParams fused{};
+    bool fused_ready = false;
+    int mlp_mode = 1;                 // 1: fused fp16x3-split MFMA kernel, 0: layer-by-layer fp32 MFMA
     int device = 0;
     void* mlp_store = nullptr;
     void* vit_store = nullptr;
