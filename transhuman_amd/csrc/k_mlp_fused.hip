@@ -26,6 +26,8 @@
 // branch) + 124 B; every intermediate of the reference's ~40 kernels/chunk
 // (~70 KB/sample of HBM round trips) stays on chip.
 #include <hip/hip_fp16.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "th_internal.h"
@@ -87,49 +89,65 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ src, int ld
     }
 }
 
-// acc[ct][rt] += W_tile(ct) * A_rows(rt)^T over KB k-blocks of 16 (3-term fp16 split)
+// one k-block (16 deep): acc[c][r] += W(c) * X(r)^T as three fp16 products, ordered term-major so
+// consecutive MFMAs hit different accumulators (no back-to-back dependent issue)
+template <int RT, int CT, int STR>
+__device__ __forceinline__ void gemm_kblock(const char* __restrict__ ahi, const char* __restrict__ alo, int aoff, int kb,
+                                            const uint4 (&w)[CT][2], f32x16 (&acc)[CT][RT]) {
+    h8 xh[RT], xl[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        xh[r] = *reinterpret_cast<const h8*>(ahi + r * 32 * STR + aoff + kb * 32);
+        xl[r] = *reinterpret_cast<const h8*>(alo + r * 32 * STR + aoff + kb * 32);
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&w[c][1]), xh[r], acc[c][r], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&w[c][0]), xl[r], acc[c][r], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&w[c][0]), xh[r], acc[c][r], 0, 0, 0);
+}
+
+template <int CT>
+__device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb, uint4 (&w)[CT][2]) {
+    const uint4* p = wl + (long long)kb * (CT * 2 * 64);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        w[c][0] = p[(c * 2 + 0) * 64];
+        w[c][1] = p[(c * 2 + 1) * 64];
+    }
+}
+
+// acc[ct][rt] += W_tile(ct) * A_rows(rt)^T over KB (even) k-blocks of 16.  The weight fragments
+// ping-pong between two register sets (unrolled by two, no copies), so the loads of block k+1 are
+// in flight during the whole MFMA burst of block k and are waited for only at their first use.
 template <int RT, int CT, int STR>
 __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const char* __restrict__ alo,
                                            const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
-    // this wave's weight stream: per kb: CT x {hi, lo} x 64 lanes x 16 B
-    const uint4* wl = wp + lane;
-    uint4 wc[CT][2], wn[CT][2];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-        wc[c][0] = wl[(c * 2 + 0) * 64];
-        wc[c][1] = wl[(c * 2 + 1) * 64];
-    }
+    const uint4* wl = wp + lane;     // this wave's stream: per kb: CT x {hi, lo} x 64 lanes x 16 B
     const int aoff = (lane & 31) * STR + (lane >> 5) * 16;
-    for (int kb = 0; kb < KB; ++kb) {
-        const uint4* wnext = wl + (long long)(kb + 1) * (CT * 2 * 64);
-        if (kb + 1 < KB) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                wn[c][0] = wnext[(c * 2 + 0) * 64];
-                wn[c][1] = wnext[(c * 2 + 1) * 64];
-            }
-        }
-        h8 xh[RT], xl[RT];
-#pragma unroll
-        for (int r = 0; r < RT; ++r) {
-            xh[r] = *reinterpret_cast<const h8*>(ahi + r * 32 * STR + aoff + kb * 32);
-            xl[r] = *reinterpret_cast<const h8*>(alo + r * 32 * STR + aoff + kb * 32);
-        }
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            h8 wh = *reinterpret_cast<h8*>(&wc[c][0]);
-            h8 wlo = *reinterpret_cast<h8*>(&wc[c][1]);
-#pragma unroll
-            for (int r = 0; r < RT; ++r) {
-                acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wlo, xh[r], acc[c][r], 0, 0, 0);
-                acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[r], acc[c][r], 0, 0, 0);
-                acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[r], acc[c][r], 0, 0, 0);
-            }
-        }
-        if (kb + 1 < KB) {
-#pragma unroll
-            for (int c = 0; c < CT; ++c) { wc[c][0] = wn[c][0]; wc[c][1] = wn[c][1]; }
-        }
+    uint4 w0[CT][2], w1[CT][2];
+    load_wfrag<CT>(wl, 0, w0);
+    // never fully unroll (a constant KB would hoist every weight load of the phase -> VGPR spills)
+#pragma unroll 1
+    for (int kb = 0; kb < KB; kb += 2) {
+        load_wfrag<CT>(wl, kb + 1, w1);
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ABOVE this block's MFMA burst
+        gemm_kblock<RT, CT, STR>(ahi, alo, aoff, kb, w0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kb + 2 < KB) load_wfrag<CT>(wl, kb + 2, w0);
+        __builtin_amdgcn_sched_barrier(0);
+        gemm_kblock<RT, CT, STR>(ahi, alo, aoff, kb + 1, w1, acc);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -195,6 +213,13 @@ __device__ __forceinline__ void store_tile_f(const f32x16& t, int row, int col0,
     }
 }
 
+// barrier + optional cycle stamp (developer aid: TH_FUSED_DBG=1 prints per-phase cycles of one tile)
+#define FM_SYNC()                                                                   \
+    do {                                                                            \
+        __syncthreads();                                                            \
+        if (P.dbg != nullptr && tid == 0 && blockIdx.x == gridDim.x / 2) P.dbg[dbg_i++] = clock64(); \
+    } while (0)
+
 #define ABUF_BYTES (2 * 96 * STR288)
 #define MBUF_BYTES (2 * 32 * STR256)
 #define MISC_FLOATS (9 * 32 + 32 * 4 + 32 * 28 + 4 * 32 * 4 + 8)
@@ -217,6 +242,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     const int npts = min(FM_PTS, P.P - pbase);
     constexpr int ROWS = 32 * V;
     const int myrow = lane & 31;
+    int dbg_i = 0;
+    if (P.dbg != nullptr && tid == 0 && blockIdx.x == gridDim.x / 2) P.dbg[dbg_i++] = clock64();
 
     // ================= token branch: s = relu(fc_0 h); ks|vs = kv1(s) =================
     stage_rows<V, 256, STR256>(P.h, 256, 0, pbase, npts, abuf, abuf + ROWS * STR256, tid);
@@ -224,12 +251,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         int p = i / 28, c = i % 28;
         vds[i] = (p < npts && c < 27) ? P.vd[(long long)(pbase + p) * 27 + c] : 0.f;
     }
-    __syncthreads();
+    FM_SYNC();
     f32x16 acc2[2][V];
     zero_acc<2, V>(acc2);
     gemm_phase<V, 2, STR256>(abuf, abuf + ROWS * STR256, P.fc_0.w + (long long)wave * P.fc_0.KB * (2 * 2 * 64), P.fc_0.KB,
                              lane, acc2);
-    __syncthreads();
+    FM_SYNC();
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         finish_tile<V>(acc2[c], P.fc_0.bias, wave * 64 + c * 32, P.fc_0.inv_scale, true, lane);
@@ -237,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         for (int r = 0; r < V; ++r)
             store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, abuf + ROWS * STR256, lane);
     }
-    __syncthreads();
+    FM_SYNC();
     // kv layers: column tile 0 = key tile `wave` (cols wave*32..), tiles 1,2 = value cols 128 + wave*64 ..
     f32x16 ks[1][V], vs[2][V];
     {
@@ -251,17 +278,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
 #pragma unroll
         for (int r = 0; r < V; ++r) { ks[0][r] = acc3[0][r]; vs[0][r] = acc3[1][r]; vs[1][r] = acc3[2][r]; }
     }
-    __syncthreads();
+    FM_SYNC();
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
     zero_acc<2, V>(acc2);
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
         stage_rows<V, 192, STR192>(P.f, 384, half * 192, pbase, npts, abuf, abuf + ROWS * STR192, tid);
-        __syncthreads();
+        FM_SYNC();
         gemm_phase<V, 2, STR192>(abuf, abuf + ROWS * STR192,
                                  P.ar0.w + ((long long)wave * P.ar0.KB + half * 12) * (2 * 2 * 64), 12, lane, acc2);
-        __syncthreads();
+        FM_SYNC();
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -270,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         for (int r = 0; r < V; ++r)
             store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, abuf + ROWS * STR256, lane);
     }
-    __syncthreads();
+    FM_SYNC();
     f32x16 kp[1][V], vp[2][V];
     {
         f32x16 acc3[3][V];
@@ -283,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
 #pragma unroll
         for (int r = 0; r < V; ++r) { kp[0][r] = acc3[0][r]; vp[0][r] = acc3[1][r]; vp[1][r] = acc3[2][r]; }
     }
-    __syncthreads();
+    FM_SYNC();
 
     // ================= cross-view attention (cross_transformer.py:128-149) =================
     {
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             store_tile_f(kp[0][r], r * 32 + myrow, wave * 32, kpb, lane);
             store_tile_f(ks[0][r], r * 32 + myrow, wave * 32, ksb, lane);
         }
-        __syncthreads();
+        FM_SYNC();
         // A[j][i] = kp_j . ks_i / sqrt(128)
         for (int t = tid; t < 32 * V * V; t += 256) {
             int p = t & 31, ji = t >> 5, j = ji / V, i = ji % V;
@@ -308,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             }
             probs[ji * 32 + p] = s / 11.313708498984761f;
         }
-        __syncthreads();
+        FM_SYNC();
         for (int t = tid; t < 32 * V; t += 256) {                    // softmax over j for each (sample, i)
             int p = t & 31, i = t >> 5;
             float m = -3.0e38f;
@@ -320,7 +347,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
 #pragma unroll
             for (int j = 0; j < V; ++j) probs[(j * V + i) * 32 + p] = e[j] / se;
         }
-        __syncthreads();
+        FM_SYNC();
         float A[V][V];
 #pragma unroll
         for (int j = 0; j < V; ++j)
@@ -344,14 +371,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
                 store_tile_h<STR256>(n, i * 32 + myrow, wave * 64 + c * 32, abuf, abuf + ROWS * STR256, lane);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        __syncthreads();
+        FM_SYNC();
     }
 
     // ================= fc_1, fc_2 =================
     zero_acc<2, V>(acc2);
     gemm_phase<V, 2, STR256>(abuf, abuf + ROWS * STR256, P.fc_1.w + (long long)wave * P.fc_1.KB * (2 * 2 * 64), P.fc_1.KB,
                              lane, acc2);
-    __syncthreads();
+    FM_SYNC();
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         finish_tile<V>(acc2[c], P.fc_1.bias, wave * 64 + c * 32, P.fc_1.inv_scale, true, lane);
@@ -359,11 +386,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         for (int r = 0; r < V; ++r)
             store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, abuf + ROWS * STR256, lane);
     }
-    __syncthreads();
+    FM_SYNC();
     zero_acc<2, V>(acc2);
     gemm_phase<V, 2, STR256>(abuf, abuf + ROWS * STR256, P.fc_2.w + (long long)wave * P.fc_2.KB * (2 * 2 * 64), P.fc_2.KB,
                              lane, acc2);
-    __syncthreads();
+    FM_SYNC();
     // inter = relu(.) stays in registers (acc2) and goes to ABUF for feature_fc; its view mean -> MBUF
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -381,7 +408,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         for (int r = 0; r < V; ++r)
             store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, abuf + ROWS * STR256, lane);
     }
-    __syncthreads();
+    FM_SYNC();
 
     // ================= sigma head: relu(fc_3 m) . alpha_w + b =================
     {
@@ -398,15 +425,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         }
         s += __shfl_xor(s, 32);
         if (lane < 32) part[(wave * 32 + lane) * 4] = s;
-        __syncthreads();
+        FM_SYNC();
         if (tid < 32) {
             float t = part[tid * 4] + part[(32 + tid) * 4] + part[(64 + tid) * 4] + part[(96 + tid) * 4] + P.alpha_b[0];
             sig[tid] = t;
         }
         if (tid == 0) *flag = 0;
-        __syncthreads();
+        FM_SYNC();
         if (tid < npts && (P.rgb_all || sig[tid] > 0.f)) *flag = 1;
-        __syncthreads();
+        FM_SYNC();
     }
     const bool need_rgb = *flag != 0;
     float rgb_out[3] = {0.f, 0.f, 0.f};
@@ -418,16 +445,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         zero_acc<1, V>(r1);
         gemm_phase<V, 2, STR256>(abuf, abuf + ROWS * STR256, P.feat.w + (long long)wave * P.feat.KB * (2 * 2 * 64),
                                  P.feat.KB, lane, acc2);
-        __syncthreads();
+        FM_SYNC();
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
             stage_rows<V, 192, STR192>(P.f, 384, half * 192, pbase, npts, abuf, abuf + ROWS * STR192, tid);
-            __syncthreads();
+            FM_SYNC();
             gemm_phase<V, 2, STR192>(abuf, abuf + ROWS * STR192,
                                      P.rr0.w + ((long long)wave * P.rr0.KB + half * 12) * (2 * 2 * 64), 12, lane, acc2);
             gemm_phase<V, 1, STR192>(abuf, abuf + ROWS * STR192,
                                      P.rr1.w + ((long long)wave * P.rr1.KB + half * 12) * (1 * 2 * 64), 12, lane, r1);
-            __syncthreads();
+            FM_SYNC();
         }
         // feat (+ both biases) | viewdir -> [ROWS][288]
 #pragma unroll
@@ -454,7 +481,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             *reinterpret_cast<_Float16*>(abuf + row * STR288 + 2 * (256 + c)) = a;
             *reinterpret_cast<_Float16*>(abuf + ROWS * STR288 + row * STR288 + 2 * (256 + c)) = b;
         }
-        __syncthreads();
+        FM_SYNC();
         f32x16 vf[1][V];
         zero_acc<1, V>(vf);
         gemm_phase<V, 1, STR288>(abuf, abuf + ROWS * STR288, P.vfc.w + (long long)wave * P.vfc.KB * (1 * 2 * 64), P.vfc.KB,
@@ -472,7 +499,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             }
             store_tile_h<STR128>(m, myrow, wave * 32, mbuf, mbuf + 32 * STR128, lane);
         }
-        __syncthreads();
+        FM_SYNC();
         f32x16 a4[1][1];
         zero_acc<1, 1>(a4);
         gemm_phase<1, 1, STR128>(mbuf, mbuf + 32 * STR128, P.fc_4.w + (long long)wave * P.fc_4.KB * (1 * 2 * 64), P.fc_4.KB,
@@ -492,7 +519,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             part[(wave * 32 + lane) * 4 + 1] = s3[1];
             part[(wave * 32 + lane) * 4 + 2] = s3[2];
         }
-        __syncthreads();
+        FM_SYNC();
         if (tid < 32) {
 #pragma unroll
             for (int o = 0; o < 3; ++o)
@@ -662,11 +689,37 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
         attr = true;
     }
     dim3 grid(th_cdiv(P, FM_PTS));
+    // developer experiment (timing only, results are wrong): alias every layer's weights onto fc_1's image
+    // so the weight working set is 256 KB -> shows how much of a phase is L2-capacity/latency
+    static int alias_w = getenv("TH_FUSED_ALIAS_W") ? 1 : 0;
+    if (alias_w) {
+        FusedLayer* ls[] = {&p.fc_0, &p.kv1, &p.ar0, &p.kv0, &p.fc_2, &p.fc_3, &p.feat, &p.rr0, &p.vfc, &p.rr1, &p.fc_4};
+        for (auto* l : ls) l->w = p.fc_1.w;
+    }
+    // developer aid: TH_FUSED_DBG=1 -> cycle stamps of the middle tile after every barrier (first big launch only)
+    static int dbg_state = getenv("TH_FUSED_DBG") ? 1 : 0;
+    static long long* dbg_dev = nullptr;
+    p.dbg = nullptr;
+    const bool dbg_now = dbg_state == 1 && P >= 4096;
+    if (dbg_now) {
+        if (!dbg_dev) TH_HIP(hipMalloc((void**)&dbg_dev, 64 * sizeof(long long)));
+        TH_HIP(hipMemsetAsync(dbg_dev, 0, 64 * sizeof(long long), s));
+        p.dbg = dbg_dev;
+    }
     switch (V) {
         case 1: hipLaunchKernelGGL(mlp_fused_kernel<1>, grid, dim3(256), FUSED_LDS_BYTES, s, p); break;
         case 2: hipLaunchKernelGGL(mlp_fused_kernel<2>, grid, dim3(256), FUSED_LDS_BYTES, s, p); break;
         default: hipLaunchKernelGGL(mlp_fused_kernel<3>, grid, dim3(256), FUSED_LDS_BYTES, s, p); break;
     }
     TH_LAUNCH_CHECK();
+    if (dbg_now) {
+        long long st[64];
+        TH_HIP(hipStreamSynchronize(s));
+        TH_HIP(hipMemcpy(st, dbg_dev, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[TH_FUSED_DBG] tile %d of %d, cycles between barriers:", grid.x / 2, grid.x);
+        for (int i = 1; i < 64 && st[i] != 0; ++i) fprintf(stderr, " %lld", st[i] - st[i - 1]);
+        fprintf(stderr, "\n");
+        dbg_state = 2;
+    }
     return 0;
 }

@@ -191,6 +191,7 @@ struct FusedParams {
     float* raw_c;       // [P][4]
     int P;
     int rgb_all;
+    long long* dbg;     // optional cycle stamps (TH_FUSED_DBG)
 };
 size_t th_fused_pack_bytes();
 int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStream_t s);
