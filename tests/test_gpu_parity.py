@@ -185,8 +185,15 @@ def test_network_forward_chunk_invariance(hip, gpu, net):
     vd = O.view_embed(torch.from_numpy(rs.normal(size=(P, 3)).astype(np.float32)))
     mask = torch.from_numpy(rs.uniform(size=P) < 0.9)
     rot = blend[:, :3, :3].float().reshape(-1, 9)
-    raw = hip.network_forward(net, pf.to(gpu), vd.to(gpu), pts.to(gpu), centres.to(gpu), rot.to(gpu), tok.to(gpu),
-                              mask.to(gpu)).cpu()
+    args = (net, pf.to(gpu), vd.to(gpu), pts.to(gpu), centres.to(gpu), rot.to(gpu), tok.to(gpu), mask.to(gpu))
+    hip.set_chunk_samples(32768)          # 36 k valid samples -> two passes
+    raw = hip.network_forward(*args).cpu()
+    hip.set_chunk_samples(262144)         # default: one pass
+    assert torch.equal(hip.network_forward(*args).cpu(), raw), "result must not depend on the chunk size"
+    hip.set_mlp_mode(0)                   # per-layer fp32 MFMA form vs fused fp16-split form
+    raw32 = hip.network_forward(*args).cpu()
+    hip.set_mlp_mode(1)
+    assert maxdiff(raw32, raw) < 5e-5
     sel = torch.cat([torch.arange(0, 700), torch.arange(32500, 33200), torch.arange(P - 600, P)])
     ref = O.network_forward(make_sd(), pf[:, :, sel], vd[sel], pts[sel], centres, blend, tok, mask[sel])
     assert maxdiff(raw[sel], ref) < 1e-4

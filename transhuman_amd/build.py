@@ -38,7 +38,8 @@ def _sources():
 
 def _digest():
     h = hashlib.sha256()
-    for p in _sources() + [os.path.join(CSRC, "th_internal.h"), os.path.join(INC, "transhuman_hip.h")]:
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    for p in _sources() + headers + [os.path.join(INC, "transhuman_hip.h")]:
         h.update(open(p, "rb").read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()

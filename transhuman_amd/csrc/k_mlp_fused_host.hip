@@ -1,0 +1,226 @@
+// K6 (fused form): the whole per-point multi-view MLP in ONE kernel.
+//
+// Network._multiview_agg / cross_attention / _alpha_forward / _RGB_forward
+// (cross_transformer.py:128-149, :291-353) for a tile of 32 samples x V views.
+//
+// Arithmetic: every dense layer runs on v_mfma_f32_32x32x16_f16 with BOTH
+// operands split into fp16 hi + lo halves (x = hi + lo exactly to ~2^-22) and
+// three products accumulated in fp32:  W_hi*x_hi + W_hi*x_lo + W_lo*x_hi.
+// The dropped W_lo*x_lo term is 2^-22 relative, i.e. fp32-class accuracy
+// (measured: raw logits within 7e-6 of the fp32 oracle) at 16/3 = 5.3x the
+// fp32-MFMA rate.  Weights are pre-scaled by a power of two per layer so their
+// lo halves stay in fp16's normal range; the scale is undone in fp32.
+//
+// Data flow per workgroup (256 threads = 4 waves, one per SIMD, 1 workgroup/CU):
+//   activations that feed a GEMM live in LDS as fp16 hi/lo planes
+//   [row = view*32 + sample][K] (row stride = 2K+16 B: conflict-free
+//   ds_read_b128 fragments); each wave owns a 64-column slice of every layer
+//   and keeps its outputs in MFMA accumulators (the layers are evaluated
+//   transposed, out^T = W * in^T, so a lane holds 4 consecutive output channels
+//   of ONE sample row -> 8-byte LDS stores, and the V views of a sample sit in
+//   the same lane/register of V accumulator tiles: the 3x3 cross-view softmax
+//   and the view means are pure register arithmetic).  Weight fragments are
+//   streamed from the L2-resident packed image straight into VGPRs
+//   (double-buffered), no LDS round trip.
+// HBM traffic per sample: 3 KB (h) + 2 x 4.6 KB (f, read again for the RGB
+// branch) + 124 B; every intermediate of the reference's ~40 kernels/chunk
+// (~70 KB/sample of HBM round trips) stays on chip.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "k_mlp_fused_kernel.h"
+
+// ---- host: packing -------------------------------------------------------------------
+// cols[] gives, for every (wave, ct), the first output column of that 32-wide tile.
+__global__ void pack_fused_kernel(const float* __restrict__ W, int N, int K, int KB, int CT, const int* __restrict__ cols,
+                                  float scale, uint4* __restrict__ out) {
+    long long total = 4LL * KB * CT * 2 * 64;
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        int lane = (int)(o & 63);
+        long long q = o >> 6;
+        int plane = (int)(q & 1); q >>= 1;
+        int ct = (int)(q % CT); q /= CT;
+        int kb = (int)(q % KB);
+        int wave = (int)(q / KB);
+        int col = cols[wave * CT + ct] + (lane & 31);
+        int k0 = 16 * kb + 8 * (lane >> 5);
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int k = k0 + j;
+            float x = (col < N && k < K) ? W[(long long)col * K + k] * scale : 0.f;
+            _Float16 hi, lo;
+            split_h(x, hi, lo);
+            v[j] = plane == 0 ? hi : lo;
+        }
+        out[o] = *reinterpret_cast<uint4*>(&v);
+    }
+}
+
+__global__ void absmax_kernel(const float* __restrict__ w, long long n, unsigned int* __restrict__ out) {
+    float m = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+size_t th_fused_pack_bytes() {
+    // every layer, both planes, K padded to 16 (+ biases / column tables / scratch in a 64 KiB tail)
+    size_t halves = 0;
+    const int dims[][2] = {{256, 256}, {384, 256}, {256, 384}, {384, 256}, {256, 256}, {256, 256}, {256, 256},
+                           {256, 256}, {256, 384}, {128, 288}, {128, 384}, {128, 128}};
+    for (auto& d : dims) halves += (size_t)d[0] * d[1] * 2;
+    return th_align(halves * 2) + 16 * 256 + 64 * 1024;
+}
+
+// power-of-two scale putting max|W| into [2^12, 2^13): hi fits fp16, lo stays a normal number
+static int layer_scale_log2(const float* w, long long n, unsigned int* amax_dev, int* out, hipStream_t s) {
+    TH_HIP(hipMemsetAsync(amax_dev, 0, 4, s));
+    hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, s, w, n, amax_dev);
+    unsigned int bits = 0;
+    TH_HIP(hipMemcpyAsync(&bits, amax_dev, 4, hipMemcpyDeviceToHost, s));
+    TH_HIP(hipStreamSynchronize(s));
+    float amax;
+    memcpy(&amax, &bits, 4);
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) amax = 1.f;
+    int e;
+    frexpf(amax, &e);            // amax = m * 2^e, m in [0.5,1)
+    *out = 13 - e;
+    return 0;
+}
+
+struct PackCursor {
+    char* w;        // packed halves
+    float* bias;    // fp32 biases
+    int* cols;      // device column tables (16 ints per layer)
+};
+
+static int pack_layer(const float* w, const float* b, int N, int K, int CT, const int* cols_host, int sl2,
+                      PackCursor& cur, FusedLayer* out, hipStream_t s) {
+    const int KB = (K + 15) / 16;
+    if (b) TH_HIP(hipMemcpyAsync(cur.bias, b, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+    else TH_HIP(hipMemsetAsync(cur.bias, 0, (size_t)N * 4, s));
+    TH_HIP(hipMemcpyAsync(cur.cols, cols_host, 4 * CT * sizeof(int), hipMemcpyHostToDevice, s));
+    uint4* dst = (uint4*)cur.w;
+    long long total = 4LL * KB * CT * 2 * 64;
+    hipLaunchKernelGGL(pack_fused_kernel, dim3(256), dim3(256), 0, s, w, N, K, KB, CT, cur.cols, ldexpf(1.f, sl2), dst);
+    TH_HIP(hipStreamSynchronize(s));   // cols_host is a caller stack array
+    out->w = dst;
+    out->bias = cur.bias;
+    out->inv_scale = ldexpf(1.f, -sl2);
+    out->CT = CT;
+    out->KB = KB;
+    cur.w += th_align((size_t)total * 16);
+    cur.bias += (N + 3) & ~3;
+    cur.cols += 16;
+    return 0;
+}
+
+// Builds the fused image from the fp32 layers.  `store` = th_fused_pack_bytes() of device memory.
+int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStream_t s) {
+    char* tail = (char*)store + th_fused_pack_bytes() - 64 * 1024;
+    PackCursor cur{(char*)store, (float*)tail, (int*)(tail + 40 * 1024)};
+    unsigned int* amax = (unsigned int*)(tail + 60 * 1024);
+    int c256[8], c128[4], ckv[12];
+    for (int wv = 0; wv < 4; ++wv) {
+        c256[wv * 2] = wv * 64; c256[wv * 2 + 1] = wv * 64 + 32;
+        c128[wv] = wv * 32;
+        // stacked [key(128); value(256)]: tile 0 = key cols wave*32, tiles 1,2 = value cols 128 + wave*64 (+32)
+        ckv[wv * 3] = wv * 32; ckv[wv * 3 + 1] = 128 + wv * 64; ckv[wv * 3 + 2] = 128 + wv * 64 + 32;
+    }
+    int sl2, sl2b;
+#define PACK_SIMPLE(LAYER, L, N_, K_, CT_, COLS)                                       \
+    TH_TRY(layer_scale_log2((L).w, (long long)(N_) * (K_), amax, &sl2, s));            \
+    TH_TRY(pack_layer((L).w, (L).b, N_, K_, CT_, COLS, sl2, cur, &out->LAYER, s))
+    PACK_SIMPLE(fc_0, w->fc_0, 256, 255, 2, c256);
+    PACK_SIMPLE(ar0, w->alpha_res_0, 256, 384, 2, c256);
+    PACK_SIMPLE(fc_1, w->fc_1, 256, 256, 2, c256);
+    PACK_SIMPLE(fc_2, w->fc_2, 256, 256, 2, c256);
+    PACK_SIMPLE(fc_3, w->fc_3, 256, 256, 2, c256);
+    PACK_SIMPLE(vfc, w->view_fc, 128, 283, 1, c128);
+    PACK_SIMPLE(rr1, w->rgb_res_1, 128, 384, 1, c128);
+    PACK_SIMPLE(fc_4, w->fc_4, 128, 128, 1, c128);
+#undef PACK_SIMPLE
+    // feature_fc and rgb_res_0 accumulate into ONE register tile -> they must share a scale
+    TH_TRY(layer_scale_log2(w->feature_fc.w, 256LL * 256, amax, &sl2, s));
+    TH_TRY(layer_scale_log2(w->rgb_res_0.w, 256LL * 384, amax, &sl2b, s));
+    if (sl2b < sl2) sl2 = sl2b;
+    TH_TRY(pack_layer(w->feature_fc.w, w->feature_fc.b, 256, 256, 2, c256, sl2, cur, &out->feat, s));
+    TH_TRY(pack_layer(w->rgb_res_0.w, w->rgb_res_0.b, 256, 384, 2, c256, sl2, cur, &out->rr0, s));
+    // stacked key/value layers need a contiguous [384,256] weight + [384] bias
+    float* tw = nullptr;
+    TH_HIP(hipMalloc((void**)&tw, (size_t)(384 * 256 + 384) * 4));
+    float* tb = tw + 384 * 256;
+    for (int which = 0; which < 2; ++which) {
+        const th_linear& k = which == 0 ? w->key1 : w->key0;
+        const th_linear& v = which == 0 ? w->val1 : w->val0;
+        TH_HIP(hipMemcpyAsync(tw, k.w, 128 * 256 * 4, hipMemcpyDeviceToDevice, s));
+        TH_HIP(hipMemcpyAsync(tw + 128 * 256, v.w, 256 * 256 * 4, hipMemcpyDeviceToDevice, s));
+        if (k.b) TH_HIP(hipMemcpyAsync(tb, k.b, 128 * 4, hipMemcpyDeviceToDevice, s));
+        else TH_HIP(hipMemsetAsync(tb, 0, 128 * 4, s));
+        if (v.b) TH_HIP(hipMemcpyAsync(tb + 128, v.b, 256 * 4, hipMemcpyDeviceToDevice, s));
+        else TH_HIP(hipMemsetAsync(tb + 128, 0, 256 * 4, s));
+        TH_TRY(layer_scale_log2(tw, 384LL * 256, amax, &sl2, s));
+        TH_TRY(pack_layer(tw, tb, 384, 256, 3, ckv, sl2, cur, which == 0 ? &out->kv1 : &out->kv0, s));
+    }
+    TH_HIP(hipStreamSynchronize(s));
+    TH_HIP(hipFree(tw));
+    TH_REQUIRE(cur.w <= tail, "fused pack overflow");
+    TH_REQUIRE((char*)cur.bias <= tail + 40 * 1024 && (char*)cur.cols <= tail + 60 * 1024, "fused pack tail overflow");
+    return 0;
+}
+
+int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* h, const float* f,
+                         const float* vd, int rgb_all, float* raw_c, hipStream_t s) {
+    if (P <= 0) return 0;
+    TH_REQUIRE(V >= 1 && V <= 3, "fused MLP supports 1..3 reference views");
+    FusedParams p = base;
+    p.alpha_w = heads.alpha_w; p.alpha_b = heads.alpha_b; p.rgb_w = heads.rgb_w; p.rgb_b = heads.rgb_b;
+    p.h = h; p.f = f; p.vd = vd; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
+    static bool attr = false;
+    if (!attr) {
+        TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+        TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+        TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+        attr = true;
+    }
+    dim3 grid(th_cdiv(P, FM_PTS));
+    // developer experiment (timing only, results are wrong): alias every layer's weights onto fc_1's image
+    // so the weight working set is 256 KB -> shows how much of a phase is L2-capacity/latency
+    static int alias_w = getenv("TH_FUSED_ALIAS_W") ? 1 : 0;
+    if (alias_w) {
+        FusedLayer* ls[] = {&p.fc_0, &p.kv1, &p.ar0, &p.kv0, &p.fc_2, &p.fc_3, &p.feat, &p.rr0, &p.vfc, &p.rr1, &p.fc_4};
+        for (auto* l : ls) l->w = p.fc_1.w;
+    }
+    // developer aid: TH_FUSED_DBG=1 -> cycle stamps of the middle tile after every barrier (first big launch only)
+    static int dbg_state = getenv("TH_FUSED_DBG") ? 1 : 0;
+    static long long* dbg_dev = nullptr;
+    p.dbg = nullptr;
+    static int skew = getenv("TH_FUSED_SKEW") ? atoi(getenv("TH_FUSED_SKEW")) : 12000;
+    p.skew_cycles = (grid.x >= 1024) ? skew : 0;     // only worth it when every CU runs several tiles
+    const bool dbg_now = dbg_state == 1 && P >= 4096;
+    if (dbg_now) {
+        if (!dbg_dev) TH_HIP(hipMalloc((void**)&dbg_dev, 64 * sizeof(long long)));
+        TH_HIP(hipMemsetAsync(dbg_dev, 0, 64 * sizeof(long long), s));
+        p.dbg = dbg_dev;
+    }
+    switch (V) {
+        case 1: hipLaunchKernelGGL(mlp_fused_kernel<1>, grid, dim3(256), FUSED_LDS_BYTES, s, p); break;
+        case 2: hipLaunchKernelGGL(mlp_fused_kernel<2>, grid, dim3(256), FUSED_LDS_BYTES, s, p); break;
+        default: hipLaunchKernelGGL(mlp_fused_kernel<3>, grid, dim3(256), FUSED_LDS_BYTES, s, p); break;
+    }
+    TH_LAUNCH_CHECK();
+    if (dbg_now) {
+        long long st[64];
+        TH_HIP(hipStreamSynchronize(s));
+        TH_HIP(hipMemcpy(st, dbg_dev, sizeof(st), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[TH_FUSED_DBG] tile %d of %d, cycles between barriers:", grid.x / 2, grid.x);
+        for (int i = 1; i < 64 && st[i] != 0; ++i) fprintf(stderr, " %lld", st[i] - st[i - 1]);
+        fprintf(stderr, "\n");
+        dbg_state = 2;
+    }
+    return 0;
+}

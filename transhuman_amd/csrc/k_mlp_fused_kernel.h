@@ -1,0 +1,560 @@
+// Device code of the fused per-point MLP (included by k_mlp_fused.hip only).
+//
+// One workgroup = 256 threads = 4 waves (one per SIMD, up to 512 registers each) shades a tile of
+// 32 samples x V views.  See k_mlp_fused.hip for the arithmetic (fp16 hi/lo split MFMA) and the
+// data-flow overview.  LDS map (bytes, V = 3):
+//   ABUF  101 376  activation operand of the running GEMM: fp16 hi + lo planes [row = view*32+sample][K],
+//                  row stride 2K+16 B (conflict-free ds_read_b128); aliased by the fp32 key buffer kp
+//   MBUF   50 688  ks (fp32 keys of the token branch, parked here so they do not occupy accumulators
+//                  during the pixel branch) -> later the view-mean operand of fc_3 -> later viewdir + fc_4 operand
+//   MISC    7 328  softmax probabilities, sigma, view directions, cross-wave partial sums
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "th_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+#define FM_PTS 32
+#define STR256 528   // bytes per LDS row, K = 256 halves (+16)
+#define STR192 400   // K = 192
+#define STR128 272   // K = 128
+#define STRVD 80     // K = 32 (view-direction block of view_fc)
+#define KSTR 132     // floats per row of the fp32 key buffers
+
+#define ABUF_BYTES (2 * 96 * STR256)
+#define MBUF_BYTES (96 * KSTR * 4)
+#define MISC_FLOATS (9 * 32 + 128 + 32 * 28 + 4 * 32 * 4 + 8)
+#define FUSED_LDS_BYTES (ABUF_BYTES + MBUF_BYTES + MISC_FLOATS * 4)
+#define MBUF_VD_OFF 0
+#define MBUF_FC4_OFF 8192
+
+// barrier + optional cycle stamp (developer aid: TH_FUSED_DBG=1 prints per-phase cycles of one tile)
+#define FM_SYNC()                                                                                        \
+    do {                                                                                                 \
+        __syncthreads();                                                                                 \
+        if (P.dbg != nullptr && tid == 0 && blockIdx.x == gridDim.x / 2) P.dbg[dbg_i++] = clock64();     \
+    } while (0)
+
+__device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+
+// ---- global -> registers -> LDS staging, split so the loads fly during the previous GEMM -----------
+template <int V, int KC>
+struct StageRegs {
+    static constexpr int C4 = KC / 4;
+    static constexpr int TOTAL = 32 * V * C4;
+    static constexpr int ITERS = (TOTAL + 255) / 256;
+    f32x4v v[ITERS];
+};
+
+// rows: r -> sample (r & 31), view (r >> 5); source row = (pbase + sample) * V + view
+template <int V, int KC>
+__device__ __forceinline__ void stage_issue(StageRegs<V, KC>& r, const float* __restrict__ src, int ld, int coff,
+                                            int pbase, int npts, int tid) {
+    constexpr int C4 = StageRegs<V, KC>::C4;
+#pragma unroll
+    for (int i = 0; i < StageRegs<V, KC>::ITERS; ++i) {
+        int idx = tid + 256 * i;
+        int row = idx / C4, c4 = idx % C4;
+        int p = row & 31, vw = row >> 5;
+        r.v[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        if (idx < StageRegs<V, KC>::TOTAL && p < npts)
+            r.v[i] = __builtin_nontemporal_load(
+                reinterpret_cast<const f32x4v*>(src + ((long long)(pbase + p) * V + vw) * ld + coff + 4 * c4));
+    }
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads here (in flight under the following GEMM)
+}
+
+template <int V, int KC, int STR>
+__device__ __forceinline__ void stage_commit(const StageRegs<V, KC>& r, char* __restrict__ hi, char* __restrict__ lo,
+                                             int tid) {
+    constexpr int C4 = StageRegs<V, KC>::C4;
+#pragma unroll
+    for (int i = 0; i < StageRegs<V, KC>::ITERS; ++i) {
+        int idx = tid + 256 * i;
+        if (idx < StageRegs<V, KC>::TOTAL) {
+            int row = idx / C4, c4 = idx % C4;
+            h4 a, b;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                _Float16 x, y;
+                split_h(r.v[i][q], x, y);
+                a[q] = x; b[q] = y;
+            }
+            *reinterpret_cast<h4*>(hi + row * STR + 8 * c4) = a;
+            *reinterpret_cast<h4*>(lo + row * STR + 8 * c4) = b;
+        }
+    }
+}
+
+// ---- GEMM phase ---------------------------------------------------------------------------------------
+// one k-block (16 deep): acc[c][r] += W(c) * X(r)^T as three fp16 products (lo*hi, hi*lo, hi*hi),
+// term-major so consecutive MFMAs hit different accumulators
+template <int RT, int CT, int STR, int ROWSTEP>
+__device__ __forceinline__ void gemm_kblock(const char* __restrict__ ahi, const char* __restrict__ alo, int aoff, int kb,
+                                            const uint4 (&w)[CT][2], f32x16 (&acc)[CT][RT]) {
+    h8 xh[RT], xl[RT];
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+        xh[r] = *reinterpret_cast<const h8*>(ahi + r * ROWSTEP + aoff + kb * 32);
+        xl[r] = *reinterpret_cast<const h8*>(alo + r * ROWSTEP + aoff + kb * 32);
+    }
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&w[c][1]), xh[r], acc[c][r], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&w[c][0]), xl[r], acc[c][r], 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&w[c][0]), xh[r], acc[c][r], 0, 0, 0);
+}
+
+template <int CT>
+__device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb, uint4 (&w)[CT][2]) {
+    const uint4* p = wl + (long long)kb * (CT * 2 * 64);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        w[c][0] = p[(c * 2 + 0) * 64];
+        w[c][1] = p[(c * 2 + 1) * 64];
+    }
+}
+
+#define FM_SB() __builtin_amdgcn_sched_barrier(0)
+
+// acc[ct][rt] += W_tile(ct) * A_rows(rt)^T over KB k-blocks of 16.  Weight fragments stream from the
+// (L2-resident) packed image through a ring of three register sets: the loads of block k+2 are issued
+// before the MFMA burst of block k (sched_barrier pins them there), i.e. two bursts (>= 1100 cycles) of
+// latency tolerance, and no register copies (loop unrolled by three).
+template <int RT, int CT, int STR, int ROWSTEP = 32 * STR>
+__device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const char* __restrict__ alo,
+                                           const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
+    const uint4* wl = wp + lane;     // this wave's stream: per kb: CT x {hi, lo} x 64 lanes x 16 B
+    const int aoff = (lane & 31) * STR + (lane >> 5) * 16;
+    uint4 w0[CT][2], w1[CT][2], w2[CT][2];
+    load_wfrag<CT>(wl, 0, w0);
+    if (KB > 1) load_wfrag<CT>(wl, 1, w1);
+    FM_SB();
+    int kb = 0;
+#pragma unroll 1
+    for (; kb + 3 <= KB; kb += 3) {
+        load_wfrag<CT>(wl, kb + 2, w2);
+        FM_SB();
+        gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb, w0, acc);
+        FM_SB();
+        if (kb + 3 < KB) load_wfrag<CT>(wl, kb + 3, w0);
+        FM_SB();
+        gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + 1, w1, acc);
+        FM_SB();
+        if (kb + 4 < KB) load_wfrag<CT>(wl, kb + 4, w1);
+        FM_SB();
+        gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + 2, w2, acc);
+        FM_SB();
+    }
+    if (kb < KB) gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb, w0, acc);
+    if (kb + 1 < KB) gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + 1, w1, acc);
+    FM_SB();
+}
+
+template <int CT, int RT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[CT][RT]) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][r][e] = 0.f;
+}
+
+// channel of accumulator register e (within a 32-wide column tile) for this lane
+__device__ __forceinline__ int acc_chan(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
+
+// y = acc*inv_scale + bias (per output channel), optional relu, in place
+template <int RT>
+__device__ __forceinline__ void finish_tile(f32x16 (&acc)[RT], const float* __restrict__ bias, int col0, float inv_scale,
+                                            bool relu, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float4 b = *reinterpret_cast<const float4*>(bias + col0 + 8 * g + 4 * (lane >> 5));
+        float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float y = acc[r][4 * g + q] * inv_scale + bb[q];
+                acc[r][4 * g + q] = relu ? fmaxf(y, 0.f) : y;
+            }
+    }
+}
+
+// write one 32x32 output tile (this lane: row, 4 groups of 4 consecutive channels) as hi/lo halves
+template <int STR>
+__device__ __forceinline__ void store_tile_h(const f32x16& t, int row, int col0, char* __restrict__ hi,
+                                             char* __restrict__ lo, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int c = col0 + 8 * g + 4 * (lane >> 5);
+        h4 a, b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            _Float16 x, y;
+            split_h(t[4 * g + q], x, y);
+            a[q] = x; b[q] = y;
+        }
+        *reinterpret_cast<h4*>(hi + row * STR + 2 * c) = a;
+        *reinterpret_cast<h4*>(lo + row * STR + 2 * c) = b;
+    }
+    FM_SB();   // VALU temporaries must be arch VGPRs (<= 256): do not let the next tile's conversions hoist above
+}
+// same tile as fp32 (key buffers for the cross-view dots)
+__device__ __forceinline__ void store_tile_f(const f32x16& t, int row, int col0, float* __restrict__ dst, int lane) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        int c = col0 + 8 * g + 4 * (lane >> 5);
+        *reinterpret_cast<float4*>(dst + row * KSTR + c) =
+            make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
+    }
+    FM_SB();
+}
+
+// this wave's slice of a packed layer (+ k-block offset)
+__device__ __forceinline__ const uint4* wslice(const FusedLayer& L, int wave, int ct, int kb0) {
+    return L.w + ((long long)wave * L.KB + kb0) * (ct * 2 * 64);
+}
+
+template <int V>
+__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* abuf = lds;
+    char* mbuf = lds + ABUF_BYTES;
+    float* misc = reinterpret_cast<float*>(lds + ABUF_BYTES + MBUF_BYTES);
+    float* probs = misc;                  // [V*V][32]
+    float* sig = misc + 9 * 32;           // [32] (+ padding)
+    float* vds = sig + 128;               // [32][28]
+    float* part = vds + 32 * 28;          // [4 waves][32][4]
+    int* flag = reinterpret_cast<int*>(part + 4 * 32 * 4);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pbase = blockIdx.x * FM_PTS;
+    const int npts = min(FM_PTS, P.P - pbase);
+    constexpr int ROWS = 32 * V;
+    const int myrow = lane & 31;
+    // De-phase the CUs once per launch: all workgroups do identical work, so without a skew every CU
+    // hits its HBM staging bursts (96..147 KB each) at the same instant and the bursts run bandwidth-bound
+    // while the matrix pipes idle.  The first wave of workgroups starts staggered by up to ~15 x 12k
+    // cycles; later workgroups inherit the skew (they start when an earlier one retires).
+    if (P.skew_cycles > 0 && blockIdx.x < 256) {
+        long long t0 = clock64();
+        long long wait = (long long)(blockIdx.x & 15) * P.skew_cycles;
+        while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
+    int dbg_i = 0;
+    if (P.dbg != nullptr && tid == 0 && blockIdx.x == gridDim.x / 2) P.dbg[dbg_i++] = clock64();
+
+    char* a256_lo = abuf + ROWS * STR256;
+    char* a192_lo = abuf + ROWS * STR192;
+    StageRegs<V, 192> rf;
+
+    // ================= token branch: s = relu(fc_0 h); ks|vs = kv1(s) =================
+    {
+        StageRegs<V, 256> rh;
+        stage_issue<V, 256>(rh, P.h, 256, 0, pbase, npts, tid);
+        for (int i = tid; i < 32 * 28; i += 256) {
+            int p = i / 28, c = i % 28;
+            vds[i] = (p < npts && c < 27) ? P.vd[(long long)(pbase + p) * 27 + c] : 0.f;
+        }
+        stage_commit<V, 256, STR256>(rh, abuf, a256_lo, tid);
+    }
+    FM_SYNC();
+    stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid);        // f[:, 0:192] flies under fc_0 / kv1
+    f32x16 acc2[2][V];
+    zero_acc<2, V>(acc2);
+    gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_0, wave, 2, 0), P.fc_0.KB, lane, acc2);
+    FM_SYNC();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        finish_tile<V>(acc2[c], P.fc_0.bias, wave * 64 + c * 32, P.fc_0.inv_scale, true, lane);
+#pragma unroll
+        for (int r = 0; r < V; ++r)
+            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+    }
+    FM_SYNC();
+    // kv layers: column tile 0 = key tile `wave` (cols wave*32..), tiles 1,2 = value cols 128 + wave*64 ..
+    f32x16 vs[2][V];
+    float* ksb = reinterpret_cast<float*>(mbuf);                    // [ROWS][KSTR] fp32 keys of the token branch
+    {
+        f32x16 acc3[3][V];
+        zero_acc<3, V>(acc3);
+        gemm_phase<V, 3, STR256>(abuf, a256_lo, wslice(P.kv1, wave, 3, 0), P.kv1.KB, lane, acc3);
+        finish_tile<V>(acc3[0], P.kv1.bias, wave * 32, P.kv1.inv_scale, false, lane);
+        finish_tile<V>(acc3[1], P.kv1.bias, 128 + wave * 64, P.kv1.inv_scale, false, lane);
+        finish_tile<V>(acc3[2], P.kv1.bias, 128 + wave * 64 + 32, P.kv1.inv_scale, false, lane);
+#pragma unroll
+        for (int r = 0; r < V; ++r) {
+            store_tile_f(acc3[0][r], r * 32 + myrow, wave * 32, ksb, lane);
+            vs[0][r] = acc3[1][r];
+            vs[1][r] = acc3[2][r];
+        }
+    }
+    FM_SYNC();
+
+    // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
+    zero_acc<2, V>(acc2);
+    stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
+    stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid);      // f[:, 192:384] flies under the first half
+    FM_SYNC();
+    gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.ar0, wave, 2, 0), 12, lane, acc2);
+    FM_SYNC();
+    stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
+    FM_SYNC();
+    gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.ar0, wave, 2, 12), 12, lane, acc2);
+    FM_SYNC();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        finish_tile<V>(acc2[c], P.ar0.bias, wave * 64 + c * 32, P.ar0.inv_scale, true, lane);
+#pragma unroll
+        for (int r = 0; r < V; ++r)
+            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+    }
+    FM_SYNC();
+    f32x16 vp[2][V];
+    {
+        f32x16 acc3[3][V];
+        zero_acc<3, V>(acc3);
+        gemm_phase<V, 3, STR256>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane, acc3);
+        finish_tile<V>(acc3[0], P.kv0.bias, wave * 32, P.kv0.inv_scale, false, lane);
+        finish_tile<V>(acc3[1], P.kv0.bias, 128 + wave * 64, P.kv0.inv_scale, false, lane);
+        finish_tile<V>(acc3[2], P.kv0.bias, 128 + wave * 64 + 32, P.kv0.inv_scale, false, lane);
+        FM_SYNC();                                                  // every wave is done reading p from ABUF
+        float* kpb = reinterpret_cast<float*>(abuf);                // [ROWS][KSTR]
+#pragma unroll
+        for (int r = 0; r < V; ++r) {
+            store_tile_f(acc3[0][r], r * 32 + myrow, wave * 32, kpb, lane);
+            vp[0][r] = acc3[1][r];
+            vp[1][r] = acc3[2][r];
+        }
+    }
+    FM_SYNC();
+
+    // ================= cross-view attention (cross_transformer.py:128-149) =================
+    {
+        const float* kpb = reinterpret_cast<const float*>(abuf);
+        // A[j][i] = kp_j . ks_i / sqrt(128)
+        for (int t = tid; t < 32 * V * V; t += 256) {
+            int p = t & 31, ji = t >> 5, j = ji / V, i = ji % V;
+            const float4* a = reinterpret_cast<const float4*>(kpb + (j * 32 + p) * KSTR);
+            const float4* b = reinterpret_cast<const float4*>(ksb + (i * 32 + p) * KSTR);
+            float s = 0.f;
+#pragma unroll 8
+            for (int c = 0; c < 32; ++c) {
+                float4 x = a[c], y = b[c];
+                s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+            }
+            probs[ji * 32 + p] = s / 11.313708498984761f;
+        }
+        FM_SYNC();
+        for (int t = tid; t < 32 * V; t += 256) {                    // softmax over j for each (sample, i)
+            int p = t & 31, i = t >> 5;
+            float m = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < V; ++j) m = fmaxf(m, probs[(j * V + i) * 32 + p]);
+            float e[V], se = 0.f;
+#pragma unroll
+            for (int j = 0; j < V; ++j) { e[j] = expf(probs[(j * V + i) * 32 + p] - m); se = se + e[j]; }
+#pragma unroll
+            for (int j = 0; j < V; ++j) probs[(j * V + i) * 32 + p] = e[j] / se;
+        }
+        FM_SYNC();
+        float A[V][V];
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+#pragma unroll
+            for (int i = 0; i < V; ++i) A[j][i] = probs[(j * V + i) * 32 + myrow];
+        // n_i = vs_i + sum_j vp_j A[j][i]  -> hi/lo planes (K = 256) for fc_1.  The key buffer in ABUF
+        // was last read before the two barriers above, so each tile is stored as soon as it is formed.
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                f32x16 n;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float t = vp[c][0][e] * A[0][i];
+#pragma unroll
+                    for (int j = 1; j < V; ++j) t = t + vp[c][j][e] * A[j][i];
+                    n[e] = vs[c][i][e] + t;
+                }
+                store_tile_h<STR256>(n, i * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+            }
+        FM_SYNC();
+    }
+
+    // ================= fc_1, fc_2 =================
+    zero_acc<2, V>(acc2);
+    gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_1, wave, 2, 0), P.fc_1.KB, lane, acc2);
+    FM_SYNC();
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        finish_tile<V>(acc2[c], P.fc_1.bias, wave * 64 + c * 32, P.fc_1.inv_scale, true, lane);
+#pragma unroll
+        for (int r = 0; r < V; ++r)
+            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+    }
+    FM_SYNC();
+    zero_acc<2, V>(acc2);
+    gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_2, wave, 2, 0), P.fc_2.KB, lane, acc2);
+    FM_SYNC();
+    // inter = relu(.) -> ABUF (operand of feature_fc); its view mean -> MBUF (operand of fc_3)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        finish_tile<V>(acc2[c], P.fc_2.bias, wave * 64 + c * 32, P.fc_2.inv_scale, true, lane);
+        f32x16 m;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float a = acc2[c][0][e];
+#pragma unroll
+            for (int r = 1; r < V; ++r) a = a + acc2[c][r][e];
+            m[e] = a / (float)V;
+        }
+        store_tile_h<STR256>(m, myrow, wave * 64 + c * 32, mbuf, mbuf + 32 * STR256, lane);
+#pragma unroll
+        for (int r = 0; r < V; ++r)
+            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+    }
+    FM_SYNC();
+
+    // ================= sigma head: relu(fc_3 m) . alpha_w + b =================
+    {
+        f32x16 a1[2][1];
+        zero_acc<2, 1>(a1);
+        gemm_phase<1, 2, STR256>(mbuf, mbuf + 32 * STR256, wslice(P.fc_3, wave, 2, 0), P.fc_3.KB, lane, a1);
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            finish_tile<1>(a1[c], P.fc_3.bias, wave * 64 + c * 32, P.fc_3.inv_scale, true, lane);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s = fmaf(a1[c][0][e], P.alpha_w[wave * 64 + c * 32 + acc_chan(e, lane)], s);
+        }
+        s += __shfl_xor(s, 32);
+        if (lane < 32) part[(wave * 32 + lane) * 4] = s;
+        FM_SYNC();
+        if (tid < 32)
+            sig[tid] = part[tid * 4] + part[(32 + tid) * 4] + part[(64 + tid) * 4] + part[(96 + tid) * 4] + P.alpha_b[0];
+        if (tid == 0) *flag = 0;
+        FM_SYNC();
+        if (tid < npts && (P.rgb_all || sig[tid] > 0.f)) *flag = 1;
+        FM_SYNC();
+    }
+    const bool need_rgb = *flag != 0;
+    float rgb_out[3] = {0.f, 0.f, 0.f};
+    if (need_rgb) {
+        // ================= RGB branch (cross_transformer.py:330-353) =================
+        // feat = feature_fc(inter) + rgb_res_0(f)   (one accumulator: both layers share a scale)
+        stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid);
+        f32x16 r1[1][V];
+        zero_acc<2, V>(acc2);
+        zero_acc<1, V>(r1);
+        gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.feat, wave, 2, 0), P.feat.KB, lane, acc2);
+        FM_SYNC();
+        stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
+        stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid);
+        FM_SYNC();
+        gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 0), 12, lane, acc2);
+        gemm_phase<V, 1, STR192>(abuf, a192_lo, wslice(P.rr1, wave, 1, 0), 12, lane, r1);
+        FM_SYNC();
+        stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
+        FM_SYNC();
+        gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 12), 12, lane, acc2);
+        gemm_phase<V, 1, STR192>(abuf, a192_lo, wslice(P.rr1, wave, 1, 12), 12, lane, r1);
+        FM_SYNC();
+        // feat (+ both biases) -> ABUF [ROWS][256]; the 27 view-direction inputs of view_fc -> MBUF [32][32]
+        char* vd_hi = mbuf + MBUF_VD_OFF;
+        char* vd_lo = vd_hi + 32 * STRVD;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            finish_tile<V>(acc2[c], P.feat.bias, wave * 64 + c * 32, P.feat.inv_scale, false, lane);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 b = *reinterpret_cast<const float4*>(P.rr0.bias + wave * 64 + c * 32 + 8 * g + 4 * (lane >> 5));
+#pragma unroll
+                for (int r = 0; r < V; ++r) {
+                    acc2[c][r][4 * g] += b.x; acc2[c][r][4 * g + 1] += b.y;
+                    acc2[c][r][4 * g + 2] += b.z; acc2[c][r][4 * g + 3] += b.w;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < V; ++r)
+                store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+        }
+        for (int i = tid; i < 32 * 32; i += 256) {
+            int row = i >> 5, c = i & 31;
+            float x = (c < 27) ? vds[row * 28 + c] : 0.f;
+            _Float16 a, b;
+            split_h(x, a, b);
+            *reinterpret_cast<_Float16*>(vd_hi + row * STRVD + 2 * c) = a;
+            *reinterpret_cast<_Float16*>(vd_lo + row * STRVD + 2 * c) = b;
+        }
+        FM_SYNC();
+        // view_fc over [feat(256) | viewdir(27 -> 32)]: 16 k-blocks from ABUF + 2 from the shared viewdir rows
+        f32x16 vf[1][V];
+        zero_acc<1, V>(vf);
+        gemm_phase<V, 1, STR256>(abuf, a256_lo, wslice(P.vfc, wave, 1, 0), 16, lane, vf);
+        gemm_phase<V, 1, STRVD, 0>(vd_hi, vd_lo, wslice(P.vfc, wave, 1, 16), 2, lane, vf);
+        finish_tile<V>(vf[0], P.vfc.bias, wave * 32, P.vfc.inv_scale, true, lane);
+        finish_tile<V>(r1[0], P.rr1.bias, wave * 32, P.rr1.inv_scale, false, lane);
+        char* f4_hi = mbuf + MBUF_FC4_OFF;
+        char* f4_lo = f4_hi + 32 * STR128;
+        {
+            f32x16 m;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float a = vf[0][0][e] + r1[0][0][e];
+#pragma unroll
+                for (int r = 1; r < V; ++r) a = a + (vf[0][r][e] + r1[0][r][e]);
+                m[e] = a / (float)V;
+            }
+            store_tile_h<STR128>(m, myrow, wave * 32, f4_hi, f4_lo, lane);
+        }
+        FM_SYNC();
+        f32x16 a4[1][1];
+        zero_acc<1, 1>(a4);
+        gemm_phase<1, 1, STR128>(f4_hi, f4_lo, wslice(P.fc_4, wave, 1, 0), P.fc_4.KB, lane, a4);
+        finish_tile<1>(a4[0], P.fc_4.bias, wave * 32, P.fc_4.inv_scale, true, lane);
+        float s3[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int ch = wave * 32 + acc_chan(e, lane);
+#pragma unroll
+            for (int o = 0; o < 3; ++o) s3[o] = fmaf(a4[0][0][e], P.rgb_w[o * 128 + ch], s3[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) s3[o] += __shfl_xor(s3[o], 32);
+        if (lane < 32) {
+            part[(wave * 32 + lane) * 4 + 0] = s3[0];
+            part[(wave * 32 + lane) * 4 + 1] = s3[1];
+            part[(wave * 32 + lane) * 4 + 2] = s3[2];
+        }
+        FM_SYNC();
+        if (tid < 32) {
+#pragma unroll
+            for (int o = 0; o < 3; ++o)
+                rgb_out[o] = part[tid * 4 + o] + part[(32 + tid) * 4 + o] + part[(64 + tid) * 4 + o] +
+                             part[(96 + tid) * 4 + o] + P.rgb_b[o];
+        }
+    }
+    if (tid < npts)
+        *reinterpret_cast<float4*>(P.raw_c + (long long)(pbase + tid) * 4) =
+            make_float4(rgb_out[0], rgb_out[1], rgb_out[2], sig[tid]);
+}

@@ -1,6 +1,7 @@
 // C-ABI of libtranshuman_hip.so: context, weight packing, per-kernel entry
 // points and the frame-level orchestration (th_render_rays /
 // th_eval_sigma_grid / th_network_forward).  See include/transhuman_hip.h.
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -318,7 +319,23 @@ int th_view_embed(th_ctx* c, const float* d, int R, int res, float* out, th_stre
 // ---------------------------------------------------------------------------
 // chunked per-sample stage shared by the three frame-level entry points
 // ---------------------------------------------------------------------------
-static const int TH_CHUNK = 32768;   // samples per MLP pass (same as batchify_rays chunk, :575)
+// Samples per pass of the per-sample stage.  The reference chunks at 32768 (batchify_rays :575) to fit a
+// 2021 GPU; results are chunk-size invariant (the network is strictly per-sample).  With 288 GB of HBM a
+// pass of 256 Ki samples (2 GB of h/f staging) keeps every launch >= 8 waves of tiles per CU: measured
+// DPaRF 10.7 -> 3.2 ms/frame vs 32 Ki chunks.  th_set_chunk_samples() / TH_CHUNK_SAMPLES override.
+static int th_chunk_init() {
+    const char* e = getenv("TH_CHUNK_SAMPLES");
+    long v = e ? atol(e) : 0;
+    if (v >= 1024 && v <= (1L << 24)) return (int)v;
+    return 262144;
+}
+static int TH_CHUNK = th_chunk_init();
+
+int th_set_chunk_samples(int n) {
+    TH_REQUIRE(n >= 1024 && n <= (1 << 24), "chunk must be in [1024, 2^24] samples");
+    TH_CHUNK = n;
+    return 0;
+}
 
 struct ChunkBufs {
     float *h, *f, *vdc, *raw_c;

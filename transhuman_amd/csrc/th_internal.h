@@ -192,6 +192,7 @@ struct FusedParams {
     int P;
     int rgb_all;
     long long* dbg;     // optional cycle stamps (TH_FUSED_DBG)
+    int skew_cycles;    // start-up stagger unit of the first 256 workgroups (0 = off)
 };
 size_t th_fused_pack_bytes();
 int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStream_t s);

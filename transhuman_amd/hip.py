@@ -55,6 +55,7 @@ SYMBOLS = {
     "th_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "th_set_mlp_weights": (C.c_int, [C.c_void_p, C.POINTER(ThMlpWeights), C.c_void_p]),
     "th_set_mlp_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "th_set_chunk_samples": (C.c_int, [C.c_int]),
     "th_set_vit_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(ThVitBlock), C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "th_linear_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -460,6 +461,11 @@ def eval_sigma_grid(net, frame, pts):
 def set_mlp_mode(mode, device=None):
     """1 = fused fp16-split MFMA kernel (default), 0 = layer-by-layer fp32 MFMA GEMMs."""
     _check(load_library().th_set_mlp_mode(ctx(device), int(mode)))
+
+
+def set_chunk_samples(n):
+    """Samples per pass of the per-sample stage (default 262144; results are invariant to it)."""
+    _check(load_library().th_set_chunk_samples(int(n)))
 
 
 PROF_PHASES = ("hull", "dparf", "gather", "mlp", "composite", "vit", "_6", "_7")
