@@ -1,0 +1,64 @@
+"""CPU: the N>1 path (ray-tile sharding + image gather) with torch.distributed `gloo`,
+world_size 2 and 3 (ragged shards), one process per rank like the GPU launch.
+
+The per-rank "renderer" here is the CPU oracle's compositing on random raw values: the point is
+the sharding / gather plumbing (transhuman_amd/dist.py), which is backend-agnostic; on the GPU box
+the same code runs over RCCL (bench.py --gpus N)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from transhuman_amd.dist import gather_image, shard_ray_indices
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, H, W, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(1234)
+        full = torch.rand((H * W, 5), generator=g)            # what a single GPU would render
+        idx = shard_ray_indices(H, W, world, rank, tile=8)
+        local = full[idx].clone()                              # this rank's rays
+        # global decision of the reference's R' <= 2400 switch: sum of per-rank hit counts
+        hits = torch.tensor([int((local[:, 3] > 0.5).sum())])
+        dist.all_reduce(hits)
+        img = gather_image(local, idx, H * W, world)
+        ok = torch.equal(img, full) and int(hits) == int((full[:, 3] > 0.5).sum())
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, H, W):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, W, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r for r, _ in res) == list(range(world))
+    assert all(ok for _, ok in res)
+
+
+def test_gather_world2_balanced():
+    _run(2, 64, 64)
+
+
+def test_gather_world3_ragged_tiles():
+    _run(3, 40, 56)          # 5 x 7 tiles over 3 ranks: unequal shard lengths -> padded all_gather
