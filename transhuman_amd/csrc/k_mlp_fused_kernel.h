@@ -65,8 +65,12 @@ __device__ __forceinline__ void stage_issue(StageRegs<V, KC>& r, const float* __
         int p = row & 31, vw = row >> 5;
         r.v[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         if (idx < StageRegs<V, KC>::TOTAL && p < npts)
+#ifndef FM_NT_STAGE_LOADS
+            r.v[i] = *reinterpret_cast<const f32x4v*>(src + ((long long)(pbase + p) * V + vw) * ld + coff + 4 * c4);
+#else
             r.v[i] = __builtin_nontemporal_load(
                 reinterpret_cast<const f32x4v*>(src + ((long long)(pbase + p) * V + vw) * ld + coff + 4 * c4));
+#endif
     }
     __builtin_amdgcn_sched_barrier(0);   // keep the loads here (in flight under the following GEMM)
 }
@@ -133,6 +137,17 @@ __device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb,
 }
 
 #define FM_SB() __builtin_amdgcn_sched_barrier(0)
+
+// staging policy: loads of the next operand are issued right before they are committed to LDS
+// (FM_EARLY_STAGE would issue them one GEMM earlier; vmcnt retires in order, so the GEMM's first weight
+// wait then also waits for the whole staging burst -- measured slower)
+#ifdef FM_EARLY_STAGE
+#define FM_EARLY(...) __VA_ARGS__
+#define FM_LATE(...)
+#else
+#define FM_EARLY(...)
+#define FM_LATE(...) __VA_ARGS__
+#endif
 
 // acc[ct][rt] += W_tile(ct) * A_rows(rt)^T over KB k-blocks of 16.  Weight fragments stream from the
 // (L2-resident) packed image through a ring of three register sets: the loads of block k+2 are issued
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         stage_commit<V, 256, STR256>(rh, abuf, a256_lo, tid);
     }
     FM_SYNC();
-    stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid);        // f[:, 0:192] flies under fc_0 / kv1
+    FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));   // early mode: f[:, 0:192] flies under fc_0 / kv1
     f32x16 acc2[2][V];
     zero_acc<2, V>(acc2);
     gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_0, wave, 2, 0), P.fc_0.KB, lane, acc2);
@@ -312,11 +327,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
     zero_acc<2, V>(acc2);
+    FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));
     stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
-    stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid);      // f[:, 192:384] flies under the first half
+    FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
     FM_SYNC();
     gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.ar0, wave, 2, 0), 12, lane, acc2);
     FM_SYNC();
+    FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
     stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
     FM_SYNC();
     gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.ar0, wave, 2, 12), 12, lane, acc2);
@@ -462,18 +479,20 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     if (need_rgb) {
         // ================= RGB branch (cross_transformer.py:330-353) =================
         // feat = feature_fc(inter) + rgb_res_0(f)   (one accumulator: both layers share a scale)
-        stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid);
+        FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));
         f32x16 r1[1][V];
         zero_acc<2, V>(acc2);
         zero_acc<1, V>(r1);
         gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.feat, wave, 2, 0), P.feat.KB, lane, acc2);
         FM_SYNC();
+        FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));
         stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
-        stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid);
+        FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
         FM_SYNC();
         gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 0), 12, lane, acc2);
         gemm_phase<V, 1, STR192>(abuf, a192_lo, wslice(P.rr1, wave, 1, 0), 12, lane, r1);
         FM_SYNC();
+        FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
         stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
         FM_SYNC();
         gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 12), 12, lane, acc2);

@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtranshuman_hip.so")
+# TH_LIB_PATH: developer override to A/B an experimental build of the same ABI
+LIB_PATH = os.environ.get("TH_LIB_PATH") or os.path.join(_HERE, "libtranshuman_hip.so")
 
 c_float_p = C.POINTER(C.c_float)
 
