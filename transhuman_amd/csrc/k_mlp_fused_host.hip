@@ -119,6 +119,30 @@ static int pack_layer(const float* w, const float* b, int N, int K, int CT, cons
     return 0;
 }
 
+// ---- algebraic fold of value_embed into fc_1 ------------------------------------------------------------
+// cross_attention returns n_i = (V1 s_i + b1) + sum_j A[j][i] (V0 p_j + b0)  (cross_transformer.py:145-147)
+// and the very next op is fc_1 (linear, :319).  softmax over j sums to 1, hence
+//   fc_1(n_i) = (F V1) s_i + sum_j A[j][i] (F V0) p_j + F (b1 + b0) + b_F .
+// The fused kernel therefore evaluates the two products F*V1, F*V0 in place of the value projections and has
+// no separate fc_1 GEMM: one 256x256 layer per row (8.5 % of the MACs) and one barrier-delimited phase less.
+// The products are formed once at weight-upload time with fp64 accumulation.
+__global__ void fold_matmul_kernel(const float* __restrict__ F, const float* __restrict__ Vw, float* __restrict__ out) {
+    int o = blockIdx.x, k = threadIdx.x;
+    double acc = 0.0;
+    for (int m = 0; m < 256; ++m) acc += (double)F[o * 256 + m] * (double)Vw[m * 256 + k];
+    out[o * 256 + k] = (float)acc;
+}
+__global__ void fold_bias_kernel(const float* __restrict__ F, const float* __restrict__ bF, const float* __restrict__ b1,
+                                 const float* __restrict__ b0, float* __restrict__ out) {
+    int o = threadIdx.x;
+    double acc = bF ? (double)bF[o] : 0.0;
+    for (int m = 0; m < 256; ++m) {
+        double bm = (b1 ? (double)b1[m] : 0.0) + (b0 ? (double)b0[m] : 0.0);
+        acc += (double)F[o * 256 + m] * bm;
+    }
+    out[o] = (float)acc;
+}
+
 // Builds the fused image from the fp32 layers.  `store` = th_fused_pack_bytes() of device memory.
 int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStream_t s) {
     char* tail = (char*)store + th_fused_pack_bytes() - 64 * 1024;
@@ -158,14 +182,18 @@ int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStr
         const th_linear& k = which == 0 ? w->key1 : w->key0;
         const th_linear& v = which == 0 ? w->val1 : w->val0;
         TH_HIP(hipMemcpyAsync(tw, k.w, 128 * 256 * 4, hipMemcpyDeviceToDevice, s));
-        TH_HIP(hipMemcpyAsync(tw + 128 * 256, v.w, 256 * 256 * 4, hipMemcpyDeviceToDevice, s));
+        // value rows <- fc_1.W * value_embed.W (fold, see above); their bias moves into fc_1's folded bias
+        hipLaunchKernelGGL(fold_matmul_kernel, dim3(256), dim3(256), 0, s, w->fc_1.w, v.w, tw + 128 * 256);
         if (k.b) TH_HIP(hipMemcpyAsync(tb, k.b, 128 * 4, hipMemcpyDeviceToDevice, s));
         else TH_HIP(hipMemsetAsync(tb, 0, 128 * 4, s));
-        if (v.b) TH_HIP(hipMemcpyAsync(tb + 128, v.b, 256 * 4, hipMemcpyDeviceToDevice, s));
-        else TH_HIP(hipMemsetAsync(tb + 128, 0, 256 * 4, s));
+        TH_HIP(hipMemsetAsync(tb + 128, 0, 256 * 4, s));
         TH_TRY(layer_scale_log2(tw, 384LL * 256, amax, &sl2, s));
         TH_TRY(pack_layer(tw, tb, 384, 256, 3, ckv, sl2, cur, which == 0 ? &out->kv1 : &out->kv0, s));
     }
+    // folded bias of fc_1 (the packed fc_1 weights above are no longer read by the kernel)
+    hipLaunchKernelGGL(fold_bias_kernel, dim3(1), dim3(256), 0, s, w->fc_1.w, w->fc_1.b, w->val1.b, w->val0.b, cur.bias);
+    out->fc_1.bias = cur.bias;
+    cur.bias += 256;
     TH_HIP(hipStreamSynchronize(s));
     TH_HIP(hipFree(tw));
     TH_REQUIRE(cur.w <= tail, "fused pack overflow");

@@ -153,33 +153,34 @@ __device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb,
 // (L2-resident) packed image through a ring of three register sets: the loads of block k+2 are issued
 // before the MFMA burst of block k (sched_barrier pins them there), i.e. two bursts (>= 1100 cycles) of
 // latency tolerance, and no register copies (loop unrolled by three).
-template <int RT, int CT, int STR, int ROWSTEP = 32 * STR>
+template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = 3>
 __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const char* __restrict__ alo,
                                            const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
     const uint4* wl = wp + lane;     // this wave's stream: per kb: CT x {hi, lo} x 64 lanes x 16 B
     const int aoff = (lane & 31) * STR + (lane >> 5) * 16;
-    uint4 w0[CT][2], w1[CT][2], w2[CT][2];
-    load_wfrag<CT>(wl, 0, w0);
-    if (KB > 1) load_wfrag<CT>(wl, 1, w1);
+    // ring of D register sets; block k+D-1 is requested before the MFMA burst of block k.
+    // D = 3 for the wide phases (burst >= 576 cycles); the short-burst phases (one row tile or one
+    // column tile per wave) use a deeper ring to cover the same latency.
+    uint4 w[D][CT][2];
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j)
+        if (j < KB) load_wfrag<CT>(wl, j, w[j]);
     FM_SB();
     int kb = 0;
 #pragma unroll 1
-    for (; kb + 3 <= KB; kb += 3) {
-        load_wfrag<CT>(wl, kb + 2, w2);
-        FM_SB();
-        gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb, w0, acc);
-        FM_SB();
-        if (kb + 3 < KB) load_wfrag<CT>(wl, kb + 3, w0);
-        FM_SB();
-        gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + 1, w1, acc);
-        FM_SB();
-        if (kb + 4 < KB) load_wfrag<CT>(wl, kb + 4, w1);
-        FM_SB();
-        gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + 2, w2, acc);
-        FM_SB();
+    for (; kb + D <= KB; kb += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            if (kb + j + D - 1 < KB) load_wfrag<CT>(wl, kb + j + D - 1, w[(j + D - 1) % D]);
+            FM_SB();
+            gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, w[j], acc);
+            FM_SB();
+        }
     }
-    if (kb < KB) gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb, w0, acc);
-    if (kb + 1 < KB) gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + 1, w1, acc);
+    // tail (KB % D blocks): their fragments were requested by the guarded loads above
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j)
+        if (kb + j < KB) gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, w[j], acc);
     FM_SB();
 }
 
@@ -399,37 +400,34 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         for (int j = 0; j < V; ++j)
 #pragma unroll
             for (int i = 0; i < V; ++i) A[j][i] = probs[(j * V + i) * 32 + myrow];
-        // n_i = vs_i + sum_j vp_j A[j][i]  -> hi/lo planes (K = 256) for fc_1.  The key buffer in ABUF
-        // was last read before the two barriers above, so each tile is stored as soon as it is formed.
+        // vs / vp hold (F V1) s_i and (F V0) p_j  (value_embed folded into fc_1, see k_mlp_fused_host.hip):
+        //   fc_1 pre-activation of view i = vs_i + sum_j vp_j A[j][i] + folded bias ; relu ; -> operand of fc_2.
+        // The key buffer in ABUF was last read before the two barriers above, so each tile is stored as
+        // soon as it is formed.
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 f32x16 n;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float t = vp[c][0][e] * A[0][i];
+                for (int g = 0; g < 4; ++g) {
+                    float4 b4 = *reinterpret_cast<const float4*>(P.fc_1.bias + wave * 64 + c * 32 + 8 * g + 4 * (lane >> 5));
+                    float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                    for (int j = 1; j < V; ++j) t = t + vp[c][j][e] * A[j][i];
-                    n[e] = vs[c][i][e] + t;
+                    for (int q = 0; q < 4; ++q) {
+                        int e = 4 * g + q;
+                        float t = vp[c][0][e] * A[0][i];
+#pragma unroll
+                        for (int j = 1; j < V; ++j) t = t + vp[c][j][e] * A[j][i];
+                        n[e] = fmaxf((vs[c][i][e] + t) + bb[q], 0.f);
+                    }
                 }
                 store_tile_h<STR256>(n, i * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
             }
         FM_SYNC();
     }
 
-    // ================= fc_1, fc_2 =================
-    zero_acc<2, V>(acc2);
-    gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_1, wave, 2, 0), P.fc_1.KB, lane, acc2);
-    FM_SYNC();
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        finish_tile<V>(acc2[c], P.fc_1.bias, wave * 64 + c * 32, P.fc_1.inv_scale, true, lane);
-#pragma unroll
-        for (int r = 0; r < V; ++r)
-            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
-    }
-    FM_SYNC();
+    // ================= fc_2 (fc_1 is folded into the value projections) =================
     zero_acc<2, V>(acc2);
     gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_2, wave, 2, 0), P.fc_2.KB, lane, acc2);
     FM_SYNC();
@@ -456,7 +454,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     {
         f32x16 a1[2][1];
         zero_acc<2, 1>(a1);
-        gemm_phase<1, 2, STR256>(mbuf, mbuf + 32 * STR256, wslice(P.fc_3, wave, 2, 0), P.fc_3.KB, lane, a1);
+        gemm_phase<1, 2, STR256, 32 * STR256, 6>(mbuf, mbuf + 32 * STR256, wslice(P.fc_3, wave, 2, 0), P.fc_3.KB, lane, a1);
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -490,13 +488,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
         FM_SYNC();
         gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 0), 12, lane, acc2);
-        gemm_phase<V, 1, STR192>(abuf, a192_lo, wslice(P.rr1, wave, 1, 0), 12, lane, r1);
+        gemm_phase<V, 1, STR192, 32 * STR192, 5>(abuf, a192_lo, wslice(P.rr1, wave, 1, 0), 12, lane, r1);
         FM_SYNC();
         FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
         stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
         FM_SYNC();
         gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 12), 12, lane, acc2);
-        gemm_phase<V, 1, STR192>(abuf, a192_lo, wslice(P.rr1, wave, 1, 12), 12, lane, r1);
+        gemm_phase<V, 1, STR192, 32 * STR192, 5>(abuf, a192_lo, wslice(P.rr1, wave, 1, 12), 12, lane, r1);
         FM_SYNC();
         // feat (+ both biases) -> ABUF [ROWS][256]; the 27 view-direction inputs of view_fc -> MBUF [32][32]
         char* vd_hi = mbuf + MBUF_VD_OFF;
@@ -529,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         // view_fc over [feat(256) | viewdir(27 -> 32)]: 16 k-blocks from ABUF + 2 from the shared viewdir rows
         f32x16 vf[1][V];
         zero_acc<1, V>(vf);
-        gemm_phase<V, 1, STR256>(abuf, a256_lo, wslice(P.vfc, wave, 1, 0), 16, lane, vf);
+        gemm_phase<V, 1, STR256, 32 * STR256, 5>(abuf, a256_lo, wslice(P.vfc, wave, 1, 0), 16, lane, vf);
         gemm_phase<V, 1, STRVD, 0>(vd_hi, vd_lo, wslice(P.vfc, wave, 1, 16), 2, lane, vf);
         finish_tile<V>(vf[0], P.vfc.bias, wave * 32, P.vfc.inv_scale, true, lane);
         finish_tile<V>(r1[0], P.rr1.bias, wave * 32, P.rr1.inv_scale, false, lane);
@@ -549,7 +547,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         FM_SYNC();
         f32x16 a4[1][1];
         zero_acc<1, 1>(a4);
-        gemm_phase<1, 1, STR128>(f4_hi, f4_lo, wslice(P.fc_4, wave, 1, 0), P.fc_4.KB, lane, a4);
+        gemm_phase<1, 1, STR128, 32 * STR128, 8>(f4_hi, f4_lo, wslice(P.fc_4, wave, 1, 0), P.fc_4.KB, lane, a4);
         finish_tile<1>(a4[0], P.fc_4.bias, wave * 32, P.fc_4.inv_scale, true, lane);
         float s3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
