@@ -139,6 +139,25 @@ int th_segment_mean_rot_f64(th_ctx* ctx, const double* blend, const int32_t* csr
                             const int32_t* csr_members, int n_clusters, float* rot_out,
                             th_stream stream);
 
+/* ---- K8: encoder tail written channels-last + painting from that map ------ */
+/* encoder.py:133-146: bilinear-upsample (align_corners=True) the three ResNet latents
+ * lat0 [V,64,h0,w0], lat1 [V,64,h1,w1], lat2 [V,128,h2,w2] to HxW, append upsample_color(img)
+ * (1x1 conv 3->128, color_w [128,3], color_b [128]) and write pixel_feat_map DIRECTLY channels-last
+ * [V,H,W,384] (the layout K5 gathers from).  dims_host = {h0,w0,h1,w1,h2,w2} (host ints). */
+int th_upsample_concat_nhwc(th_ctx* ctx, const float* img, const float* lat0, const float* lat1,
+                            const float* lat2, const int32_t* dims_host, int V, int H, int W,
+                            const float* color_w, const float* color_b, float* out_nhwc, th_stream stream);
+/* paint_neural_human + can_body_grouping without materialising holder_feat_map: reduction_layer
+ * (1x1 conv C->out_f, encoder.py:85,146) commutes with the bilinear sampling at :168-172, so the C-channel
+ * channels-last map is sampled at the projected vertices and the layer is applied to those V*n_verts
+ * rows; then the vizmap zeroing (:181-182) and the cluster mean (:356-371).  tokens_out [V,N_c,out_f]. */
+size_t th_paint_group_nhwc_workspace_bytes(int V, int n_verts, int C, int out_f);
+int th_paint_group_nhwc(th_ctx* ctx, const float* map_nhwc, int V, int H, int W, int C,
+                        const float* verts_world, int n_verts, const float* cams, const float* scale_xy,
+                        const uint8_t* vizmap, const th_linear* reduction, const int32_t* csr_offsets,
+                        const int32_t* csr_members, int n_clusters, float* tokens_out, void* workspace,
+                        size_t workspace_bytes, th_stream stream);
+
 /* ---- K3: TransHE (ViT-tiny) ---------------------------------------------- */
 /* VisionTransformer.forward, vision_transformer.py:371-383.  x [V,N,dim]
  * tokens, pe [V,N,dim] sin-cos table (host-built, see vision_transformer.py),

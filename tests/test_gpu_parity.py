@@ -311,3 +311,29 @@ def test_dense_frame_properties(hip, gpu, net):
     assert int(hit.sum()) == st["hit_rays"] and int(m.sum()) == st["valid_samples"]
     assert (o1["rgb_map"][0][~hit] == 0).all() and (acc[~hit] == 0).all()
     assert st["hit_rays"] > 20000
+
+
+def test_fused_encoder_tail_equals_reference_order(hip, gpu, net):
+    """K8: channels-last map written by one kernel + reduction applied after sampling == encoder() then paint"""
+    _cfg(32)
+    b = synth.batch_to(synth.make_batch(64, 48, 3, seed=0, focal=150.0), gpu)       # non-square image, too
+    r = _renderer(net)
+    imgs = b["input_imgs"][0][0]
+    with torch.no_grad():
+        hol, hs, pix, ps = net.encoder(imgs)
+        lat = net.encoder.trunk(imgs)
+    nhwc = hip.upsample_concat_nhwc(imgs, lat[0], lat[1], lat[2], net.encoder.upsample_color.weight,
+                                    net.encoder.upsample_color.bias)
+    assert maxdiff(nhwc.permute(0, 3, 1, 2).cpu(), pix.cpu()) < 2e-5
+    f_ref = r.prepare_frame(b, fused_encoder_tail=False)
+    g_ref = r.last_grouped.clone()
+    f_new = r.prepare_frame(b, fused_encoder_tail=True)
+    assert maxdiff(r.last_grouped.cpu(), g_ref.cpu()) < 5e-5
+    assert maxdiff(f_new.tokens.cpu(), f_ref.tokens.cpu()) < 1e-4
+    g13 = gold("g13_encoder")
+    b32 = synth.batch_to(synth.make_batch(32, 32, 3, seed=0), gpu)
+    i32 = b32["input_imgs"][0][0]
+    lat = net.encoder.trunk(i32)
+    n32 = hip.upsample_concat_nhwc(i32, lat[0], lat[1], lat[2], net.encoder.upsample_color.weight,
+                                   net.encoder.upsample_color.bias)
+    assert maxdiff(n32.permute(0, 3, 1, 2)[:, :, ::8, ::8].cpu(), g13["pixel_px"]) < 1e-4

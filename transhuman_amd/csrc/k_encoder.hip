@@ -1,0 +1,113 @@
+// K8: tail of SpatialEncoder.forward written channels-last, + painting from the channels-last map.
+//
+// encoder.py:133-146: the three ResNet latents (64ch @H/2, 64ch @H/4, 128ch @H/8) are bilinearly
+// upsampled (align_corners=True) to HxW, concatenated with upsample_color(img) (1x1 conv 3->128) into the
+// 384-channel pixel_feat_map, and reduction_layer (1x1 conv 384->192) makes holder_feat_map.  The
+// reference materialises both maps NCHW (1.2 GB + 0.6 GB per frame) through six torch kernels; the
+// per-sample gather (K5) wants channels-last.  Here ONE kernel writes the channels-last map directly
+// (1.2 GB written once, nothing re-read), and holder_feat_map is never built: it is only ever sampled at
+// the 3 x 6890 projected SMPL vertices (if_clight_renderer.py:168-172), and a 1x1 conv commutes with
+// bilinear sampling, so the 384-ch map is sampled at the vertices and the 384->192 layer is applied to
+// those 20 670 rows (th_gemm) before the visibility mask and the cluster mean.
+// Bound: HBM write stream (1.2 GB/frame); the latents (75 MB) stay L2/MALL resident.
+#include "th_internal.h"
+
+struct UpsSrc {
+    const float* p;    // [V, C, h, w]
+    int C, h, w;
+    int c0;            // first output channel
+};
+
+// torch upsample_bilinear2d(align_corners=True): src = dst * (in-1)/(out-1)
+__device__ __forceinline__ void ups_coord(int dst, int in, int out, int& i0, int& i1, float& l0, float& l1) {
+    float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    float src = scale * (float)dst;
+    i0 = (int)src;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+// grid (W/64, H, V*6): z%6 selects a 64-channel group: 0 lat0, 1 lat1, 2..3 lat2, 4..5 colour.
+// Phase 1: lane = x (coalesced source reads along x), waves stride over the group's 64 channels -> LDS tile.
+// Phase 2: 64 channels of a pixel are 256 contiguous bytes of the NHWC map.
+__global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, UpsSrc s1, UpsSrc s2,
+                                                                   const float* __restrict__ img,
+                                                                   const float* __restrict__ wc,
+                                                                   const float* __restrict__ bc, int H, int W,
+                                                                   float* __restrict__ out) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane, y = blockIdx.y;
+    const int v = blockIdx.z / 6, grp = blockIdx.z % 6;
+    int cout0;
+    if (grp < 4) {
+        UpsSrc s = grp == 0 ? s0 : (grp == 1 ? s1 : s2);
+        int cin0 = grp == 3 ? 64 : 0;
+        cout0 = s.c0 + cin0;
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        ups_coord(y, s.h, H, y0, y1, ly0, ly1);
+        ups_coord(x < W ? x : W - 1, s.w, W, x0, x1, lx0, lx1);
+        const float* base = s.p + ((long long)v * s.C + cin0) * s.h * s.w;
+        for (int c = wave; c < 64; c += 4) {
+            const float* pl = base + (long long)c * s.h * s.w;
+            float v00 = pl[y0 * s.w + x0], v01 = pl[y0 * s.w + x1], v10 = pl[y1 * s.w + x0], v11 = pl[y1 * s.w + x1];
+            tile[lane][c] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+        }
+    } else {
+        int cin0 = (grp - 4) * 64;
+        cout0 = 256 + cin0;
+        int xx = x < W ? x : W - 1;
+        long long hw = (long long)H * W;
+        const float* ip = img + (long long)v * 3 * hw + (long long)y * W + xx;
+        float r = ip[0], g = ip[hw], b = ip[2 * hw];
+        for (int c = wave; c < 64; c += 4) {
+            const float* w = wc + (cin0 + c) * 3;
+            tile[lane][c] = fmaf(b, w[2], fmaf(g, w[1], r * w[0])) + bc[cin0 + c];
+        }
+    }
+    __syncthreads();
+    float* orow = out + (((long long)v * H + y) * W + (long long)blockIdx.x * 64) * 384 + cout0;
+    for (int px = wave; px < 64; px += 4)
+        if (blockIdx.x * 64 + px < W) orow[(long long)px * 384 + lane] = tile[px][lane];
+}
+
+int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
+                              const int* dims /* h0,w0,h1,w1,h2,w2 */, int V, int H, int W, const float* wc,
+                              const float* bc, float* out, hipStream_t s) {
+    UpsSrc s0{lat0, 64, dims[0], dims[1], 0};
+    UpsSrc s1{lat1, 64, dims[2], dims[3], 64};
+    UpsSrc s2{lat2, 128, dims[4], dims[5], 128};
+    hipLaunchKernelGGL(upsample_concat_nhwc_kernel, dim3(th_cdiv(W, 64), H, V * 6), dim3(256), 0, s, s0, s1, s2, img, wc,
+                       bc, H, W, out);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+// tokens[v][c][:] = mean over cluster members m of ( visible(v,m) ? rows[(m*V + v)][:] : 0 )
+// (rows come from the [P,V,C] gather layout; invisible vertices count as zeros, if_clight_renderer.py:181-182,:364)
+__global__ void segmean_masked_kernel(const float* __restrict__ rows, int V, int width, const uint8_t* __restrict__ viz,
+                                      int nv, const int32_t* __restrict__ off, const int32_t* __restrict__ mem, int nc,
+                                      float* __restrict__ out) {
+    int c = blockIdx.x, v = blockIdx.y;
+    int s0 = off[c], s1 = off[c + 1];
+    float n = (float)(s1 - s0);
+    for (int k = threadIdx.x; k < width; k += blockDim.x) {
+        float acc = 0.f;
+        for (int j = s0; j < s1; ++j) {
+            int m = mem[j];
+            float val = (!viz || viz[(long long)v * nv + m]) ? rows[((long long)m * V + v) * width + k] : 0.f;
+            acc = acc + val;
+        }
+        out[((long long)v * nc + c) * width + k] = acc / n;
+    }
+}
+
+int th_segmean_masked_launch(const float* rows, int V, int width, const uint8_t* viz, int nv, const int32_t* off,
+                             const int32_t* mem, int nc, float* out, hipStream_t s) {
+    int th = width <= 64 ? 64 : (width <= 128 ? 128 : 256);
+    hipLaunchKernelGGL(segmean_masked_kernel, dim3(nc, V), dim3(th), 0, s, rows, V, width, viz, nv, off, mem, nc, out);
+    TH_LAUNCH_CHECK();
+    return 0;
+}

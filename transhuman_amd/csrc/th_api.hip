@@ -276,6 +276,42 @@ int th_segment_mean_rot_f64(th_ctx* c, const double* blend, const int32_t* off, 
     return th_segmean_rot_launch(blend, off, mem, nc, rot, (hipStream_t)stream);
 }
 
+int th_upsample_concat_nhwc(th_ctx* c, const float* img, const float* lat0, const float* lat1, const float* lat2,
+                            const int32_t* dims_host, int V, int H, int W, const float* color_w, const float* color_b,
+                            float* out_nhwc, th_stream stream) {
+    TH_REQUIRE(c && img && lat0 && lat1 && lat2 && dims_host && color_w && color_b && out_nhwc, "null argument");
+    return th_upsample_concat_launch(img, lat0, lat1, lat2, dims_host, V, H, W, color_w, color_b, out_nhwc,
+                                     (hipStream_t)stream);
+}
+
+size_t th_paint_group_nhwc_workspace_bytes(int V, int n_verts, int C, int out_f) {
+    size_t rows = (size_t)V * n_verts;
+    return th_align(rows * C * 4) + th_align(rows * out_f * 4) + ThPacked::bytes(out_f, C);
+}
+
+int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, int C, const float* verts, int nv,
+                        const float* cams, const float* scale, const uint8_t* viz, const th_linear* reduction,
+                        const int32_t* off, const int32_t* mem, int nc, float* tokens, void* ws, size_t ws_bytes,
+                        th_stream stream) {
+    TH_REQUIRE(c && map_nhwc && verts && cams && scale && reduction && off && mem && tokens && ws, "null argument");
+    TH_REQUIRE(reduction->in_f == C, "reduction layer must take the map's channel count");
+    const int out_f = reduction->out_f;
+    TH_REQUIRE(ws_bytes >= th_paint_group_nhwc_workspace_bytes(V, nv, C, out_f), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ThArena ar(ws, ws_bytes);
+    const size_t rows = (size_t)V * nv;
+    float* g = ar.take<float>(rows * C);              // [nv][V][C]
+    float* r = ar.take<float>(rows * out_f);          // [nv][V][out_f]
+    void* pk = ar.take<char>(ThPacked::bytes(out_f, C));
+    TH_REQUIRE(pk != nullptr, "workspace carve failed");
+    // sample the channels-last map at the projected vertices, then the 1x1 conv on those rows only
+    TH_TRY(th_pixgather_launch(map_nhwc, V, C, H, W, verts, nullptr, nullptr, nv, cams, scale, g, s));
+    ThPacked P;
+    TH_TRY(th_pack_linear(*reduction, pk, &P, s));
+    TH_TRY(th_gemm(g, C, (int)rows, P, TH_ACT_NONE, r, out_f, s));
+    return th_segmean_masked_launch(r, V, out_f, viz, nv, off, mem, nc, tokens, s);
+}
+
 size_t th_vit_workspace_bytes(int V, int N, int dim, int heads) { return th_vit_ws(V, N, dim, heads); }
 
 int th_vit_forward(th_ctx* c, const float* x, const float* pe, int V, int N, float* out, void* ws, size_t ws_bytes,

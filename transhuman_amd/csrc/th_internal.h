@@ -263,3 +263,10 @@ int th_view_embed_launch(const float* d, int R, int res, float* out, hipStream_t
 size_t th_vit_ws(int V, int N, int dim, int heads);
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
                   size_t ws_bytes, hipStream_t s);
+
+// k_encoder.hip
+int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
+                              const int* dims, int V, int H, int W, const float* wc, const float* bc, float* out,
+                              hipStream_t s);
+int th_segmean_masked_launch(const float* rows, int V, int width, const uint8_t* viz, int nv, const int32_t* off,
+                             const int32_t* mem, int nc, float* out, hipStream_t s);

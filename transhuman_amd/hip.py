@@ -72,6 +72,13 @@ SYMBOLS = {
                                       C.c_void_p]),
     "th_segment_mean_rot_f64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                           C.c_void_p]),
+    "th_upsample_concat_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]),
+    "th_paint_group_nhwc_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "th_paint_group_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ThLinear), C.c_void_p, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "th_vit_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "th_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
@@ -298,6 +305,36 @@ def paint_group(holder_map, verts_world, cams, scale_xy, vizmap, off, mem, retur
     _check(lib.th_paint_group(ctx(m.device), _p(m), V, Cc, H, W, _p(v), v.shape[0], _p(cams), _p(scale_xy), _p(viz),
                               _p(off), _p(mem), nc, _p(painted), _p(tokens), _stream()))
     return (tokens, painted) if return_painted else tokens
+
+
+def upsample_concat_nhwc(images, lat0, lat1, lat2, color_w, color_b):
+    """Encoder tail (encoder.py:133-146) -> channels-last pixel_feat_map [V,H,W,384]."""
+    lib = load_library()
+    img, l0, l1, l2 = _f32(images), _f32(lat0), _f32(lat1), _f32(lat2)
+    V, _, H, W = img.shape
+    assert l0.shape[1] == 64 and l1.shape[1] == 64 and l2.shape[1] == 128
+    dims = (C.c_int32 * 6)(l0.shape[2], l0.shape[3], l1.shape[2], l1.shape[3], l2.shape[2], l2.shape[3])
+    cw, cb = _f32(color_w).reshape(128, 3), _f32(color_b)
+    out = torch.empty((V, H, W, 384), dtype=torch.float32, device=img.device)
+    _check(lib.th_upsample_concat_nhwc(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(cw), _p(cb),
+                                       _p(out), _stream()))
+    return out
+
+
+def paint_group_nhwc(map_nhwc, verts_world, cams, scale_xy, vizmap, red_w, red_b, off, mem):
+    """Sample the channels-last map at the projected vertices, apply reduction_layer there, mask, pool."""
+    lib = load_library()
+    V, H, W, Cc = map_nhwc.shape
+    v = _f32(verts_world).reshape(-1, 3)
+    nc = off.numel() - 1
+    viz = vizmap.to(torch.uint8).contiguous() if vizmap is not None else None
+    lin, keep = _linear(red_w, red_b)
+    tokens = torch.empty((V, nc, lin.out_f), dtype=torch.float32, device=v.device)
+    ws = _ws(lib.th_paint_group_nhwc_workspace_bytes(V, v.shape[0], Cc, lin.out_f), v.device)
+    _check(lib.th_paint_group_nhwc(ctx(v.device), _p(map_nhwc), V, H, W, Cc, _p(v), v.shape[0], _p(cams), _p(scale_xy),
+                                   _p(viz), C.byref(lin), _p(off), _p(mem), nc, _p(tokens), _p(ws), ws.numel(),
+                                   _stream()))
+    return tokens
 
 
 def segment_mean(src, off, mem):

@@ -87,9 +87,9 @@ class SpatialEncoder(nn.Module):
         self.PE_color = _PEBuffers(10)                                                 # encoder.py:93 (unused)
         self.upsample_color = nn.Conv2d(3, 128, 1)                                     # encoder.py:95
 
-    def forward(self, x):
-        H, W = x.shape[2:]
-        x_ori = x
+    def trunk(self, x):
+        """ResNet18 stem -> the three latents (64ch @H/2, 64ch @H/4, 128ch @H/8), encoder.py:114-126.
+        Stock torch/MIOpen convolutions + train-mode BatchNorm."""
         m = self.model
         x = m.relu(m.bn1(m.conv1(x)))
         lat = [x]
@@ -97,6 +97,18 @@ class SpatialEncoder(nn.Module):
         lat.append(x)
         x = m.layer2(x)
         lat.append(x)
+        return lat
+
+    @staticmethod
+    def feat_scale(H, W):
+        """'scales used in projection', encoder.py:148-153 (pixel and holder maps are both HxW)."""
+        s = np.array([W, H])
+        return s / (s - 1) * 2.0
+
+    def forward(self, x):
+        H, W = x.shape[2:]
+        x_ori = x
+        lat = self.trunk(x)
         lat = [F.interpolate(l, (H, W), mode="bilinear", align_corners=True) for l in lat]
         pixel_feat_map = torch.cat(lat + [self.upsample_color(x_ori)], dim=1)
         holder_feat_map = self.reduction_layer(pixel_feat_map)

@@ -85,29 +85,50 @@ class Renderer:
         return self._dev[key]
 
     # ---- per-frame constants ---------------------------------------------------------
-    def prepare_frame(self, batch, hull_thresh=None):
-        """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame."""
+    def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True):
+        """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
+
+        fused_encoder_tail=True (default): the ResNet stem runs as stock torch ops, its tail
+        (3 upsamples + colour lift + concat, encoder.py:133-146) is ONE HIP kernel that writes the
+        384-channel map channels-last, and holder_feat_map is never materialised -- the 384->192
+        reduction_layer is applied to the 3 x 6890 sampled vertex rows instead (it commutes with the
+        bilinear sampling).  False: the reference's op order through ``net.encoder(images)``.
+        Both give the same tokens to fp32 rounding (tests/test_gpu_parity.py)."""
         cfg = get_cfg()
         assert cfg.time_steps == 1                                                  # :412
         t = 0
         images = batch["input_imgs"][t]
         images = images.reshape(-1, *images.shape[2:])                              # :397
         dev = images.device
-        holder_map, holder_scale, pixel_map, pixel_scale = self.net.encoder(images)  # :399
-        V, _, H, W = pixel_map.shape
         cams = hip.pack_cams(batch["input_R"][t].reshape(-1, 3, 3), batch["input_T"][t].reshape(-1, 3, 1),
                              batch["input_K"][t].reshape(-1, 3, 3))
         image_shape = batch["input_imgs"][t].shape[-2:]
         off, mem = self._csr(dev)
         viz = batch["input_vizmaps"][t][0] if cfg.rasterize else None               # :103-119
-        grouped = hip.paint_group(holder_map, batch["input_smpl_vertice"][t][0], cams,
-                                  hip.feat_scale(holder_scale, image_shape, dev), viz, off, mem)
+        enc = self.net.encoder
+        if fused_encoder_tail and hasattr(enc, "trunk"):
+            H, W = images.shape[2:]
+            V = images.shape[0]
+            lat = enc.trunk(images)
+            map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2], enc.upsample_color.weight,
+                                                enc.upsample_color.bias)
+            scale = hip.feat_scale(enc.feat_scale(H, W), image_shape, dev)
+            grouped = hip.paint_group_nhwc(map_nhwc, batch["input_smpl_vertice"][t][0], cams, scale, viz,
+                                           enc.reduction_layer.weight, enc.reduction_layer.bias, off, mem)
+            pix_scale = scale
+        else:
+            holder_map, holder_scale, pixel_map, pixel_scale = enc(images)          # :399
+            V, _, H, W = pixel_map.shape
+            grouped = hip.paint_group(holder_map, batch["input_smpl_vertice"][t][0], cams,
+                                      hip.feat_scale(holder_scale, image_shape, dev), viz, off, mem)
+            map_nhwc = hip.nchw_to_nhwc(pixel_map)
+            pix_scale = hip.feat_scale(pixel_scale, image_shape, dev)
+        self.last_grouped = grouped
         tokens = self.net.ViT(grouped, self._pe_norm(V, dev), mask=None)            # :538
         centres = hip.segment_mean(batch["tar_smpl_vertice_smplcoord"][0], off, mem)   # :543
         rot = hip.segment_mean_rot(batch["blend_mtx"][0], off, mem)                 # :544 + cross_transformer.py:185
-        frame = hip.Frame(batch["tar_smpl_vertice"][0], batch["Rh"][0], batch["Th"][0], cams,
-                          hip.feat_scale(pixel_scale, image_shape, dev), hip.nchw_to_nhwc(pixel_map), tokens,
-                          centres, rot,
+        frame = hip.Frame(batch["tar_smpl_vertice"][0], batch["Rh"][0], batch["Th"][0], cams, pix_scale, map_nhwc,
+                          tokens, centres, rot,
                           hull_thresh=cfg_hull() if hull_thresh is None else hull_thresh,
                           small_frame_rays=2400)
         return frame
