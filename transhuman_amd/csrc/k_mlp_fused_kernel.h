@@ -98,17 +98,21 @@ __device__ __forceinline__ void stage_commit(const StageRegs<V, KC>& r, char* __
 }
 
 // ---- GEMM phase ---------------------------------------------------------------------------------------
-// one k-block (16 deep): acc[c][r] += W(c) * X(r)^T as three fp16 products (lo*hi, hi*lo, hi*hi),
-// term-major so consecutive MFMAs hit different accumulators
-template <int RT, int CT, int STR, int ROWSTEP>
-__device__ __forceinline__ void gemm_kblock(const char* __restrict__ ahi, const char* __restrict__ alo, int aoff, int kb,
-                                            const uint4 (&w)[CT][2], f32x16 (&acc)[CT][RT]) {
-    h8 xh[RT], xl[RT];
+template <int RT, int STR, int ROWSTEP>
+__device__ __forceinline__ void load_xfrag(const char* __restrict__ ahi, const char* __restrict__ alo, int aoff, int kb,
+                                           h8 (&xh)[RT], h8 (&xl)[RT]) {
 #pragma unroll
     for (int r = 0; r < RT; ++r) {
         xh[r] = *reinterpret_cast<const h8*>(ahi + r * ROWSTEP + aoff + kb * 32);
         xl[r] = *reinterpret_cast<const h8*>(alo + r * ROWSTEP + aoff + kb * 32);
     }
+}
+
+// one k-block (16 deep): acc[c][r] += W(c) * X(r)^T as three fp16 products (lo*hi, hi*lo, hi*hi),
+// term-major so consecutive MFMAs hit different accumulators
+template <int RT, int CT>
+__device__ __forceinline__ void mfma_kblock(const uint4 (&w)[CT][2], const h8 (&xh)[RT], const h8 (&xl)[RT],
+                                            f32x16 (&acc)[CT][RT]) {
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -149,22 +153,24 @@ __device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb,
 #define FM_LATE(...) __VA_ARGS__
 #endif
 
-// acc[ct][rt] += W_tile(ct) * A_rows(rt)^T over KB k-blocks of 16.  Weight fragments stream from the
-// (L2-resident) packed image through a ring of three register sets: the loads of block k+2 are issued
-// before the MFMA burst of block k (sched_barrier pins them there), i.e. two bursts (>= 1100 cycles) of
-// latency tolerance, and no register copies (loop unrolled by three).
-template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = 3>
+// acc[ct][rt] += W_tile(ct) * A_rows(rt)^T over KB k-blocks of 16.
+//  * weight fragments stream from the (L2-resident) packed image through a ring of D register sets: block
+//    k+D-1 is requested before the MFMA burst of block k (sched_barrier pins the loads there) -- D-1 bursts
+//    of latency tolerance, no register copies (loop unrolled by D, D even);
+//  * activation fragments (LDS, ds_read_b128) ping-pong between two register sets: block k+1 is read
+//    while block k multiplies, so no burst starts with an exposed LDS round trip.
+template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = 4>
 __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const char* __restrict__ alo,
                                            const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
+    static_assert((D & 1) == 0, "ring depth must be even (activation ping-pong parity)");
     const uint4* wl = wp + lane;     // this wave's stream: per kb: CT x {hi, lo} x 64 lanes x 16 B
     const int aoff = (lane & 31) * STR + (lane >> 5) * 16;
-    // ring of D register sets; block k+D-1 is requested before the MFMA burst of block k.
-    // D = 3 for the wide phases (burst >= 576 cycles); the short-burst phases (one row tile or one
-    // column tile per wave) use a deeper ring to cover the same latency.
     uint4 w[D][CT][2];
+    h8 xh[2][RT], xl[2][RT];
 #pragma unroll
     for (int j = 0; j < D - 1; ++j)
         if (j < KB) load_wfrag<CT>(wl, j, w[j]);
+    load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, 0, xh[0], xl[0]);
     FM_SB();
     int kb = 0;
 #pragma unroll 1
@@ -172,16 +178,21 @@ __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const c
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             if (kb + j + D - 1 < KB) load_wfrag<CT>(wl, kb + j + D - 1, w[(j + D - 1) % D]);
+            if (kb + j + 1 < KB) load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j + 1, xh[(j + 1) & 1], xl[(j + 1) & 1]);
             FM_SB();
-            gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, w[j], acc);
+            mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
             FM_SB();
         }
     }
-    // tail (KB % D blocks): their fragments were requested by the guarded loads above
+    // tail (KB % D blocks): their weight fragments were requested by the guarded loads above
 #pragma unroll
     for (int j = 0; j < D - 1; ++j)
-        if (kb + j < KB) gemm_kblock<RT, CT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, w[j], acc);
-    FM_SB();
+        if (kb + j < KB) {
+            if (kb + j + 1 < KB) load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j + 1, xh[(j + 1) & 1], xl[(j + 1) & 1]);
+            FM_SB();
+            mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
+            FM_SB();
+        }
 }
 
 template <int CT, int RT>
@@ -488,13 +499,13 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
         FM_SYNC();
         gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 0), 12, lane, acc2);
-        gemm_phase<V, 1, STR192, 32 * STR192, 5>(abuf, a192_lo, wslice(P.rr1, wave, 1, 0), 12, lane, r1);
+        gemm_phase<V, 1, STR192, 32 * STR192, 6>(abuf, a192_lo, wslice(P.rr1, wave, 1, 0), 12, lane, r1);
         FM_SYNC();
         FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
         stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
         FM_SYNC();
         gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 12), 12, lane, acc2);
-        gemm_phase<V, 1, STR192, 32 * STR192, 5>(abuf, a192_lo, wslice(P.rr1, wave, 1, 12), 12, lane, r1);
+        gemm_phase<V, 1, STR192, 32 * STR192, 6>(abuf, a192_lo, wslice(P.rr1, wave, 1, 12), 12, lane, r1);
         FM_SYNC();
         // feat (+ both biases) -> ABUF [ROWS][256]; the 27 view-direction inputs of view_fc -> MBUF [32][32]
         char* vd_hi = mbuf + MBUF_VD_OFF;
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         // view_fc over [feat(256) | viewdir(27 -> 32)]: 16 k-blocks from ABUF + 2 from the shared viewdir rows
         f32x16 vf[1][V];
         zero_acc<1, V>(vf);
-        gemm_phase<V, 1, STR256, 32 * STR256, 5>(abuf, a256_lo, wslice(P.vfc, wave, 1, 0), 16, lane, vf);
+        gemm_phase<V, 1, STR256, 32 * STR256, 6>(abuf, a256_lo, wslice(P.vfc, wave, 1, 0), 16, lane, vf);
         gemm_phase<V, 1, STRVD, 0>(vd_hi, vd_lo, wslice(P.vfc, wave, 1, 16), 2, lane, vf);
         finish_tile<V>(vf[0], P.vfc.bias, wave * 32, P.vfc.inv_scale, true, lane);
         finish_tile<V>(r1[0], P.rr1.bias, wave * 32, P.rr1.inv_scale, false, lane);
