@@ -177,11 +177,32 @@ __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const c
     for (; kb + D <= KB; kb += D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
+#ifdef FM_NO_INTERLEAVE
             if (kb + j + D - 1 < KB) load_wfrag<CT>(wl, kb + j + D - 1, w[(j + D - 1) % D]);
             if (kb + j + 1 < KB) load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j + 1, xh[(j + 1) & 1], xl[(j + 1) & 1]);
             FM_SB();
             mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
             FM_SB();
+#else
+            // branch-free (indices clamped: the last blocks re-request a fragment nobody consumes) so that
+            // the prefetch and the MFMA burst form ONE scheduling region, then ask for one memory
+            // instruction after each of the first MFMAs: the 2*CT global loads + 2*RT ds_reads issue in the
+            // shadow of running MFMAs instead of in front of the burst.
+            const int kw = (kb + j + D - 1 < KB) ? kb + j + D - 1 : KB - 1;
+            const int kx = (kb + j + 1 < KB) ? kb + j + 1 : KB - 1;
+            load_wfrag<CT>(wl, kw, w[(j + D - 1) % D]);
+            load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kx, xh[(j + 1) & 1], xl[(j + 1) & 1]);
+            mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
+            constexpr int NMEM = 2 * CT + 2 * RT, NMF = 3 * CT * RT;
+            constexpr int NPAIR = NMEM < NMF ? NMEM : NMF;
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);     // one VMEM read or DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NPAIR, 0);
+            FM_SB();
+#endif
         }
     }
     // tail (KB % D blocks): their weight fragments were requested by the guarded loads above
