@@ -8,18 +8,19 @@
 // single-rounding fma argument (vision_transformer.py:131-132), and for every
 // view sum_k w_k * [token_v[k] (192) | PE_k (63)] (:197-200).
 //
-// Layout: one workgroup = 128 samples.  Phase 1 (thread per sample): brute-force
-// top-7 over the N_c centres staged in LDS (N_c*12 B <= 72 KB), weights and the
-// 7 rotated offsets go to LDS.  Phase 2 (wave per sample): lanes span channels,
-// token rows are gathered as coalesced 768 B reads from the L2-resident table,
-// lanes 0..62 evaluate one PE channel each (7 accurate sinf per lane).
-// Output rows [sample][view][256] (255 + zero pad) feed the fc_0 GEMM.
+// Layout: one workgroup = 256 threads = 128 samples.
+//  Phase 1 (two lanes per sample): each lane keeps a register top-7 over the even / odd token centres
+//   (staged in LDS, N_c*12 B <= 72 KB); the pair's lists are merged by (distance, index) -- same result as
+//   one ordered scan; softmax weights and the 7 rotated offsets go to LDS.
+//  Phase 2 (wave per sample, 32 samples per wave): lanes 0..47 fetch a token row as one float4 each
+//   (768 B coalesced, L2-resident table), lanes 0..62 evaluate one PE channel each (7 accurate sinf).
+// Output rows [sample][view][256] (255 + zero pad) feed fc_0.
 // Bound: L2 gather of 7*V*768 B per sample; HBM write 3 KB per sample.
 #include "th_internal.h"
 
 #define DP_K 7
-#define DP_BLOCK 128
-#define DP_FREQ 10
+#define DP_SAMPLES 128
+#define DP_THREADS 256
 
 struct DpNbr {
     float w[DP_K];
@@ -27,27 +28,41 @@ struct DpNbr {
     float def[DP_K][3];
 };
 
-__global__ __launch_bounds__(DP_BLOCK) void dparf_kernel(const float* __restrict__ pts_smpl, ThPointSrc ps,
-                                                         const float* __restrict__ Rh, const float* __restrict__ Th,
-                                                         const int32_t* __restrict__ sel, int P,
-                                                         const float* __restrict__ centres,
-                                                         const float* __restrict__ rot,
-                                                         const float* __restrict__ tokens, int V, int nc,
-                                                         float alpha, float* __restrict__ out) {
+// insert (cd, ci) into the ascending list; on equal distance the smaller index stays first
+__device__ __forceinline__ void dp_insert(float (&bd)[DP_K], int (&bi)[DP_K], float cd, int ci) {
+#pragma unroll
+    for (int k = 0; k < DP_K; ++k) {
+        bool sw = (cd < bd[k]) || (cd == bd[k] && ci < bi[k]);
+        float td = sw ? bd[k] : cd;
+        int ti = sw ? bi[k] : ci;
+        bd[k] = sw ? cd : bd[k];
+        bi[k] = sw ? ci : bi[k];
+        cd = td; ci = ti;
+    }
+}
+
+__global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restrict__ pts_smpl, ThPointSrc ps,
+                                                           const float* __restrict__ Rh, const float* __restrict__ Th,
+                                                           const int32_t* __restrict__ sel, int P,
+                                                           const float* __restrict__ centres,
+                                                           const float* __restrict__ rot,
+                                                           const float* __restrict__ tokens, int V, int nc,
+                                                           float alpha, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* cen = lds;                                   // [nc*3]
     DpNbr* nb = reinterpret_cast<DpNbr*>(lds + ((nc * 3 + 3) & ~3));
-    for (int i = threadIdx.x; i < nc * 3; i += DP_BLOCK) cen[i] = centres[i];
+    for (int i = threadIdx.x; i < nc * 3; i += DP_THREADS) cen[i] = centres[i];
     __syncthreads();
 
-    const int p = blockIdx.x * DP_BLOCK + threadIdx.x;
-    if (p < P) {
+    // ---- phase 1: lanes (2s, 2s+1) share sample s ----
+    const int ls = threadIdx.x >> 1, half = threadIdx.x & 1;
+    const int p = blockIdx.x * DP_SAMPLES + ls;
+    if (p < P) {                                        // (both lanes of a pair take the same branch)
         float x, y, z;
+        long long q = sel ? sel[p] : p;
         if (pts_smpl) {
-            long long q = sel ? sel[p] : p;
             x = pts_smpl[3 * q]; y = pts_smpl[3 * q + 1]; z = pts_smpl[3 * q + 2];
         } else {
-            long long q = sel ? sel[p] : p;
             float wx, wy, wz;
             th_get_point(ps, q, wx, wy, wz);
             // world2smpl, if_clight_renderer.py:289-295: (p - Th) @ Rh
@@ -59,47 +74,44 @@ __global__ __launch_bounds__(DP_BLOCK) void dparf_kernel(const float* __restrict
         float bd[DP_K];
         int bi[DP_K];
 #pragma unroll
-        for (int k = 0; k < DP_K; ++k) { bd[k] = 3.0e38f; bi[k] = 0; }
-        for (int c = 0; c < nc; ++c) {
+        for (int k = 0; k < DP_K; ++k) { bd[k] = 3.0e38f; bi[k] = 0x7fffffff; }
+        for (int c = half; c < nc; c += 2) {
             float dx = x - cen[3 * c], dy = y - cen[3 * c + 1], dz = z - cen[3 * c + 2];
             float d2 = dx * dx + dy * dy;
             d2 = d2 + dz * dz;
-            if (d2 < bd[DP_K - 1]) {
-                // stable insertion: goes after every element <= d2
-                float cd = d2;
-                int ci = c;
+            if (d2 < bd[DP_K - 1]) dp_insert(bd, bi, d2, c);   // ascending c: a tie never displaces an earlier index
+        }
+        // merge the partner's list (7 candidates) -> global top-7 ordered by (d2, index)
+        float od[DP_K];
+        int oi[DP_K];
 #pragma unroll
-                for (int k = 0; k < DP_K; ++k) {
-                    bool sw = cd < bd[k];
-                    float td = sw ? bd[k] : cd;
-                    int ti = sw ? bi[k] : ci;
-                    bd[k] = sw ? cd : bd[k];
-                    bi[k] = sw ? ci : bi[k];
-                    cd = td; ci = ti;
-                }
+        for (int k = 0; k < DP_K; ++k) { od[k] = __shfl_xor(bd[k], 1); oi[k] = __shfl_xor(bi[k], 1); }
+#pragma unroll
+        for (int k = 0; k < DP_K; ++k)
+            if (od[k] < bd[DP_K - 1] || (od[k] == bd[DP_K - 1] && oi[k] < bi[DP_K - 1])) dp_insert(bd, bi, od[k], oi[k]);
+        if (half == 0) {
+            // softmax(-d/alpha) over the K neighbours
+            float xs[DP_K], mx = -3.0e38f;
+#pragma unroll
+            for (int k = 0; k < DP_K; ++k) {
+                xs[k] = (-__fsqrt_rn(bd[k])) / alpha;              // cross_transformer.py:153-154
+                mx = fmaxf(mx, xs[k]);
             }
-        }
-        // softmax(-d/alpha) over the K neighbours
-        float xs[DP_K], mx = -3.0e38f;
+            float se = 0.f;
 #pragma unroll
-        for (int k = 0; k < DP_K; ++k) {
-            xs[k] = (-__fsqrt_rn(bd[k])) / alpha;              // cross_transformer.py:153-154
-            mx = fmaxf(mx, xs[k]);
-        }
-        float se = 0.f;
+            for (int k = 0; k < DP_K; ++k) { xs[k] = expf(xs[k] - mx); se = se + xs[k]; }
+            DpNbr& o = nb[ls];
 #pragma unroll
-        for (int k = 0; k < DP_K; ++k) { xs[k] = expf(xs[k] - mx); se = se + xs[k]; }
-        DpNbr& o = nb[threadIdx.x];
-#pragma unroll
-        for (int k = 0; k < DP_K; ++k) {
-            int c = bi[k];
-            o.w[k] = xs[k] / se;
-            o.idx[k] = c;
-            float rx = x - cen[3 * c], ry = y - cen[3 * c + 1], rz = z - cen[3 * c + 2];
-            const float* Rm = rot + 9 * c;
-            o.def[k][0] = fmaf(rz, Rm[6], fmaf(ry, Rm[3], rx * Rm[0]));
-            o.def[k][1] = fmaf(rz, Rm[7], fmaf(ry, Rm[4], rx * Rm[1]));
-            o.def[k][2] = fmaf(rz, Rm[8], fmaf(ry, Rm[5], rx * Rm[2]));
+            for (int k = 0; k < DP_K; ++k) {
+                int c = bi[k];
+                o.w[k] = xs[k] / se;
+                o.idx[k] = c;
+                float rx = x - cen[3 * c], ry = y - cen[3 * c + 1], rz = z - cen[3 * c + 2];
+                const float* Rm = rot + 9 * c;
+                o.def[k][0] = fmaf(rz, Rm[6], fmaf(ry, Rm[3], rx * Rm[0]));
+                o.def[k][1] = fmaf(rz, Rm[7], fmaf(ry, Rm[4], rx * Rm[1]));
+                o.def[k][2] = fmaf(rz, Rm[8], fmaf(ry, Rm[5], rx * Rm[2]));
+            }
         }
     }
     __syncthreads();
@@ -108,28 +120,28 @@ __global__ __launch_bounds__(DP_BLOCK) void dparf_kernel(const float* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float PI_F = 3.14159274101257324219f;          // fp32(pi)
     const float HALF_PI_F = 1.57079637050628662109f;     // fp32(pi/2)
-    for (int lp = wave; lp < DP_BLOCK; lp += DP_BLOCK / 64) {
-        int gp = blockIdx.x * DP_BLOCK + lp;
+    // PE channel `lane` (0..62): 0..2 raw xyz; then per octave f: sin xyz, cos xyz
+    int axis = 0, oct = 0;
+    float phase = 0.f;
+    if (lane < 3) axis = lane;
+    else if (lane < 63) {
+        int qq = lane - 3;
+        oct = qq / 6;
+        int r = qq % 6;
+        axis = r % 3;
+        phase = (r >= 3) ? HALF_PI_F : 0.f;
+    }
+    const float freq = PI_F * (float)(1 << oct);
+    for (int lp = wave; lp < DP_SAMPLES; lp += DP_THREADS / 64) {
+        int gp = blockIdx.x * DP_SAMPLES + lp;
         if (gp >= P) break;
         const DpNbr& n = nb[lp];
         float w[DP_K];
         int id[DP_K];
 #pragma unroll
         for (int k = 0; k < DP_K; ++k) { w[k] = n.w[k]; id[k] = n.idx[k]; }
-        // PE channel `lane` (0..62): 0..2 raw xyz; then per octave f: sin xyz, cos xyz
         float pe = 0.f;
         if (lane < 63) {
-            int axis, oct = 0;
-            float phase = 0.f;
-            if (lane < 3) axis = lane;
-            else {
-                int q = lane - 3;
-                oct = q / 6;
-                int r = q % 6;
-                axis = r % 3;
-                phase = (r >= 3) ? HALF_PI_F : 0.f;
-            }
-            float freq = PI_F * (float)(1 << oct);
 #pragma unroll
             for (int k = 0; k < DP_K; ++k) {
                 float xv = n.def[k][axis];
@@ -141,13 +153,17 @@ __global__ __launch_bounds__(DP_BLOCK) void dparf_kernel(const float* __restrict
         for (int v = 0; v < V; ++v) {
             const float* tv = tokens + (long long)v * nc * 192;
             float* o = out + ((long long)gp * V + v) * 256;
+            if (lane < 48) {
+                float4 r[DP_K];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                int c = lane + 64 * j;
-                float acc = w[0] * tv[(long long)id[0] * 192 + c];
+                for (int k = 0; k < DP_K; ++k) r[k] = *reinterpret_cast<const float4*>(tv + (long long)id[k] * 192 + 4 * lane);
+                float4 acc = make_float4(w[0] * r[0].x, w[0] * r[0].y, w[0] * r[0].z, w[0] * r[0].w);
 #pragma unroll
-                for (int k = 1; k < DP_K; ++k) acc = acc + w[k] * tv[(long long)id[k] * 192 + c];
-                o[c] = acc;
+                for (int k = 1; k < DP_K; ++k) {
+                    acc.x = acc.x + w[k] * r[k].x; acc.y = acc.y + w[k] * r[k].y;
+                    acc.z = acc.z + w[k] * r[k].z; acc.w = acc.w + w[k] * r[k].w;
+                }
+                *reinterpret_cast<float4*>(o + 4 * lane) = acc;
             }
             o[192 + lane] = (lane < 63) ? pe : 0.f;
         }
@@ -161,14 +177,14 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
     TH_REQUIRE(nc >= DP_K, "need at least 7 token centres");
     ThPointSrc src;
     if (ps) src = *ps; else { src = ThPointSrc{}; }
-    size_t lds = ((size_t)((nc * 3 + 3) & ~3)) * sizeof(float) + DP_BLOCK * sizeof(DpNbr);
+    size_t lds = ((size_t)((nc * 3 + 3) & ~3)) * sizeof(float) + DP_SAMPLES * sizeof(DpNbr);
     TH_REQUIRE(lds <= 160 * 1024, "too many token centres for LDS staging");
     static bool attr_set = false;
     if (!attr_set) {
         TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(dparf_kernel, dim3(th_cdiv(P, DP_BLOCK)), dim3(DP_BLOCK), lds, s, pts_smpl, src, Rh, Th, sel,
+    hipLaunchKernelGGL(dparf_kernel, dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh, Th, sel,
                        P, centres, rot, tokens, V, nc, alpha, out);
     TH_LAUNCH_CHECK();
     return 0;
