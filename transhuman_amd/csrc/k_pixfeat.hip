@@ -7,7 +7,7 @@
 // corner) and masks afterwards (cross_transformer.py:235); here the map is
 // channels-last (th_nchw_to_nhwc, once per frame) so each corner is one
 // contiguous 1.5 KB read, and only hull-valid samples are gathered.
-// One wave per (sample, view) row; lanes span channels (float2 x 3 per lane).
+// One wave per (sample, view) row; lanes span channels (float4 per lane).
 // Bound: L2/HBM gather, 4 * 1536 B per (sample, view) in, 1536 B out.
 #include "th_internal.h"
 
@@ -17,7 +17,12 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
                                                         const float* __restrict__ cams,
                                                         const float* __restrict__ scale, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
-    long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);     // (sample, view)
+    // XCD-aware remap (speed only): workgroup b runs on XCD b % 8, each XCD has its own L2.  Neighbouring
+    // samples of a ray share bilinear corners, so give every XCD a CONTIGUOUS range of rows: logical block
+    // = (b % 8) * ceil(nb / 8) + b / 8 (bijective incl. ragged tails via the bounds check below).
+    const long long nb8 = ((long long)gridDim.x + 7) / 8;
+    const long long lb = (long long)(blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
+    long long row = lb * 4 + (threadIdx.x >> 6);                          // (sample, view)
     if (row >= (long long)P * V) return;
     int p = (int)(row / V), v = (int)(row % V);
     long long q = sel ? sel[p] : p;
@@ -28,17 +33,20 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
     th_project(cams + 21 * v, x, y, z, uu, vv);
     Bilin b = th_bilinear_setup(uu, vv, scale[0], scale[1], H, W);
     const float* m = map + (long long)v * H * W * C;
-    const float2* p00 = reinterpret_cast<const float2*>(m + (long long)b.i00 * C);
-    const float2* p01 = reinterpret_cast<const float2*>(m + (long long)b.i01 * C);
-    const float2* p10 = reinterpret_cast<const float2*>(m + (long long)b.i10 * C);
-    const float2* p11 = reinterpret_cast<const float2*>(m + (long long)b.i11 * C);
-    float2* o = reinterpret_cast<float2*>(out + row * C);
-    for (int c2 = lane; c2 < C / 2; c2 += 64) {
-        float2 a = p00[c2], bb = p01[c2], cc = p10[c2], d = p11[c2];
-        float2 r;
+    const float4* p00 = reinterpret_cast<const float4*>(m + (long long)b.i00 * C);
+    const float4* p01 = reinterpret_cast<const float4*>(m + (long long)b.i01 * C);
+    const float4* p10 = reinterpret_cast<const float4*>(m + (long long)b.i10 * C);
+    const float4* p11 = reinterpret_cast<const float4*>(m + (long long)b.i11 * C);
+    float4* o = reinterpret_cast<float4*>(out + row * C);
+    // 16 B per lane: C = 384 -> 96 float4 per corner row = 1.5 wave-loads (the second one half masked)
+    for (int c4 = lane; c4 < C / 4; c4 += 64) {
+        float4 a = p00[c4], bb = p01[c4], cc = p10[c4], d = p11[c4];
+        float4 r;
         r.x = a.x * b.w00; r.x = r.x + bb.x * b.w01; r.x = r.x + cc.x * b.w10; r.x = r.x + d.x * b.w11;
         r.y = a.y * b.w00; r.y = r.y + bb.y * b.w01; r.y = r.y + cc.y * b.w10; r.y = r.y + d.y * b.w11;
-        o[c2] = r;
+        r.z = a.z * b.w00; r.z = r.z + bb.z * b.w01; r.z = r.z + cc.z * b.w10; r.z = r.z + d.z * b.w11;
+        r.w = a.w * b.w00; r.w = r.w + bb.w * b.w01; r.w = r.w + cc.w * b.w10; r.w = r.w + d.w * b.w11;
+        o[c4] = r;
     }
 }
 
@@ -46,11 +54,12 @@ int th_pixgather_launch(const float* map, int V, int C, int H, int W, const floa
                         const int32_t* sel, int P, const float* cams, const float* scale, float* out,
                         hipStream_t s) {
     if (P <= 0) return 0;
-    TH_REQUIRE((C & 1) == 0, "channel count must be even");
+    TH_REQUIRE((C & 3) == 0, "channel count must be a multiple of 4");
     ThPointSrc src = ps ? *ps : ThPointSrc{};
     long long rows = (long long)P * V;
-    hipLaunchKernelGGL(pixgather_kernel, dim3(th_cdiv(rows, 4)), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel,
-                       P, cams, scale, out);
+    const int nblk = 8 * th_cdiv(th_cdiv(rows, 4), 8);      // multiple of 8 so the XCD remap is onto
+    hipLaunchKernelGGL(pixgather_kernel, dim3(nblk), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel, P, cams,
+                       scale, out);
     TH_LAUNCH_CHECK();
     return 0;
 }
