@@ -63,7 +63,7 @@ __device__ __forceinline__ float th_gelu_erf(float x) {
     return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <int NT>
+template <int NT, int MT>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, int lda, int M, int Kreal,
                                                             const float* __restrict__ Wp,
                                                             const float* __restrict__ bias, int N, int NB, int KB,
@@ -72,13 +72,14 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int m0 = blockIdx.x * GEMM_BM;
+    constexpr int BM = 16 * MT;                          // rows per workgroup (MT = 4: 64, MT = 1: 16)
+    const int m0 = blockIdx.x * BM;
     const int nb0 = (blockIdx.y * 4 + wave) * NT;       // first 16-col tile of this wave
     const bool wave_active = nb0 < NB;
 
-    f32x4 acc[4][NT];
+    f32x4 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
         const int k0 = ch * GEMM_KC;
         // ---- stage A[m0:m0+64, k0:k0+128] -> LDS (zero fill outside M x Kreal) ----
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 2 * MT; ++i) {
             int idx = tid + 256 * i;
             int row = idx >> 5;
             int c4 = idx & 31;
@@ -128,15 +129,15 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
                                    ? *reinterpret_cast<const f32x4*>(Wp + ((long long)nb * KB + kb + 1) * 256 + lane * 4)
                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                f32x4 a[4];
+                f32x4 a[MT];
                 const int kl = (kb - kb_lo) * 16 + 4 * (lane >> 4);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MT; ++i)
                     a[i] = *reinterpret_cast<const f32x4*>(&As[(i * 16 + (lane & 15)) * GEMM_LDS_STRIDE + kl]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int j = 0; j < NT; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], bcur[j][e], acc[i][j], 0, 0, 0);
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
         if (col >= N) continue;
         float bv = bias[col];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int row = m0 + i * 16 + 4 * (lane >> 4) + r;
@@ -190,17 +191,26 @@ int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float*
     TH_REQUIRE((lda & 3) == 0 && (((uintptr_t)A) & 15) == 0, "A must be 16-byte aligned with lda % 4 == 0");
     TH_REQUIRE(W.w != nullptr, "weights not packed");
     int nt = pick_nt(W.NB);
-    dim3 grid(th_cdiv(M, GEMM_BM), th_cdiv(W.NB, 4 * nt));
-    size_t lds = GEMM_BM * GEMM_LDS_STRIDE * sizeof(float);
-#define LAUNCH(NT_)                                                                                             \
-    hipLaunchKernelGGL(gemm_f32_mfma_kernel<NT_>, grid, dim3(256), lds, s, A, lda, M, W.K, W.w, W.b, W.N, W.NB, \
+    // few rows (the ViT: V*N_c = 900..4500 tokens): 16-row workgroups so the launch still covers the chip
+    const bool small = M <= 8192;
+    const int bm = small ? 16 : GEMM_BM;
+    dim3 grid(th_cdiv(M, bm), th_cdiv(W.NB, 4 * nt));
+    size_t lds = (size_t)bm * GEMM_LDS_STRIDE * sizeof(float);
+#define LAUNCH(NT_, MT_)                                                                                            \
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<NT_, MT_>), grid, dim3(256), lds, s, A, lda, M, W.K, W.w, W.b, W.N, W.NB, \
                        W.KB, C, ldc, flags)
+#define LAUNCH_NT(NT_)                 \
+    do {                               \
+        if (small) LAUNCH(NT_, 1);     \
+        else LAUNCH(NT_, 4);           \
+    } while (0)
     switch (nt) {
-        case 4: LAUNCH(4); break;
-        case 3: LAUNCH(3); break;
-        case 2: LAUNCH(2); break;
-        default: LAUNCH(1); break;
+        case 4: LAUNCH_NT(4); break;
+        case 3: LAUNCH_NT(3); break;
+        case 2: LAUNCH_NT(2); break;
+        default: LAUNCH_NT(1); break;
     }
+#undef LAUNCH_NT
 #undef LAUNCH
     TH_LAUNCH_CHECK();
     return 0;
