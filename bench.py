@@ -153,7 +153,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist_on = world > 1
+    # TH_FORCE_DIST=1 runs the RCCL code path (process group, all_reduce, all_gather) even with one rank
+    dist_on = world > 1 or os.environ.get("TH_FORCE_DIST") == "1"
+    if dist_on and "RANK" not in os.environ:
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -180,16 +183,23 @@ def main():
     for k in ("ray_o", "ray_d", "near", "far"):
         shard[k] = batch[k][:, my_idx].contiguous()
 
+    hit_buf = torch.zeros(1, dtype=torch.int64, device=dev)
+
     def step():
         frame = renderer.prepare_frame(batch)
         if dist_on:
-            # the reference's R'<=2400 switch (:551) looks at the whole frame: decide it globally
-            pts = hip.Points(shard["ray_o"][0], shard["ray_d"][0], shard["near"][0], shard["far"][0], args.samples)
-            _, hit = hip.hull_mask(pts, batch["tar_smpl_vertice"][0])
-            n_hit = hit.sum().to(torch.int64)
-            dist.all_reduce(n_hit)
-            frame.c.small_frame_rays = (1 << 30) if int(n_hit) <= 2400 else -1
+            # The reference's R' <= 2400 switch (if_clight_renderer.py:551) looks at the WHOLE frame.  Render the
+            # shard in the (overwhelmingly common) masked mode, sum the per-rank hit-ray counts that
+            # th_render_rays reports anyway (8-byte all-reduce), and only if the frame total is <= 2400 render
+            # again in the reference's un-masked mode.
+            frame.c.small_frame_rays = -1
         out = renderer.render_fast(shard, frame=frame)
+        if dist_on:
+            hit_buf.fill_(int(renderer.last_stats["hit_rays"]))
+            dist.all_reduce(hit_buf)
+            if int(hit_buf) <= 2400:
+                frame.c.small_frame_rays = 1 << 30
+                out = renderer.render_fast(shard, frame=frame)
         local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
         img = gather_image(local, my_idx, R, world) if dist_on else local
         return img, dict(renderer.last_stats)

@@ -159,7 +159,7 @@ __device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb,
 //    of latency tolerance, no register copies (loop unrolled by D, D even);
 //  * activation fragments (LDS, ds_read_b128) ping-pong between two register sets: block k+1 is read
 //    while block k multiplies, so no burst starts with an exposed LDS round trip.
-template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = 4>
+template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = 4, bool XPP = true>
 __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const char* __restrict__ alo,
                                            const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
     static_assert((D & 1) == 0, "ring depth must be even (activation ping-pong parity)");
@@ -191,8 +191,13 @@ __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const c
             const int kw = (kb + j + D - 1 < KB) ? kb + j + D - 1 : KB - 1;
             const int kx = (kb + j + 1 < KB) ? kb + j + 1 : KB - 1;
             load_wfrag<CT>(wl, kw, w[(j + D - 1) % D]);
-            load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kx, xh[(j + 1) & 1], xl[(j + 1) & 1]);
-            mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
+            if (XPP) {
+                load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kx, xh[(j + 1) & 1], xl[(j + 1) & 1]);
+                mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
+            } else {   // register-tight phases: one activation set, read right before its burst
+                load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, xh[0], xl[0]);
+                mfma_kblock<RT, CT>(w[j], xh[0], xl[0], acc);
+            }
             constexpr int NMEM = 2 * CT + 2 * RT, NMF = 3 * CT * RT;
             constexpr int NPAIR = NMEM < NMF ? NMEM : NMF;
 #pragma unroll
@@ -209,9 +214,14 @@ __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const c
 #pragma unroll
     for (int j = 0; j < D - 1; ++j)
         if (kb + j < KB) {
-            if (kb + j + 1 < KB) load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j + 1, xh[(j + 1) & 1], xl[(j + 1) & 1]);
-            FM_SB();
-            mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
+            if (XPP) {
+                if (kb + j + 1 < KB) load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j + 1, xh[(j + 1) & 1], xl[(j + 1) & 1]);
+                FM_SB();
+                mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
+            } else {
+                load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, xh[0], xl[0]);
+                mfma_kblock<RT, CT>(w[j], xh[0], xl[0], acc);
+            }
             FM_SB();
         }
 }
@@ -359,17 +369,33 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     FM_SYNC();
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
+    // FM_ONE_F_PASS: the two f-consuming layers of the RGB branch (rgb_res_0, rgb_res_1) are evaluated in the
+    // same pass over f and their accumulators (144 registers) stay resident until the RGB branch: f is read
+    // from HBM once instead of twice and the RGB branch loses two staging + GEMM phases.
     zero_acc<2, V>(acc2);
+#ifdef FM_ONE_F_PASS
+    f32x16 r0[2][V], r1[1][V];
+    zero_acc<2, V>(r0);
+    zero_acc<1, V>(r1);
+#endif
     FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));
     stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
     FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
     FM_SYNC();
     gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.ar0, wave, 2, 0), 12, lane, acc2);
+#ifdef FM_ONE_F_PASS
+    gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 0), 12, lane, r0);
+    gemm_phase<V, 1, STR192, 32 * STR192, 6>(abuf, a192_lo, wslice(P.rr1, wave, 1, 0), 12, lane, r1);
+#endif
     FM_SYNC();
     FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
     stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
     FM_SYNC();
     gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.ar0, wave, 2, 12), 12, lane, acc2);
+#ifdef FM_ONE_F_PASS
+    gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 12), 12, lane, r0);
+    gemm_phase<V, 1, STR192, 32 * STR192, 6>(abuf, a192_lo, wslice(P.rr1, wave, 1, 12), 12, lane, r1);
+#endif
     FM_SYNC();
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -383,7 +409,11 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     {
         f32x16 acc3[3][V];
         zero_acc<3, V>(acc3);
+#ifdef FM_ONE_F_PASS
+        gemm_phase<V, 3, STR256, 32 * STR256, 2, false>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane, acc3);
+#else
         gemm_phase<V, 3, STR256>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane, acc3);
+#endif
         finish_tile<V>(acc3[0], P.kv0.bias, wave * 32, P.kv0.inv_scale, false, lane);
         finish_tile<V>(acc3[1], P.kv0.bias, 128 + wave * 64, P.kv0.inv_scale, false, lane);
         finish_tile<V>(acc3[2], P.kv0.bias, 128 + wave * 64 + 32, P.kv0.inv_scale, false, lane);
@@ -509,6 +539,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     if (need_rgb) {
         // ================= RGB branch (cross_transformer.py:330-353) =================
         // feat = feature_fc(inter) + rgb_res_0(f)   (one accumulator: both layers share a scale)
+#ifdef FM_ONE_F_PASS
+        // r0 already holds rgb_res_0(f) (same power-of-two scale as feature_fc): accumulate feature_fc on top
+        gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.feat, wave, 2, 0), P.feat.KB, lane, r0);
+        FM_SYNC();
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < V; ++r) acc2[c][r] = r0[c][r];
+#else
         FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));
         f32x16 r1[1][V];
         zero_acc<2, V>(acc2);
@@ -528,6 +567,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 12), 12, lane, acc2);
         gemm_phase<V, 1, STR192, 32 * STR192, 6>(abuf, a192_lo, wslice(P.rr1, wave, 1, 12), 12, lane, r1);
         FM_SYNC();
+#endif
         // feat (+ both biases) -> ABUF [ROWS][256]; the 27 view-direction inputs of view_fc -> MBUF [32][32]
         char* vd_hi = mbuf + MBUF_VD_OFF;
         char* vd_lo = vd_hi + 32 * STRVD;
