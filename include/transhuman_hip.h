@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 1
+#define TH_ABI_VERSION 2
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -68,6 +68,14 @@ typedef struct {
     th_linear key1, val1;          /* spatial_key_value_1 (token branch)  */
     th_linear fc_1, fc_2, fc_3, alpha_fc;
     th_linear feature_fc, rgb_res_0, view_fc, rgb_res_1, fc_4, rgb_fc;
+    /* optional (w == NULL: absent): encoder.upsample_color, the 1x1 conv 3->128 that produces the last 128
+     * channels of pixel_feat_map (encoder.py:95,:139).  When given, the three layers that read the 384-channel
+     * pixel feature (alpha_res_0, rgb_res_0, rgb_res_1) are ALSO kept in a colour-folded form
+     *   W' = [W[:, :256] | W[:, 256:] Wc | 0]  (in_f 260),  b' = b + W[:, 256:] bc
+     * which is what the per-sample stage uses with a compact map (th_frame.map_channels = 260): bilinear
+     * sampling is linear with weights summing to 1, so sampling r,g,b and lifting afterwards equals
+     * sampling the lifted map. */
+    th_linear upsample_color;
 } th_mlp_weights;
 
 /* One transformer block (vision_transformer.py:285-307). */
@@ -139,22 +147,31 @@ int th_segment_mean_rot_f64(th_ctx* ctx, const double* blend, const int32_t* csr
                             const int32_t* csr_members, int n_clusters, float* rot_out,
                             th_stream stream);
 
+/* channel counts of the channels-last pixel map */
+#define TH_MAP_FULL    384   /* pixel_feat_map as the reference builds it: 256 latent + 128 lifted colour  */
+#define TH_MAP_COMPACT 260   /* 256 latent | r g b | 0 : the colour lift is folded into the consumers        */
+
 /* ---- K8: encoder tail written channels-last + painting from that map ------ */
 /* encoder.py:133-146: bilinear-upsample (align_corners=True) the three ResNet latents
  * lat0 [V,64,h0,w0], lat1 [V,64,h1,w1], lat2 [V,128,h2,w2] to HxW, append upsample_color(img)
  * (1x1 conv 3->128, color_w [128,3], color_b [128]) and write pixel_feat_map DIRECTLY channels-last
- * [V,H,W,384] (the layout K5 gathers from).  dims_host = {h0,w0,h1,w1,h2,w2} (host ints). */
+ * [V,H,W,384] (the layout K5 gathers from).  dims_host = {h0,w0,h1,w1,h2,w2} (host ints).
+ * color_w == NULL: write the COMPACT map [V,H,W,260] = 256 upsampled latent channels | r g b | 0 instead
+ * (a third less HBM written per frame and read per sample; consumers use colour-folded weights). */
 int th_upsample_concat_nhwc(th_ctx* ctx, const float* img, const float* lat0, const float* lat1,
                             const float* lat2, const int32_t* dims_host, int V, int H, int W,
                             const float* color_w, const float* color_b, float* out_nhwc, th_stream stream);
 /* paint_neural_human + can_body_grouping without materialising holder_feat_map: reduction_layer
  * (1x1 conv C->out_f, encoder.py:85,146) commutes with the bilinear sampling at :168-172, so the C-channel
  * channels-last map is sampled at the projected vertices and the layer is applied to those V*n_verts
- * rows; then the vizmap zeroing (:181-182) and the cluster mean (:356-371).  tokens_out [V,N_c,out_f]. */
+ * rows; then the vizmap zeroing (:181-182) and the cluster mean (:356-371).  tokens_out [V,N_c,out_f].
+ * C = 384 (full map) or 260 (compact map: `color_lift` = upsample_color is then required and is folded into
+ * the 384-input reduction layer on the fly); color_lift may be NULL for C = 384. */
 size_t th_paint_group_nhwc_workspace_bytes(int V, int n_verts, int C, int out_f);
 int th_paint_group_nhwc(th_ctx* ctx, const float* map_nhwc, int V, int H, int W, int C,
                         const float* verts_world, int n_verts, const float* cams, const float* scale_xy,
-                        const uint8_t* vizmap, const th_linear* reduction, const int32_t* csr_offsets,
+                        const uint8_t* vizmap, const th_linear* reduction, const th_linear* color_lift,
+                        const int32_t* csr_offsets,
                         const int32_t* csr_members, int n_clusters, float* tokens_out, void* workspace,
                         size_t workspace_bytes, th_stream stream);
 
@@ -177,11 +194,12 @@ int th_dparf_encode(th_ctx* ctx, const float* pts_smpl, const int32_t* sel, int 
 
 /* ---- K5: pixel-aligned feature gather -------------------------------------- */
 /* get_pixel_aligned_feature :210-269 on a channels-last map
- * pixel_map_nhwc [V,H,W,C]; pts_world [P,3]; out [P,V,C]. */
+ * pixel_map_nhwc [V,H,W,C]; pts_world [P,3]; out [P,V,ldo] (ldo >= C floats per row, a multiple of 4;
+ * columns C..ldo-1 are written as zeros). */
 int th_nchw_to_nhwc(th_ctx* ctx, const float* src, int V, int C, int H, int W, float* dst, th_stream stream);
 int th_pixel_gather(th_ctx* ctx, const float* pixel_map_nhwc, int V, int C, int H, int W,
                     const float* pts_world, const int32_t* sel, int P, const float* cams,
-                    const float* scale_xy, float* out, th_stream stream);
+                    const float* scale_xy, float* out, int ldo, th_stream stream);
 
 /* ---- K6: per-point multi-view MLP ------------------------------------------ */
 /* Network.forward, cross_transformer.py:207-353, on already-gathered inputs.
@@ -216,8 +234,9 @@ typedef struct {
     const float* Th;               /* [3]                                     */
     const float* cams;             /* [V,21]                                  */
     const float* scale_xy;         /* [2]                                     */
-    const float* pixel_map_nhwc;   /* [V,H,W,384]                             */
+    const float* pixel_map_nhwc;   /* [V,H,W,map_channels]                    */
     int          V, H, W;
+    int          map_channels;     /* TH_MAP_FULL (384) or TH_MAP_COMPACT (260, needs upsample_color weights) */
     const float* tokens;           /* [V,N_c,192] ViT output                  */
     const float* centres;          /* [N_c,3]                                 */
     const float* rot;              /* [N_c,9]                                 */

@@ -327,9 +327,15 @@ def test_fused_encoder_tail_equals_reference_order(hip, gpu, net):
     assert maxdiff(nhwc.permute(0, 3, 1, 2).cpu(), pix.cpu()) < 2e-5
     f_ref = r.prepare_frame(b, fused_encoder_tail=False)
     g_ref = r.last_grouped.clone()
-    f_new = r.prepare_frame(b, fused_encoder_tail=True)
-    assert maxdiff(r.last_grouped.cpu(), g_ref.cpu()) < 5e-5
-    assert maxdiff(f_new.tokens.cpu(), f_ref.tokens.cpu()) < 1e-4
+    for compact in (False, True):
+        f_new = r.prepare_frame(b, fused_encoder_tail=True, compact_map=compact)
+        assert f_new.map.shape[-1] == (260 if compact else 384)
+        assert maxdiff(r.last_grouped.cpu(), g_ref.cpu()) < 5e-5
+        assert maxdiff(f_new.tokens.cpu(), f_ref.tokens.cpu()) < 1e-4
+    # compact map = the 256 latent channels of the full map | r g b | 0
+    cmp_map = hip.upsample_concat_nhwc(imgs, lat[0], lat[1], lat[2])
+    assert torch.equal(cmp_map[..., :256], nhwc[..., :256])
+    assert torch.equal(cmp_map[..., 256:259], imgs.permute(0, 2, 3, 1)) and (cmp_map[..., 259] == 0).all()
     g13 = gold("g13_encoder")
     b32 = synth.batch_to(synth.make_batch(32, 32, 3, seed=0), gpu)
     i32 = b32["input_imgs"][0][0]
@@ -337,3 +343,38 @@ def test_fused_encoder_tail_equals_reference_order(hip, gpu, net):
     n32 = hip.upsample_concat_nhwc(i32, lat[0], lat[1], lat[2], net.encoder.upsample_color.weight,
                                    net.encoder.upsample_color.bias)
     assert maxdiff(n32.permute(0, 3, 1, 2)[:, :, ::8, ::8].cpu(), g13["pixel_px"]) < 1e-4
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_compact_map_equals_full_map(hip, gpu, net, mode):
+    """colour-lift fold: rendering from the 260-channel map with colour-folded layers == rendering from the
+    reference's 384-channel map (same function, different association of a linear map), in both MLP forms"""
+    _cfg(32)
+    b = synth.batch_to(synth.make_batch(64, 64, 3, seed=0, focal=210.0), gpu)
+    r = _renderer(net)
+    hip.set_mlp_mode(mode)
+    try:
+        outs = []
+        for compact in (False, True):
+            frame = r.prepare_frame(b, compact_map=compact)
+            outs.append(r.render_fast(b, frame=frame))
+    finally:
+        hip.set_mlp_mode(1)
+    assert maxdiff(outs[0]["rgb_map"].cpu(), outs[1]["rgb_map"].cpu()) < 3e-5
+    assert maxdiff(outs[0]["acc_map"].cpu(), outs[1]["acc_map"].cpu()) < 3e-5
+    g = gold("g11_render_large")
+    assert maxdiff(outs[1]["rgb_map"][0].cpu(), g["rgb"]) < 1e-4
+
+
+def test_pixel_gather_padded_rows(hip, gpu):
+    """th_pixel_gather with ldo > C: the sampled channels are unchanged and the tail is zero"""
+    torch.manual_seed(3)
+    m = torch.randn(2, 24, 20, 260, device=gpu)
+    pts = torch.randn(777, 3, device=gpu) * 0.3 + torch.tensor([0.0, 0.0, 3.0], device=gpu)
+    b = synth.batch_to(synth.make_batch(24, 20, 2, seed=1), gpu)
+    cams = cams_of(b, gpu)
+    scale = torch.tensor([2.0 / 20, 2.0 / 24], device=gpu)
+    a = hip.pixel_gather(m, pts, cams, scale)
+    w = hip.pixel_gather(m, pts, cams, scale, row_floats=272)
+    assert w.shape == (777, 2, 272)
+    assert torch.equal(w[..., :260], a) and (w[..., 260:] == 0).all()

@@ -9,7 +9,11 @@
 // the 3 x 6890 projected SMPL vertices (if_clight_renderer.py:168-172), and a 1x1 conv commutes with
 // bilinear sampling, so the 384-ch map is sampled at the vertices and the 384->192 layer is applied to
 // those 20 670 rows (th_gemm) before the visibility mask and the cluster mean.
-// Bound: HBM write stream (1.2 GB/frame); the latents (75 MB) stay L2/MALL resident.
+// Compact form (wc == nullptr): the colour lift is not applied here at all -- the map carries the raw
+// r,g,b after the 256 latent channels ([V,H,W,260]) and the lift is folded into the three MLP layers and
+// the reduction layer that consume those channels (see th_set_mlp_weights): 0.82 GB written instead of
+// 1.2 GB and a third fewer bytes per gathered sample.
+// Bound: HBM write stream; the latents (75 MB) stay L2/MALL resident.
 #include "th_internal.h"
 
 struct UpsSrc {
@@ -28,19 +32,29 @@ __device__ __forceinline__ void ups_coord(int dst, int in, int out, int& i0, int
     l0 = 1.0f - l1;
 }
 
-// grid (W/64, H, V*6): z%6 selects a 64-channel group: 0 lat0, 1 lat1, 2..3 lat2, 4..5 colour.
+// grid (W/64, H, V*NG): z%NG selects a 64-channel group: 0 lat0, 1 lat1, 2..3 lat2, then either 4..5 lifted
+// colour (NG = 6, CO = 384) or 4 = raw r,g,b,0 (NG = 5, CO = 260).
 // Phase 1: lane = x (coalesced source reads along x), waves stride over the group's 64 channels -> LDS tile.
 // Phase 2: 64 channels of a pixel are 256 contiguous bytes of the NHWC map.
 __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, UpsSrc s1, UpsSrc s2,
                                                                    const float* __restrict__ img,
                                                                    const float* __restrict__ wc,
                                                                    const float* __restrict__ bc, int H, int W,
-                                                                   float* __restrict__ out) {
+                                                                   int NG, int CO, float* __restrict__ out) {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane, y = blockIdx.y;
-    const int v = blockIdx.z / 6, grp = blockIdx.z % 6;
+    const int v = blockIdx.z / NG, grp = blockIdx.z % NG;
     int cout0;
+    if (grp == 4 && NG == 5) {          // compact map: channels 256..259 = r, g, b, 0 (one float4 per pixel)
+        if (wave == 0 && x < W) {
+            long long hw = (long long)H * W;
+            const float* ip = img + (long long)v * 3 * hw + (long long)y * W + x;
+            *reinterpret_cast<float4*>(out + (((long long)v * H + y) * W + x) * CO + 256) =
+                make_float4(ip[0], ip[hw], ip[2 * hw], 0.f);
+        }
+        return;
+    }
     if (grp < 4) {
         UpsSrc s = grp == 0 ? s0 : (grp == 1 ? s1 : s2);
         int cin0 = grp == 3 ? 64 : 0;
@@ -68,9 +82,9 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
         }
     }
     __syncthreads();
-    float* orow = out + (((long long)v * H + y) * W + (long long)blockIdx.x * 64) * 384 + cout0;
+    float* orow = out + (((long long)v * H + y) * W + (long long)blockIdx.x * 64) * CO + cout0;
     for (int px = wave; px < 64; px += 4)
-        if (blockIdx.x * 64 + px < W) orow[(long long)px * 384 + lane] = tile[px][lane];
+        if (blockIdx.x * 64 + px < W) orow[(long long)px * CO + lane] = tile[px][lane];
 }
 
 int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
@@ -79,8 +93,34 @@ int th_upsample_concat_launch(const float* img, const float* lat0, const float* 
     UpsSrc s0{lat0, 64, dims[0], dims[1], 0};
     UpsSrc s1{lat1, 64, dims[2], dims[3], 64};
     UpsSrc s2{lat2, 128, dims[4], dims[5], 128};
-    hipLaunchKernelGGL(upsample_concat_nhwc_kernel, dim3(th_cdiv(W, 64), H, V * 6), dim3(256), 0, s, s0, s1, s2, img, wc,
-                       bc, H, W, out);
+    const int NG = wc ? 6 : 5, CO = wc ? 384 : 260;
+    hipLaunchKernelGGL(upsample_concat_nhwc_kernel, dim3(th_cdiv(W, 64), H, V * NG), dim3(256), 0, s, s0, s1, s2, img, wc,
+                       bc, H, W, NG, CO, out);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+// Colour-lift fold: a layer L reading the full 384-channel feature [latent(256) | Wc rgb + bc] equals the layer
+//   W' = [W[:, :256] | W[:, 256:] Wc | 0] (in_f 260),  b' = b + W[:, 256:] bc   reading [latent | r g b | 0].
+__global__ void fold_color_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ wc,
+                                  const float* __restrict__ bc, int N, float* __restrict__ Wo, float* __restrict__ bo) {
+    int o = blockIdx.x;
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) Wo[(long long)o * 260 + k] = W[(long long)o * 384 + k];
+    if (threadIdx.x < 4) {
+        double acc = 0.0;
+        if (threadIdx.x < 3)
+            for (int c = 0; c < 128; ++c) acc += (double)W[(long long)o * 384 + 256 + c] * (double)wc[c * 3 + threadIdx.x];
+        else {
+            acc = b ? (double)b[o] : 0.0;
+            for (int c = 0; c < 128; ++c) acc += (double)W[(long long)o * 384 + 256 + c] * (bc ? (double)bc[c] : 0.0);
+        }
+        if (threadIdx.x < 3) Wo[(long long)o * 260 + 256 + threadIdx.x] = (float)acc;
+        else { Wo[(long long)o * 260 + 259] = 0.f; bo[o] = (float)acc; }
+    }
+}
+int th_fold_color_launch(const float* W, const float* b, const float* wc, const float* bc, int N, float* Wo, float* bo,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(fold_color_kernel, dim3(N), dim3(256), 0, s, W, b, wc, bc, N, Wo, bo);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -150,10 +150,16 @@ size_t th_mlp_ws(int V, int P) {
     return 2 * th_align(rows * 256 * 4) + 2 * th_align(rows * 384 * 4) + 2 * th_align((size_t)P * 256 * 4);
 }
 
-int th_mlp_forward(const ThMlpPacked& W, int V, int P, const float* h, const float* f, const float* vd, float* raw_c,
-                   void* ws, size_t ws_bytes, hipStream_t s) {
+int th_mlp_forward(const ThMlpPacked& W, int V, int P, const float* h, const float* f, int f_ld, const float* vd,
+                   float* raw_c, void* ws, size_t ws_bytes, hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(W.ready, "MLP weights not set (th_set_mlp_weights)");
+    TH_REQUIRE(f_ld == 384 || (f_ld == 272 && W.compact_ready),
+               "pixel-feature rows must be 384 wide, or 272 wide with upsample_color weights uploaded");
+    const bool cf = f_ld == 272;
+    const ThPacked& L_ar0 = cf ? W.alpha_res_0c : W.alpha_res_0;
+    const ThPacked& L_rr0 = cf ? W.rgb_res_0c : W.rgb_res_0;
+    const ThPacked& L_rr1 = cf ? W.rgb_res_1c : W.rgb_res_1;
     TH_REQUIRE(V >= 1 && V <= 4, "supported reference-view counts: 1..4");
     TH_REQUIRE(ws_bytes >= th_mlp_ws(V, P), "workspace too small");
     ThArena ar(ws, ws_bytes);
@@ -168,7 +174,7 @@ int th_mlp_forward(const ThMlpPacked& W, int V, int P, const float* h, const flo
 
     // _multiview_agg :313-322
     TH_TRY(th_gemm(h, 256, rows, W.fc_0, TH_ACT_RELU, B1, 256, s));              // s
-    TH_TRY(th_gemm(f, 384, rows, W.alpha_res_0, TH_ACT_RELU, B2, 256, s));       // p
+    TH_TRY(th_gemm(f, f_ld, rows, L_ar0, TH_ACT_RELU, B2, 256, s));       // p
     TH_TRY(th_gemm(B1, 256, rows, W.kv1, TH_ACT_NONE, B3, 384, s));              // ks|vs
     TH_TRY(th_gemm(B2, 256, rows, W.kv0, TH_ACT_NONE, B4, 384, s));              // kp|vp
     dim3 g4(th_cdiv(P, 4));
@@ -187,10 +193,10 @@ int th_mlp_forward(const ThMlpPacked& W, int V, int P, const float* h, const flo
     // _RGB_forward :330-353 (evaluated for every compacted sample; the
     // sigma>0 gate is applied when scattering)
     TH_TRY(th_gemm(B1, 256, rows, W.feature_fc, TH_ACT_NONE, B4, 288, s));
-    TH_TRY(th_gemm(f, 384, rows, W.rgb_res_0, TH_ACT_NONE | TH_GEMM_ACCUM, B4, 288, s));
+    TH_TRY(th_gemm(f, f_ld, rows, L_rr0, TH_ACT_NONE | TH_GEMM_ACCUM, B4, 288, s));
     hipLaunchKernelGGL(viewdir_fill_kernel, dim3(th_cdiv((long long)rows * 32, 256)), dim3(256), 0, s, vd, P, V, B4);
     TH_TRY(th_gemm(B4, 288, rows, W.view_fc, TH_ACT_RELU, B3, 128, s));
-    TH_TRY(th_gemm(f, 384, rows, W.rgb_res_1, TH_ACT_NONE | TH_GEMM_ACCUM, B3, 128, s));
+    TH_TRY(th_gemm(f, f_ld, rows, L_rr1, TH_ACT_NONE | TH_GEMM_ACCUM, B3, 128, s));
     hipLaunchKernelGGL(view_mean_kernel, dim3(th_cdiv((long long)P * 128, 256)), dim3(256), 0, s, B3, P, V, 128, M1);
     TH_TRY(th_gemm(M1, 128, P, W.fc_4, TH_ACT_RELU, M2, 128, s));
     hipLaunchKernelGGL(head_kernel<3>, g4, dim3(256), 0, s, M2, P, 128, W.rgb_w, W.rgb_b, raw_c, 4);

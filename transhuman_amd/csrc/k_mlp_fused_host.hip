@@ -23,8 +23,8 @@
 //   streamed from the L2-resident packed image straight into VGPRs
 //   (double-buffered), no LDS round trip.
 // HBM traffic per sample: 3 KB (h) + 2 x 4.6 KB (f, read again for the RGB
-// branch) + 124 B; every intermediate of the reference's ~40 kernels/chunk
-// (~70 KB/sample of HBM round trips) stays on chip.
+// branch; 2 x 3.3 KB with compact rows) + 124 B; every intermediate of the
+// reference's ~40 kernels/chunk (~70 KB/sample of HBM round trips) stays on chip.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -71,7 +71,8 @@ size_t th_fused_pack_bytes() {
     // every layer, both planes, K padded to 16 (+ biases / column tables / scratch in a 64 KiB tail)
     size_t halves = 0;
     const int dims[][2] = {{256, 256}, {384, 256}, {256, 384}, {384, 256}, {256, 256}, {256, 256}, {256, 256},
-                           {256, 256}, {256, 384}, {128, 288}, {128, 384}, {128, 128}};
+                           {256, 256}, {256, 384}, {128, 288}, {128, 384}, {128, 128},
+                           {256, 272}, {256, 272}, {128, 272}};   // colour-folded ar0 / rr0 / rr1
     for (auto& d : dims) halves += (size_t)d[0] * d[1] * 2;
     return th_align(halves * 2) + 16 * 256 + 64 * 1024;
 }
@@ -144,7 +145,7 @@ __global__ void fold_bias_kernel(const float* __restrict__ F, const float* __res
 }
 
 // Builds the fused image from the fp32 layers.  `store` = th_fused_pack_bytes() of device memory.
-int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStream_t s) {
+int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store, FusedParams* out, hipStream_t s) {
     char* tail = (char*)store + th_fused_pack_bytes() - 64 * 1024;
     PackCursor cur{(char*)store, (float*)tail, (int*)(tail + 40 * 1024)};
     unsigned int* amax = (unsigned int*)(tail + 60 * 1024);
@@ -168,12 +169,26 @@ int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStr
     PACK_SIMPLE(rr1, w->rgb_res_1, 128, 384, 1, c128);
     PACK_SIMPLE(fc_4, w->fc_4, 128, 128, 1, c128);
 #undef PACK_SIMPLE
-    // feature_fc and rgb_res_0 accumulate into ONE register tile -> they must share a scale
+    // feature_fc and rgb_res_0 (either form) accumulate into ONE register tile -> they must share a scale
     TH_TRY(layer_scale_log2(w->feature_fc.w, 256LL * 256, amax, &sl2, s));
     TH_TRY(layer_scale_log2(w->rgb_res_0.w, 256LL * 384, amax, &sl2b, s));
     if (sl2b < sl2) sl2 = sl2b;
+    if (folded) {
+        TH_TRY(layer_scale_log2(folded[1].w, 256LL * 260, amax, &sl2b, s));
+        if (sl2b < sl2) sl2 = sl2b;
+    }
     TH_TRY(pack_layer(w->feature_fc.w, w->feature_fc.b, 256, 256, 2, c256, sl2, cur, &out->feat, s));
     TH_TRY(pack_layer(w->rgb_res_0.w, w->rgb_res_0.b, 256, 384, 2, c256, sl2, cur, &out->rr0, s));
+    out->compact_ready = false;
+    if (folded) {
+        // colour-folded layers: K = 260 -> 17 k-blocks, consumed as 8 + 9 (see the kernel's f layout)
+        TH_TRY(pack_layer(folded[1].w, folded[1].b, 256, 260, 2, c256, sl2, cur, &out->rr0c, s));
+        TH_TRY(layer_scale_log2(folded[0].w, 256LL * 260, amax, &sl2, s));
+        TH_TRY(pack_layer(folded[0].w, folded[0].b, 256, 260, 2, c256, sl2, cur, &out->ar0c, s));
+        TH_TRY(layer_scale_log2(folded[2].w, 128LL * 260, amax, &sl2, s));
+        TH_TRY(pack_layer(folded[2].w, folded[2].b, 128, 260, 1, c128, sl2, cur, &out->rr1c, s));
+        out->compact_ready = true;
+    }
     // stacked key/value layers need a contiguous [384,256] weight + [384] bias
     float* tw = nullptr;
     TH_HIP(hipMalloc((void**)&tw, (size_t)(384 * 256 + 384) * 4));
@@ -202,17 +217,23 @@ int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStr
 }
 
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* h, const float* f,
-                         const float* vd, int rgb_all, float* raw_c, hipStream_t s) {
+                         int f_ld, const float* vd, int rgb_all, float* raw_c, hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(V >= 1 && V <= 3, "fused MLP supports 1..3 reference views");
+    TH_REQUIRE(f_ld == 384 || (f_ld == 272 && base.compact_ready),
+               "pixel-feature rows must be 384 wide, or 272 wide with upsample_color weights uploaded");
+    const bool cf = f_ld == 272;
     FusedParams p = base;
+    if (cf) { p.ar0 = base.ar0c; p.rr0 = base.rr0c; p.rr1 = base.rr1c; }
     p.alpha_w = heads.alpha_w; p.alpha_b = heads.alpha_b; p.rgb_w = heads.rgb_w; p.rgb_b = heads.rgb_b;
     p.h = h; p.f = f; p.vd = vd; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
     static bool attr = false;
     if (!attr) {
-        TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-        TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
-        TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_LDS_BYTES));
+#define FM_ATTR(V_, F_)                                                                                       \
+    TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<V_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               FUSED_LDS_BYTES))
+        FM_ATTR(1, 0); FM_ATTR(2, 0); FM_ATTR(3, 0); FM_ATTR(1, 1); FM_ATTR(2, 1); FM_ATTR(3, 1);
+#undef FM_ATTR
         attr = true;
     }
     dim3 grid(th_cdiv(P, FM_PTS));
@@ -235,11 +256,16 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
         TH_HIP(hipMemsetAsync(dbg_dev, 0, 64 * sizeof(long long), s));
         p.dbg = dbg_dev;
     }
-    switch (V) {
-        case 1: hipLaunchKernelGGL(mlp_fused_kernel<1>, grid, dim3(256), FUSED_LDS_BYTES, s, p); break;
-        case 2: hipLaunchKernelGGL(mlp_fused_kernel<2>, grid, dim3(256), FUSED_LDS_BYTES, s, p); break;
-        default: hipLaunchKernelGGL(mlp_fused_kernel<3>, grid, dim3(256), FUSED_LDS_BYTES, s, p); break;
+#define FM_LAUNCH(V_, F_) hipLaunchKernelGGL((mlp_fused_kernel<V_, F_>), grid, dim3(256), FUSED_LDS_BYTES, s, p)
+    switch (V * 2 + (cf ? 1 : 0)) {
+        case 2: FM_LAUNCH(1, 0); break;
+        case 3: FM_LAUNCH(1, 1); break;
+        case 4: FM_LAUNCH(2, 0); break;
+        case 5: FM_LAUNCH(2, 1); break;
+        case 6: FM_LAUNCH(3, 0); break;
+        default: FM_LAUNCH(3, 1); break;
     }
+#undef FM_LAUNCH
     TH_LAUNCH_CHECK();
     if (dbg_now) {
         long long st[64];

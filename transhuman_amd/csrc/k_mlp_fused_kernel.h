@@ -142,16 +142,26 @@ __device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb,
 
 #define FM_SB() __builtin_amdgcn_sched_barrier(0)
 
-// staging policy: loads of the next operand are issued right before they are committed to LDS
-// (FM_EARLY_STAGE would issue them one GEMM earlier; vmcnt retires in order, so the GEMM's first weight
-// wait then also waits for the whole staging burst -- measured slower)
-#ifdef FM_EARLY_STAGE
-#define FM_EARLY(...) __VA_ARGS__
-#define FM_LATE(...)
-#else
-#define FM_EARLY(...)
-#define FM_LATE(...) __VA_ARGS__
-#endif
+// staging policy: the loads of an operand are issued right before they are committed to LDS.  (Issuing them
+// one GEMM earlier was measured slower: vmcnt retires in order, so the GEMM's first weight wait then also
+// waits for the whole staging burst.)
+template <int V, int KC, int STR>
+__device__ __forceinline__ void stage_now(const float* __restrict__ src, int ld, int coff, int pbase, int npts,
+                                          char* __restrict__ hi, char* __restrict__ lo, int tid) {
+    StageRegs<V, KC> r;
+    stage_issue<V, KC>(r, src, ld, coff, pbase, npts, tid);
+    stage_commit<V, KC, STR>(r, hi, lo, tid);
+}
+
+// Layout of the pixel-feature rows f and how their K range is split over two ABUF fillings:
+//   FM = 0  full rows, 384 floats (pixel_feat_map as the reference builds it):        192 + 192, 12 + 12 k-blocks
+//   FM = 1  compact rows, 272 floats = 256 latent | r g b | 0 (colour lift folded into the weights):
+//                                                                                      128 + 144,  8 +  9 k-blocks
+// LDS row strides must be == 16 mod 128 B (conflict-free ds_read_b128): 272 B for K = 128; K = 144 uses the
+// 400 B stride of K = 192.
+template <int FM> struct FLay;
+template <> struct FLay<0> { static constexpr int LD = 384, KA = 192, KB2 = 192, SA = STR192, SB = STR192, NA = 12, NB = 12; };
+template <> struct FLay<1> { static constexpr int LD = 272, KA = 128, KB2 = 144, SA = STR128, SB = STR192, NA = 8, NB = 9; };
 
 // acc[ct][rt] += W_tile(ct) * A_rows(rt)^T over KB k-blocks of 16.
 //  * weight fragments stream from the (L2-resident) packed image through a ring of D register sets: block
@@ -292,8 +302,9 @@ __device__ __forceinline__ const uint4* wslice(const FusedLayer& L, int wave, in
     return L.w + ((long long)wave * L.KB + kb0) * (ct * 2 * 64);
 }
 
-template <int V>
+template <int V, int FM>
 __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
+    using FL = FLay<FM>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* abuf = lds;
     char* mbuf = lds + ABUF_BYTES;
@@ -322,8 +333,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     if (P.dbg != nullptr && tid == 0 && blockIdx.x == gridDim.x / 2) P.dbg[dbg_i++] = clock64();
 
     char* a256_lo = abuf + ROWS * STR256;
-    char* a192_lo = abuf + ROWS * STR192;
-    StageRegs<V, 192> rf;
+    char* fa_lo = abuf + ROWS * FL::SA;      // lo planes of the two f fillings
+    char* fb_lo = abuf + ROWS * FL::SB;
 
     // ================= token branch: s = relu(fc_0 h); ks|vs = kv1(s) =================
     {
@@ -336,7 +347,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         stage_commit<V, 256, STR256>(rh, abuf, a256_lo, tid);
     }
     FM_SYNC();
-    FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));   // early mode: f[:, 0:192] flies under fc_0 / kv1
     f32x16 acc2[2][V];
     zero_acc<2, V>(acc2);
     gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_0, wave, 2, 0), P.fc_0.KB, lane, acc2);
@@ -369,33 +379,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     FM_SYNC();
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
-    // FM_ONE_F_PASS: the two f-consuming layers of the RGB branch (rgb_res_0, rgb_res_1) are evaluated in the
-    // same pass over f and their accumulators (144 registers) stay resident until the RGB branch: f is read
-    // from HBM once instead of twice and the RGB branch loses two staging + GEMM phases.
     zero_acc<2, V>(acc2);
-#ifdef FM_ONE_F_PASS
-    f32x16 r0[2][V], r1[1][V];
-    zero_acc<2, V>(r0);
-    zero_acc<1, V>(r1);
-#endif
-    FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));
-    stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
-    FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
+    stage_now<V, FL::KA, FL::SA>(P.f, FL::LD, 0, pbase, npts, abuf, fa_lo, tid);
     FM_SYNC();
-    gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.ar0, wave, 2, 0), 12, lane, acc2);
-#ifdef FM_ONE_F_PASS
-    gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 0), 12, lane, r0);
-    gemm_phase<V, 1, STR192, 32 * STR192, 6>(abuf, a192_lo, wslice(P.rr1, wave, 1, 0), 12, lane, r1);
-#endif
+    gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2);
     FM_SYNC();
-    FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
-    stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
+    stage_now<V, FL::KB2, FL::SB>(P.f, FL::LD, FL::KA, pbase, npts, abuf, fb_lo, tid);
     FM_SYNC();
-    gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.ar0, wave, 2, 12), 12, lane, acc2);
-#ifdef FM_ONE_F_PASS
-    gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 12), 12, lane, r0);
-    gemm_phase<V, 1, STR192, 32 * STR192, 6>(abuf, a192_lo, wslice(P.rr1, wave, 1, 12), 12, lane, r1);
-#endif
+    gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.ar0, wave, 2, FL::NA), FL::NB, lane, acc2);
     FM_SYNC();
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -409,11 +400,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     {
         f32x16 acc3[3][V];
         zero_acc<3, V>(acc3);
-#ifdef FM_ONE_F_PASS
-        gemm_phase<V, 3, STR256, 32 * STR256, 2, false>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane, acc3);
-#else
         gemm_phase<V, 3, STR256>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane, acc3);
-#endif
         finish_tile<V>(acc3[0], P.kv0.bias, wave * 32, P.kv0.inv_scale, false, lane);
         finish_tile<V>(acc3[1], P.kv0.bias, 128 + wave * 64, P.kv0.inv_scale, false, lane);
         finish_tile<V>(acc3[2], P.kv0.bias, 128 + wave * 64 + 32, P.kv0.inv_scale, false, lane);
@@ -539,35 +526,21 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     if (need_rgb) {
         // ================= RGB branch (cross_transformer.py:330-353) =================
         // feat = feature_fc(inter) + rgb_res_0(f)   (one accumulator: both layers share a scale)
-#ifdef FM_ONE_F_PASS
-        // r0 already holds rgb_res_0(f) (same power-of-two scale as feature_fc): accumulate feature_fc on top
-        gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.feat, wave, 2, 0), P.feat.KB, lane, r0);
-        FM_SYNC();
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < V; ++r) acc2[c][r] = r0[c][r];
-#else
-        FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));
         f32x16 r1[1][V];
         zero_acc<2, V>(acc2);
         zero_acc<1, V>(r1);
         gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.feat, wave, 2, 0), P.feat.KB, lane, acc2);
         FM_SYNC();
-        FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 0, pbase, npts, tid));
-        stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
-        FM_EARLY(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
+        stage_now<V, FL::KA, FL::SA>(P.f, FL::LD, 0, pbase, npts, abuf, fa_lo, tid);
         FM_SYNC();
-        gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 0), 12, lane, acc2);
-        gemm_phase<V, 1, STR192, 32 * STR192, 6>(abuf, a192_lo, wslice(P.rr1, wave, 1, 0), 12, lane, r1);
+        gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.rr0, wave, 2, 0), FL::NA, lane, acc2);
+        gemm_phase<V, 1, FL::SA, 32 * FL::SA, 6>(abuf, fa_lo, wslice(P.rr1, wave, 1, 0), FL::NA, lane, r1);
         FM_SYNC();
-        FM_LATE(stage_issue<V, 192>(rf, P.f, 384, 192, pbase, npts, tid));
-        stage_commit<V, 192, STR192>(rf, abuf, a192_lo, tid);
+        stage_now<V, FL::KB2, FL::SB>(P.f, FL::LD, FL::KA, pbase, npts, abuf, fb_lo, tid);
         FM_SYNC();
-        gemm_phase<V, 2, STR192>(abuf, a192_lo, wslice(P.rr0, wave, 2, 12), 12, lane, acc2);
-        gemm_phase<V, 1, STR192, 32 * STR192, 6>(abuf, a192_lo, wslice(P.rr1, wave, 1, 12), 12, lane, r1);
+        gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.rr0, wave, 2, FL::NA), FL::NB, lane, acc2);
+        gemm_phase<V, 1, FL::SB, 32 * FL::SB, 6>(abuf, fb_lo, wslice(P.rr1, wave, 1, FL::NA), FL::NB, lane, r1);
         FM_SYNC();
-#endif
         // feat (+ both biases) -> ABUF [ROWS][256]; the 27 view-direction inputs of view_fc -> MBUF [32][32]
         char* vd_hi = mbuf + MBUF_VD_OFF;
         char* vd_lo = vd_hi + 32 * STRVD;

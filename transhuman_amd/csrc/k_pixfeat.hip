@@ -8,14 +8,17 @@
 // channels-last (th_nchw_to_nhwc, once per frame) so each corner is one
 // contiguous 1.5 KB read, and only hull-valid samples are gathered.
 // One wave per (sample, view) row; lanes span channels (float4 per lane).
-// Bound: L2/HBM gather, 4 * 1536 B per (sample, view) in, 1536 B out.
+// The map has C channels per pixel (384 full / 260 compact, see k_encoder.hip); output rows are ldo floats
+// wide (>= C; the tail is zero-filled so the row can feed a K-padded GEMM directly: compact rows are 272).
+// Bound: L2/HBM gather, 4 * 4C B per (sample, view) in, 4*ldo B out.
 #include "th_internal.h"
 
 __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict__ map, int V, int C, int H, int W,
                                                         const float* __restrict__ pts_world, ThPointSrc ps,
                                                         const int32_t* __restrict__ sel, int P,
                                                         const float* __restrict__ cams,
-                                                        const float* __restrict__ scale, float* __restrict__ out) {
+                                                        const float* __restrict__ scale, float* __restrict__ out,
+                                                        int ldo) {
     const int lane = threadIdx.x & 63;
     // XCD-aware remap (speed only): workgroup b runs on XCD b % 8, each XCD has its own L2.  Neighbouring
     // samples of a ray share bilinear corners, so give every XCD a CONTIGUOUS range of rows: logical block
@@ -37,9 +40,10 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
     const float4* p01 = reinterpret_cast<const float4*>(m + (long long)b.i01 * C);
     const float4* p10 = reinterpret_cast<const float4*>(m + (long long)b.i10 * C);
     const float4* p11 = reinterpret_cast<const float4*>(m + (long long)b.i11 * C);
-    float4* o = reinterpret_cast<float4*>(out + row * C);
+    float4* o = reinterpret_cast<float4*>(out + row * ldo);
     // 16 B per lane: C = 384 -> 96 float4 per corner row = 1.5 wave-loads (the second one half masked)
-    for (int c4 = lane; c4 < C / 4; c4 += 64) {
+    for (int c4 = lane; c4 < ldo / 4; c4 += 64) {
+        if (c4 >= C / 4) { o[c4] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
         float4 a = p00[c4], bb = p01[c4], cc = p10[c4], d = p11[c4];
         float4 r;
         r.x = a.x * b.w00; r.x = r.x + bb.x * b.w01; r.x = r.x + cc.x * b.w10; r.x = r.x + d.x * b.w11;
@@ -51,15 +55,15 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
 }
 
 int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world, const ThPointSrc* ps,
-                        const int32_t* sel, int P, const float* cams, const float* scale, float* out,
+                        const int32_t* sel, int P, const float* cams, const float* scale, float* out, int ldo,
                         hipStream_t s) {
     if (P <= 0) return 0;
-    TH_REQUIRE((C & 3) == 0, "channel count must be a multiple of 4");
+    TH_REQUIRE((C & 3) == 0 && (ldo & 3) == 0 && ldo >= C, "channel count / row stride must be multiples of 4, ldo >= C");
     ThPointSrc src = ps ? *ps : ThPointSrc{};
     long long rows = (long long)P * V;
     const int nblk = 8 * th_cdiv(th_cdiv(rows, 4), 8);      // multiple of 8 so the XCD remap is onto
     hipLaunchKernelGGL(pixgather_kernel, dim3(nblk), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel, P, cams,
-                       scale, out);
+                       scale, out, ldo);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -131,6 +131,13 @@ int th_set_mlp_weights(th_ctx* c, const th_mlp_weights* w, th_stream stream) {
                     {&w->rgb_res_0, &M.rgb_res_0, 256, 384}, {&w->view_fc, &M.view_fc, 128, 283},
                     {&w->rgb_res_1, &M.rgb_res_1, 128, 384}, {&w->fc_4, &M.fc_4, 128, 128}};
     for (auto& it : items) total += ThPacked::bytes(it.out_f, it.in_f);
+    // colour-folded forms (optional): packed layers + fp32 fold scratch [N,260] + [N]
+    const bool have_lift = w->upsample_color.w != nullptr;
+    if (have_lift) TH_REQUIRE(lin_ok(w->upsample_color, 128, 3), "upsample_color must be a 3 -> 128 layer (encoder.py:95)");
+    const size_t cpk_off = total;
+    if (have_lift) total += 2 * ThPacked::bytes(256, 260) + ThPacked::bytes(128, 260);
+    const size_t cfold_off = total;
+    if (have_lift) total += 3 * th_align((size_t)(256 * 260 + 256) * sizeof(float));
     size_t heads_off = total;
     total += th_align((256 + 1 + 3 * 128 + 3) * sizeof(float));
     size_t tmp_off = total;
@@ -169,13 +176,30 @@ int th_set_mlp_weights(th_ctx* c, const th_mlp_weights* w, th_stream stream) {
     else TH_HIP(hipMemsetAsync(M.alpha_b, 0, 4, s));
     if (w->rgb_fc.b) TH_HIP(hipMemcpyAsync(M.rgb_b, w->rgb_fc.b, 12, hipMemcpyDeviceToDevice, s));
     else TH_HIP(hipMemsetAsync(M.rgb_b, 0, 12, s));
+    th_linear folded[3] = {};
+    M.compact_ready = false;
+    if (have_lift) {
+        const th_linear* src3[3] = {&w->alpha_res_0, &w->rgb_res_0, &w->rgb_res_1};
+        ThPacked* dst3[3] = {&M.alpha_res_0c, &M.rgb_res_0c, &M.rgb_res_1c};
+        size_t po = cpk_off;
+        for (int i = 0; i < 3; ++i) {
+            float* fw = (float*)(base + cfold_off + i * th_align((size_t)(256 * 260 + 256) * sizeof(float)));
+            float* fb = fw + 256 * 260;
+            const int N = src3[i]->out_f;
+            TH_TRY(th_fold_color_launch(src3[i]->w, src3[i]->b, w->upsample_color.w, w->upsample_color.b, N, fw, fb, s));
+            folded[i].w = fw; folded[i].b = fb; folded[i].out_f = N; folded[i].in_f = 260;
+            TH_TRY(th_pack_linear(folded[i], base + po, dst3[i], s));
+            po += ThPacked::bytes(N, 260);
+        }
+        M.compact_ready = true;
+    }
     TH_HIP(hipStreamSynchronize(s));
     M.ready = true;
     // fused-kernel image (fp16 hi/lo split, per-wave fragment order)
     c->fused_ready = false;
     if (c->fused_store) { TH_HIP(hipFree(c->fused_store)); c->fused_store = nullptr; }
     TH_HIP(hipMalloc(&c->fused_store, th_fused_pack_bytes()));
-    TH_TRY(th_fused_pack(w, c->fused_store, &c->fused, s));
+    TH_TRY(th_fused_pack(w, have_lift ? folded : nullptr, c->fused_store, &c->fused, s));
     c->fused_ready = true;
     return 0;
 }
@@ -279,22 +303,27 @@ int th_segment_mean_rot_f64(th_ctx* c, const double* blend, const int32_t* off, 
 int th_upsample_concat_nhwc(th_ctx* c, const float* img, const float* lat0, const float* lat1, const float* lat2,
                             const int32_t* dims_host, int V, int H, int W, const float* color_w, const float* color_b,
                             float* out_nhwc, th_stream stream) {
-    TH_REQUIRE(c && img && lat0 && lat1 && lat2 && dims_host && color_w && color_b && out_nhwc, "null argument");
+    TH_REQUIRE(c && img && lat0 && lat1 && lat2 && dims_host && out_nhwc, "null argument");
+    TH_REQUIRE(color_w == nullptr || color_b != nullptr, "color_b is required with color_w");
     return th_upsample_concat_launch(img, lat0, lat1, lat2, dims_host, V, H, W, color_w, color_b, out_nhwc,
                                      (hipStream_t)stream);
 }
 
 size_t th_paint_group_nhwc_workspace_bytes(int V, int n_verts, int C, int out_f) {
     size_t rows = (size_t)V * n_verts;
-    return th_align(rows * C * 4) + th_align(rows * out_f * 4) + ThPacked::bytes(out_f, C);
+    return th_align(rows * C * 4) + th_align(rows * out_f * 4) + ThPacked::bytes(out_f, C) +
+           th_align((size_t)(out_f * 260 + out_f) * 4);
 }
 
 int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, int C, const float* verts, int nv,
                         const float* cams, const float* scale, const uint8_t* viz, const th_linear* reduction,
-                        const int32_t* off, const int32_t* mem, int nc, float* tokens, void* ws, size_t ws_bytes,
-                        th_stream stream) {
+                        const th_linear* color_lift, const int32_t* off, const int32_t* mem, int nc, float* tokens,
+                        void* ws, size_t ws_bytes, th_stream stream) {
     TH_REQUIRE(c && map_nhwc && verts && cams && scale && reduction && off && mem && tokens && ws, "null argument");
-    TH_REQUIRE(reduction->in_f == C, "reduction layer must take the map's channel count");
+    const bool compact = C == TH_MAP_COMPACT;
+    TH_REQUIRE(reduction->in_f == (compact ? TH_MAP_FULL : C), "reduction layer must take the (full) map's channel count");
+    TH_REQUIRE(!compact || (color_lift && color_lift->w && lin_ok(*color_lift, 128, 3)),
+               "a compact map needs the upsample_color layer (3 -> 128) to fold into the reduction layer");
     const int out_f = reduction->out_f;
     TH_REQUIRE(ws_bytes >= th_paint_group_nhwc_workspace_bytes(V, nv, C, out_f), "workspace too small");
     hipStream_t s = (hipStream_t)stream;
@@ -303,11 +332,18 @@ int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, i
     float* g = ar.take<float>(rows * C);              // [nv][V][C]
     float* r = ar.take<float>(rows * out_f);          // [nv][V][out_f]
     void* pk = ar.take<char>(ThPacked::bytes(out_f, C));
-    TH_REQUIRE(pk != nullptr, "workspace carve failed");
+    float* fold = ar.take<float>((size_t)out_f * 260 + out_f);
+    TH_REQUIRE(fold != nullptr, "workspace carve failed");
     // sample the channels-last map at the projected vertices, then the 1x1 conv on those rows only
-    TH_TRY(th_pixgather_launch(map_nhwc, V, C, H, W, verts, nullptr, nullptr, nv, cams, scale, g, s));
+    TH_TRY(th_pixgather_launch(map_nhwc, V, C, H, W, verts, nullptr, nullptr, nv, cams, scale, g, C, s));
     ThPacked P;
-    TH_TRY(th_pack_linear(*reduction, pk, &P, s));
+    th_linear red = *reduction;
+    if (compact) {
+        TH_TRY(th_fold_color_launch(reduction->w, reduction->b, color_lift->w, color_lift->b, out_f, fold,
+                                    fold + (size_t)out_f * 260, s));
+        red.w = fold; red.b = fold + (size_t)out_f * 260; red.in_f = 260;
+    }
+    TH_TRY(th_pack_linear(red, pk, &P, s));
     TH_TRY(th_gemm(g, C, (int)rows, P, TH_ACT_NONE, r, out_f, s));
     return th_segmean_masked_launch(r, V, out_f, viz, nv, off, mem, nc, tokens, s);
 }
@@ -334,9 +370,9 @@ int th_nchw_to_nhwc(th_ctx* c, const float* src, int V, int C, int H, int W, flo
 }
 
 int th_pixel_gather(th_ctx* c, const float* map, int V, int C, int H, int W, const float* pts, const int32_t* sel,
-                    int P, const float* cams, const float* scale, float* out, th_stream stream) {
+                    int P, const float* cams, const float* scale, float* out, int ldo, th_stream stream) {
     TH_REQUIRE(c && map && pts && cams && scale && out, "null argument");
-    return th_pixgather_launch(map, V, C, H, W, pts, nullptr, sel, P, cams, scale, out, (hipStream_t)stream);
+    return th_pixgather_launch(map, V, C, H, W, pts, nullptr, sel, P, cams, scale, out, ldo, (hipStream_t)stream);
 }
 
 int th_composite(th_ctx* c, const float* raw, const float* z, const th_points* rays, int white, float* rgb,
@@ -396,11 +432,12 @@ static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
 }
 
 // K6 dispatch: fused fp16x3-split kernel (default, V <= 3) or the layer-by-layer fp32 MFMA form
-static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int rgb_all, hipStream_t s) {
+// f_ld: floats per pixel-feature row of cb.f (384 full / 272 compact)
+static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, int rgb_all, hipStream_t s) {
     TH_REQUIRE(c->mlp.ready, "MLP weights not set (th_set_mlp_weights)");
     if (c->mlp_mode == 1 && c->fused_ready && V <= 3)
-        return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.f, cb.vdc, rgb_all, cb.raw_c, s);
-    return th_mlp_forward(c->mlp, V, m, cb.h, cb.f, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s);
+        return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.f, f_ld, cb.vdc, rgb_all, cb.raw_c, s);
+    return th_mlp_forward(c->mlp, V, m, cb.h, cb.f, f_ld, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s);
 }
 
 size_t th_network_workspace_bytes(int V, int P) {
@@ -444,7 +481,7 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
             TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, s));
             TH_TRY(th_gather_rows_launch(viewdir + 27LL * o, 27, nullptr, 1, m, cb.vdc, s));
         }
-        TH_TRY(mlp_dispatch(c, V, m, cb, idx ? 0 : 1, s));
+        TH_TRY(mlp_dispatch(c, V, m, cb, 384, idx ? 0 : 1, s));
         if (idx) TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, 0, raw_out, s));
         else TH_TRY(th_scatter_raw_launch(cb.raw_c, nullptr, m, 1, raw_out + 4LL * o, s));
     }
@@ -459,6 +496,8 @@ static int frame_ok(const th_frame* f) {
                    f->centres && f->rot,
                "incomplete th_frame");
     TH_REQUIRE(f->V >= 1 && f->V <= 4, "supported reference-view counts: 1..4");
+    TH_REQUIRE(f->map_channels == TH_MAP_FULL || f->map_channels == TH_MAP_COMPACT,
+               "th_frame.map_channels must be 384 (full pixel_feat_map) or 260 (compact map)");
     return 0;
 }
 
@@ -473,6 +512,10 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
 static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long long P, bool ray_mode, ThArena& ar,
                         float** raw_out, int64_t* stats_host, hipStream_t s) {
     const int R = ps.R, S = ps.S, V = f->V;
+    const bool compact = f->map_channels == TH_MAP_COMPACT;
+    const int f_ld = compact ? 272 : 384;
+    TH_REQUIRE(!compact || c->mlp.compact_ready,
+               "compact pixel map needs th_mlp_weights.upsample_color (colour-folded layers) to be uploaded");
     uint8_t* mask = ar.take<uint8_t>((size_t)P);
     int32_t* ray_hit = ar.take<int32_t>((size_t)R);
     size_t hws_b = th_hull_ws(f->n_verts);
@@ -522,13 +565,13 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         }
         {
             ProfScope ps2(pf, TH_PROF_GATHER, s);
-            TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, 384, f->H, f->W, nullptr, &ps, sel, m, f->cams,
-                                       f->scale_xy, cb.f, s));
+            TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, sel, m, f->cams,
+                                       f->scale_xy, cb.f, f_ld, s));
             if (ray_mode) TH_TRY(th_gather_rows_launch(vd_all, 27, sel, S, m, cb.vdc, s));
         }
         {
             ProfScope ps3(pf, TH_PROF_MLP, s);
-            TH_TRY(mlp_dispatch(c, V, m, cb, unmasked, s));
+            TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, unmasked, s));
         }
         ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));

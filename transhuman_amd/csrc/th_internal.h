@@ -159,6 +159,9 @@ __device__ __forceinline__ void th_project(const float* __restrict__ cam, float 
 // ---- context ----------------------------------------------------------------------
 struct ThMlpPacked {
     ThPacked fc_0, alpha_res_0, kv0, kv1, fc_1, fc_2, fc_3, feature_fc, rgb_res_0, view_fc, rgb_res_1, fc_4;
+    // colour-folded forms of the three layers that read the pixel feature (in_f 260, rows 272 floats wide)
+    ThPacked alpha_res_0c, rgb_res_0c, rgb_res_1c;
+    bool compact_ready = false;
     // tiny heads kept as plain rows
     float *alpha_w = nullptr, *alpha_b = nullptr;   // [256], [1]
     float *rgb_w = nullptr, *rgb_b = nullptr;       // [3*128], [3]
@@ -184,9 +187,11 @@ struct FusedLayer {
 };
 struct FusedParams {
     FusedLayer fc_0, kv1, ar0, kv0, fc_1, fc_2, fc_3, feat, rr0, vfc, rr1, fc_4;
+    FusedLayer ar0c, rr0c, rr1c;   // colour-folded (K = 272) forms; the launcher copies them over ar0/rr0/rr1
+    bool compact_ready;
     const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
     const float* h;     // [P][V][256]
-    const float* f;     // [P][V][384]
+    const float* f;     // [P][V][384] (full) or [P][V][272] (compact: 256 latent | r g b | 0...)
     const float* vd;    // [P][27]
     float* raw_c;       // [P][4]
     int P;
@@ -195,9 +200,10 @@ struct FusedParams {
     int skew_cycles;    // start-up stagger unit of the first 256 workgroups (0 = off)
 };
 size_t th_fused_pack_bytes();
-int th_fused_pack(const th_mlp_weights* w, void* store, FusedParams* out, hipStream_t s);
+// folded: nullptr or the three colour-folded fp32 layers {alpha_res_0, rgb_res_0, rgb_res_1} (in_f 260)
+int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store, FusedParams* out, hipStream_t s);
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* h,
-                         const float* f, const float* vd, int rgb_all, float* raw_c, hipStream_t s);
+                         const float* f, int f_ld, const float* vd, int rgb_all, float* raw_c, hipStream_t s);
 
 struct th_ctx {
     void* fused_store = nullptr;
@@ -244,13 +250,14 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
 // k_pixfeat.hip
 int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world,
                         const ThPointSrc* ps, const int32_t* sel, int P, const float* cams, const float* scale,
-                        float* out, hipStream_t s);
+                        float* out, int ldo, hipStream_t s);
 int th_gather_chan_major_launch(const float* pf /*[V,C,Pall]*/, int V, int C, long long Pall, const int32_t* sel,
                                 int P, float* out /*[P,V,C]*/, hipStream_t s);
 // k_mlp.hip
 size_t th_mlp_ws(int V, int P);
-// h [P*V,256], f [P*V,384], vd rows [P,27] (gathered), -> raw_c [P,4]
-int th_mlp_forward(const ThMlpPacked& W, int V, int P, const float* h, const float* f, const float* vd,
+// h [P*V,256], f [P*V,f_ld] (f_ld 384: full rows, 272: compact rows + colour-folded layers), vd rows [P,27]
+// (gathered), -> raw_c [P,4]
+int th_mlp_forward(const ThMlpPacked& W, int V, int P, const float* h, const float* f, int f_ld, const float* vd,
                    float* raw_c, void* ws, size_t ws_bytes, hipStream_t s);
 int th_gather_rows_launch(const float* src, int width, const int32_t* sel, int div, int P, float* out, hipStream_t s);
 // raw[sel[p]] = raw_c[p] (rgb zeroed where sigma<=0 unless rgb_all)
@@ -268,5 +275,8 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
 int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
                               const int* dims, int V, int H, int W, const float* wc, const float* bc, float* out,
                               hipStream_t s);
+// W' [N,260] = [W[:, :256] | W[:, 256:384] Wc | 0], b' = b + W[:, 256:384] bc  (fp64 accumulation)
+int th_fold_color_launch(const float* W /*[N,384]*/, const float* b, const float* wc /*[128,3]*/, const float* bc,
+                         int N, float* Wo /*[N,260]*/, float* bo /*[N]*/, hipStream_t s);
 int th_segmean_masked_launch(const float* rows, int V, int width, const uint8_t* viz, int nv, const int32_t* off,
                              const int32_t* mem, int nc, float* out, hipStream_t s);

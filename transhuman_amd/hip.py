@@ -23,7 +23,7 @@ class ThLinear(C.Structure):
 
 class ThMlpWeights(C.Structure):
     _names = ["fc_0", "alpha_res_0", "key0", "val0", "key1", "val1", "fc_1", "fc_2", "fc_3", "alpha_fc",
-              "feature_fc", "rgb_res_0", "view_fc", "rgb_res_1", "fc_4", "rgb_fc"]
+              "feature_fc", "rgb_res_0", "view_fc", "rgb_res_1", "fc_4", "rgb_fc", "upsample_color"]
     _fields_ = [(n, ThLinear) for n in _names]
 
 
@@ -41,7 +41,7 @@ class ThPoints(C.Structure):
 class ThFrame(C.Structure):
     _fields_ = [("verts_world", C.c_void_p), ("n_verts", C.c_int), ("Rh", C.c_void_p), ("Th", C.c_void_p),
                 ("cams", C.c_void_p), ("scale_xy", C.c_void_p), ("pixel_map_nhwc", C.c_void_p), ("V", C.c_int),
-                ("H", C.c_int), ("W", C.c_int), ("tokens", C.c_void_p), ("centres", C.c_void_p),
+                ("H", C.c_int), ("W", C.c_int), ("map_channels", C.c_int), ("tokens", C.c_void_p), ("centres", C.c_void_p),
                 ("rot", C.c_void_p), ("n_clusters", C.c_int), ("hull_thresh", C.c_float),
                 ("small_frame_rays", C.c_int)]
 
@@ -77,8 +77,8 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p]),
     "th_paint_group_nhwc_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "th_paint_group_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ThLinear), C.c_void_p, C.c_void_p,
-                                      C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ThLinear), C.POINTER(ThLinear),
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "th_vit_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "th_vit_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
@@ -87,7 +87,7 @@ SYMBOLS = {
     "th_nchw_to_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p]),
     "th_pixel_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "th_network_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "th_network_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -124,7 +124,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 1:
+    if lib.th_abi_version() != 2:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -184,6 +184,10 @@ def set_mlp_weights(net):
              "val1": net.spatial_key_value_1.value_embed, "fc_1": net.fc_1, "fc_2": net.fc_2, "fc_3": net.fc_3,
              "alpha_fc": net.alpha_fc, "feature_fc": net.feature_fc, "rgb_res_0": net.rgb_res_0,
              "view_fc": net.view_fc, "rgb_res_1": net.rgb_res_1, "fc_4": net.fc_4, "rgb_fc": net.rgb_fc}
+    # optional: the encoder's colour lift (encoder.py:95) -> colour-folded layers for the compact pixel map
+    enc = getattr(net, "encoder", None)
+    if enc is not None and hasattr(enc, "upsample_color"):
+        pairs["upsample_color"] = enc.upsample_color
     for name, mod in pairs.items():
         lin, k = _linear(mod.weight, mod.bias)
         keep.append(k)
@@ -307,33 +311,38 @@ def paint_group(holder_map, verts_world, cams, scale_xy, vizmap, off, mem, retur
     return (tokens, painted) if return_painted else tokens
 
 
-def upsample_concat_nhwc(images, lat0, lat1, lat2, color_w, color_b):
-    """Encoder tail (encoder.py:133-146) -> channels-last pixel_feat_map [V,H,W,384]."""
+def upsample_concat_nhwc(images, lat0, lat1, lat2, color_w=None, color_b=None):
+    """Encoder tail (encoder.py:133-146) -> channels-last pixel_feat_map [V,H,W,384], or with
+    color_w=None the compact map [V,H,W,260] (256 latent | r g b | 0; the lift is folded into the consumers)."""
     lib = load_library()
     img, l0, l1, l2 = _f32(images), _f32(lat0), _f32(lat1), _f32(lat2)
     V, _, H, W = img.shape
     assert l0.shape[1] == 64 and l1.shape[1] == 64 and l2.shape[1] == 128
     dims = (C.c_int32 * 6)(l0.shape[2], l0.shape[3], l1.shape[2], l1.shape[3], l2.shape[2], l2.shape[3])
-    cw, cb = _f32(color_w).reshape(128, 3), _f32(color_b)
-    out = torch.empty((V, H, W, 384), dtype=torch.float32, device=img.device)
+    cw = _f32(color_w).reshape(128, 3) if color_w is not None else None
+    cb = _f32(color_b) if color_w is not None else None
+    out = torch.empty((V, H, W, 384 if color_w is not None else 260), dtype=torch.float32, device=img.device)
     _check(lib.th_upsample_concat_nhwc(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(cw), _p(cb),
                                        _p(out), _stream()))
     return out
 
 
-def paint_group_nhwc(map_nhwc, verts_world, cams, scale_xy, vizmap, red_w, red_b, off, mem):
-    """Sample the channels-last map at the projected vertices, apply reduction_layer there, mask, pool."""
+def paint_group_nhwc(map_nhwc, verts_world, cams, scale_xy, vizmap, red_w, red_b, off, mem, color_w=None,
+                     color_b=None):
+    """Sample the channels-last map at the projected vertices, apply reduction_layer there, mask, pool.
+    A compact (260-channel) map needs the colour lift (color_w, color_b) to fold into the reduction layer."""
     lib = load_library()
     V, H, W, Cc = map_nhwc.shape
     v = _f32(verts_world).reshape(-1, 3)
     nc = off.numel() - 1
     viz = vizmap.to(torch.uint8).contiguous() if vizmap is not None else None
     lin, keep = _linear(red_w, red_b)
+    lift, keep2 = _linear(color_w, color_b) if color_w is not None else (None, None)
     tokens = torch.empty((V, nc, lin.out_f), dtype=torch.float32, device=v.device)
     ws = _ws(lib.th_paint_group_nhwc_workspace_bytes(V, v.shape[0], Cc, lin.out_f), v.device)
     _check(lib.th_paint_group_nhwc(ctx(v.device), _p(map_nhwc), V, H, W, Cc, _p(v), v.shape[0], _p(cams), _p(scale_xy),
-                                   _p(viz), C.byref(lin), _p(off), _p(mem), nc, _p(tokens), _p(ws), ws.numel(),
-                                   _stream()))
+                                   _p(viz), C.byref(lin), C.byref(lift) if lift is not None else None, _p(off), _p(mem),
+                                   nc, _p(tokens), _p(ws), ws.numel(), _stream()))
     return tokens
 
 
@@ -388,14 +397,16 @@ def nchw_to_nhwc(m):
     return out
 
 
-def pixel_gather(map_nhwc, pts_world, cams, scale_xy, sel=None):
+def pixel_gather(map_nhwc, pts_world, cams, scale_xy, sel=None, row_floats=None):
+    """-> [P, V, row_floats] (default: the map's channel count; wider rows are zero padded)."""
     lib = load_library()
     V, H, W, Cc = map_nhwc.shape
     p = _f32(pts_world).reshape(-1, 3)
     P = p.shape[0] if sel is None else sel.numel()
-    out = torch.empty((P, V, Cc), dtype=torch.float32, device=p.device)
+    ldo = Cc if row_floats is None else int(row_floats)
+    out = torch.empty((P, V, ldo), dtype=torch.float32, device=p.device)
     _check(lib.th_pixel_gather(ctx(p.device), _p(map_nhwc), V, Cc, H, W, _p(p), _p(sel), P, _p(cams), _p(scale_xy),
-                               _p(out), _stream()))
+                               _p(out), ldo, _stream()))
     return out
 
 
@@ -448,9 +459,9 @@ class Frame:
         self.map = pixel_map_nhwc
         self.tokens, self.centres, self.rot = _f32(tokens), _f32(centres).reshape(-1, 3), _f32(rot).reshape(-1, 9)
         V, H, W, Cc = pixel_map_nhwc.shape
-        assert Cc == 384
+        assert Cc in (384, 260), "pixel map must be the full (384) or the compact (260) channels-last map"
         self.c = ThFrame(_p(self.verts), self.verts.shape[0], _p(self.Rh), _p(self.Th), _p(self.cams), _p(self.scale),
-                         _p(self.map), V, H, W, _p(self.tokens), _p(self.centres), _p(self.rot),
+                         _p(self.map), V, H, W, Cc, _p(self.tokens), _p(self.centres), _p(self.rot),
                          self.tokens.shape[1], hull_thresh, small_frame_rays)
 
 

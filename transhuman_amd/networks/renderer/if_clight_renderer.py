@@ -85,7 +85,7 @@ class Renderer:
         return self._dev[key]
 
     # ---- per-frame constants ---------------------------------------------------------
-    def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True):
+    def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True):
         """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
 
         fused_encoder_tail=True (default): the ResNet stem runs as stock torch ops, its tail
@@ -93,7 +93,12 @@ class Renderer:
         384-channel map channels-last, and holder_feat_map is never materialised -- the 384->192
         reduction_layer is applied to the 3 x 6890 sampled vertex rows instead (it commutes with the
         bilinear sampling).  False: the reference's op order through ``net.encoder(images)``.
-        Both give the same tokens to fp32 rounding (tests/test_gpu_parity.py)."""
+        compact_map=True (default, only with the fused tail): the last 128 map channels are
+        upsample_color(img) = Wc rgb + bc, a linear lift of 3 numbers, so the map keeps r,g,b instead
+        ([V,H,W,260]) and the lift is folded into the four layers that read those channels (alpha_res_0,
+        rgb_res_0, rgb_res_1, reduction_layer: W' = [W_lat | W_col Wc], b' = b + W_col bc) -- a third less
+        map/gather/staging traffic and 12 % fewer MLP MACs, same function.
+        All forms give the same tokens / pixels to fp32 rounding (tests/test_gpu_parity.py)."""
         cfg = get_cfg()
         assert cfg.time_steps == 1                                                  # :412
         t = 0
@@ -110,11 +115,15 @@ class Renderer:
             H, W = images.shape[2:]
             V = images.shape[0]
             lat = enc.trunk(images)
-            map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2], enc.upsample_color.weight,
-                                                enc.upsample_color.bias)
+            cw, cb = enc.upsample_color.weight, enc.upsample_color.bias
+            if compact_map:
+                map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2])
+            else:
+                map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2], cw, cb)
             scale = hip.feat_scale(enc.feat_scale(H, W), image_shape, dev)
             grouped = hip.paint_group_nhwc(map_nhwc, batch["input_smpl_vertice"][t][0], cams, scale, viz,
-                                           enc.reduction_layer.weight, enc.reduction_layer.bias, off, mem)
+                                           enc.reduction_layer.weight, enc.reduction_layer.bias, off, mem,
+                                           color_w=cw if compact_map else None, color_b=cb if compact_map else None)
             pix_scale = scale
         else:
             holder_map, holder_scale, pixel_map, pixel_scale = enc(images)          # :399
