@@ -178,7 +178,8 @@ def main():
     renderer = Renderer(net, vertex_can=can, pc2voxel_ind=assign)
     batch = synth.batch_to(batch_cpu, dev)
     R = batch["ray_o"].shape[1]
-    my_idx = shard_ray_indices(H, W, world, rank, tile=8).to(dev)
+    tile_major = os.environ.get("TH_RAY_ORDER", "tile") == "tile"
+    my_idx = shard_ray_indices(H, W, world, rank, tile=8, tile_major=tile_major).to(dev)
     shard = dict(batch)
     for k in ("ray_o", "ray_d", "near", "far"):
         shard[k] = batch[k][:, my_idx].contiguous()
@@ -201,7 +202,11 @@ def main():
                 frame.c.small_frame_rays = 1 << 30
                 out = renderer.render_fast(shard, frame=frame)
         local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
-        img = gather_image(local, my_idx, R, world) if dist_on else local
+        if dist_on:
+            img = gather_image(local, my_idx, R, world)
+        else:
+            img = torch.zeros((R, 5), dtype=local.dtype, device=dev)
+            img[my_idx] = local
         return img, dict(renderer.last_stats)
 
     for _ in range(args.warmup):

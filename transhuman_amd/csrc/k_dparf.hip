@@ -14,7 +14,8 @@
 //   one ordered scan; softmax weights and the 7 rotated offsets go to LDS.
 //  Phase 2 (wave per sample, 32 samples per wave): lanes 0..47 fetch a token row as one float4 each
 //   (768 B coalesced, L2-resident table), lanes 0..62 evaluate one PE channel each (7 accurate sinf).
-// Output rows [sample][view][256] (255 + zero pad) feed fc_0.
+// Output rows [sample][view][256] (255 + zero pad) feed fc_0; SPLIT = true writes them as 256 fp16 hi halves +
+// 256 fp16 lo halves (the fused MLP kernel's LDS-DMA operand format), same 1 KiB per row.
 // Bound: L2 gather of 7*V*768 B per sample; HBM write 3 KB per sample.
 #include "th_internal.h"
 
@@ -41,6 +42,13 @@ __device__ __forceinline__ void dp_insert(float (&bd)[DP_K], int (&bi)[DP_K], fl
     }
 }
 
+__device__ __forceinline__ void dp_split(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
+typedef _Float16 dp_h4 __attribute__((ext_vector_type(4)));
+
+template <bool SPLIT>
 __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restrict__ pts_smpl, ThPointSrc ps,
                                                            const float* __restrict__ Rh, const float* __restrict__ Th,
                                                            const int32_t* __restrict__ sel, int P,
@@ -163,16 +171,35 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                     acc.x = acc.x + w[k] * r[k].x; acc.y = acc.y + w[k] * r[k].y;
                     acc.z = acc.z + w[k] * r[k].z; acc.w = acc.w + w[k] * r[k].w;
                 }
-                *reinterpret_cast<float4*>(o + 4 * lane) = acc;
+                if (!SPLIT) *reinterpret_cast<float4*>(o + 4 * lane) = acc;
+                else {
+                    _Float16* oh = reinterpret_cast<_Float16*>(o);       // hi [0,256) | lo [256,512)
+                    dp_h4 a, b;
+                    _Float16 x, y;
+                    dp_split(acc.x, x, y); a[0] = x; b[0] = y;
+                    dp_split(acc.y, x, y); a[1] = x; b[1] = y;
+                    dp_split(acc.z, x, y); a[2] = x; b[2] = y;
+                    dp_split(acc.w, x, y); a[3] = x; b[3] = y;
+                    *reinterpret_cast<dp_h4*>(oh + 4 * lane) = a;
+                    *reinterpret_cast<dp_h4*>(oh + 256 + 4 * lane) = b;
+                }
             }
-            o[192 + lane] = (lane < 63) ? pe : 0.f;
+            const float pv = (lane < 63) ? pe : 0.f;
+            if (!SPLIT) o[192 + lane] = pv;
+            else {
+                _Float16* oh = reinterpret_cast<_Float16*>(o);
+                _Float16 x, y;
+                dp_split(pv, x, y);
+                oh[192 + lane] = x;
+                oh[256 + 192 + lane] = y;
+            }
         }
     }
 }
 
 int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh, const float* Th,
                     const int32_t* sel, int P, const float* centres, const float* rot, const float* tokens, int V,
-                    int nc, float alpha, float* out, hipStream_t s) {
+                    int nc, float alpha, float* out, int fmt, hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(nc >= DP_K, "need at least 7 token centres");
     ThPointSrc src;
@@ -181,11 +208,16 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
     TH_REQUIRE(lds <= 160 * 1024, "too many token centres for LDS staging");
     static bool attr_set = false;
     if (!attr_set) {
-        TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    hipLaunchKernelGGL(dparf_kernel, dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh, Th, sel,
-                       P, centres, rot, tokens, V, nc, alpha, out);
+    if (fmt == TH_ROWS_SPLIT)
+        hipLaunchKernelGGL(dparf_kernel<true>, dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
+                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out);
+    else
+        hipLaunchKernelGGL(dparf_kernel<false>, dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
+                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out);
     TH_LAUNCH_CHECK();
     return 0;
 }

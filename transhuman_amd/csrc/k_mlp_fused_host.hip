@@ -216,7 +216,7 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
     return 0;
 }
 
-int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* h, const float* f,
+int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const void* h, const void* f,
                          int f_ld, const float* vd, int rgb_all, float* raw_c, hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(V >= 1 && V <= 3, "fused MLP supports 1..3 reference views");
@@ -226,7 +226,7 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     FusedParams p = base;
     if (cf) { p.ar0 = base.ar0c; p.rr0 = base.rr0c; p.rr1 = base.rr1c; }
     p.alpha_w = heads.alpha_w; p.alpha_b = heads.alpha_b; p.rgb_w = heads.rgb_w; p.rgb_b = heads.rgb_b;
-    p.h = h; p.f = f; p.vd = vd; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
+    p.h = (const _Float16*)h; p.f = (const _Float16*)f; p.vd = vd; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
     static bool attr = false;
     if (!attr) {
 #define FM_ATTR(V_, F_)                                                                                       \
@@ -244,7 +244,7 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
         FusedLayer* ls[] = {&p.fc_0, &p.kv1, &p.ar0, &p.kv0, &p.fc_2, &p.fc_3, &p.feat, &p.rr0, &p.vfc, &p.rr1, &p.fc_4};
         for (auto* l : ls) l->w = p.fc_1.w;
     }
-    // developer aid: TH_FUSED_DBG=1 -> cycle stamps of the middle tile after every barrier (first big launch only)
+    // developer aid: TH_FUSED_DBG=1 -> average cycles between barriers over every 16th tile (first big launch only)
     static int dbg_state = getenv("TH_FUSED_DBG") ? 1 : 0;
     static long long* dbg_dev = nullptr;
     p.dbg = nullptr;
@@ -271,9 +271,13 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
         long long st[64];
         TH_HIP(hipStreamSynchronize(s));
         TH_HIP(hipMemcpy(st, dbg_dev, sizeof(st), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[TH_FUSED_DBG] tile %d of %d, cycles between barriers:", grid.x / 2, grid.x);
-        for (int i = 1; i < 64 && st[i] != 0; ++i) fprintf(stderr, " %lld", st[i] - st[i - 1]);
-        fprintf(stderr, "\n");
+        fprintf(stderr, "[TH_FUSED_DBG] %lld tiles sampled of %d, average cycles between barriers:", st[0], grid.x);
+        long long tot = 0;
+        for (int i = 1; i < 64 && st[i] != 0; ++i) {
+            fprintf(stderr, " %lld", st[i] / (st[0] > 0 ? st[0] : 1));
+            tot += st[i] / (st[0] > 0 ? st[0] : 1);
+        }
+        fprintf(stderr, "  | total %lld\n", tot);
         dbg_state = 2;
     }
     return 0;

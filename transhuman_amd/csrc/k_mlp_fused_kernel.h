@@ -1,13 +1,17 @@
-// Device code of the fused per-point MLP (included by k_mlp_fused.hip only).
+// Device code of the fused per-point MLP (included by k_mlp_fused_host.hip only).
 //
 // One workgroup = 256 threads = 4 waves (one per SIMD, up to 512 registers each) shades a tile of
-// 32 samples x V views.  See k_mlp_fused.hip for the arithmetic (fp16 hi/lo split MFMA) and the
+// 32 samples x V views.  See k_mlp_fused_host.hip for the arithmetic (fp16 hi/lo split MFMA) and the
 // data-flow overview.  LDS map (bytes, V = 3):
-//   ABUF  101 376  activation operand of the running GEMM: fp16 hi + lo planes [row = view*32+sample][K],
-//                  row stride 2K+16 B (conflict-free ds_read_b128); aliased by the fp32 key buffer kp
+//   ABUF  107 520  activation operand of the running GEMM: fp16 hi + lo planes [row = view*32+sample][K],
+//                  row stride 2K+16 B (an odd number of 16-B slots: conflict-free ds_read_b128); aliased by
+//                  the fp32 key buffer kp
 //   MBUF   50 688  ks (fp32 keys of the token branch, parked here so they do not occupy accumulators
 //                  during the pixel branch) -> later the view-mean operand of fc_3 -> later viewdir + fc_4 operand
-//   MISC    7 328  softmax probabilities, sigma, view directions, cross-wave partial sums
+//   MISC    3 744  softmax probabilities, sigma, cross-wave partial sums
+// Inputs h and f arrive from the producer kernels (k_dparf / k_pixfeat) already split into fp16 hi|lo
+// halves per row, so an operand is staged by global_load_lds_dwordx4 (LDS-DMA): no staging registers,
+// no conversion pass, no ds_write.
 #pragma once
 #include <hip/hip_fp16.h>
 
@@ -19,24 +23,30 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 #define FM_PTS 32
-#define STR256 528   // bytes per LDS row, K = 256 halves (+16)
+#define STR272 560   // bytes per LDS row = 2K + 16, K = 272 halves (compact pixel-feature rows)
+#define STR256 528   // K = 256
 #define STR192 400   // K = 192
 #define STR128 272   // K = 128
 #define STRVD 80     // K = 32 (view-direction block of view_fc)
 #define KSTR 132     // floats per row of the fp32 key buffers
 
-#define ABUF_BYTES (2 * 96 * STR256)
+#define ABUF_BYTES (2 * 96 * STR272)
 #define MBUF_BYTES (96 * KSTR * 4)
-#define MISC_FLOATS (9 * 32 + 128 + 32 * 28 + 4 * 32 * 4 + 8)
+#define MISC_FLOATS (9 * 32 + 128 + 4 * 32 * 4 + 8)
 #define FUSED_LDS_BYTES (ABUF_BYTES + MBUF_BYTES + MISC_FLOATS * 4)
 #define MBUF_VD_OFF 0
 #define MBUF_FC4_OFF 8192
 
-// barrier + optional cycle stamp (developer aid: TH_FUSED_DBG=1 prints per-phase cycles of one tile)
+// barrier + optional cycle accounting (developer aid: TH_FUSED_DBG=1 prints the average cycles between
+// consecutive barriers over every 16th tile of one launch)
 #define FM_SYNC()                                                                                        \
     do {                                                                                                 \
         __syncthreads();                                                                                 \
-        if (P.dbg != nullptr && tid == 0 && blockIdx.x == gridDim.x / 2) P.dbg[dbg_i++] = clock64();     \
+        if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {                                    \
+            long long now_ = clock64();                                                                  \
+            atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + dbg_i++), (unsigned long long)(now_ - dbg_t)); \
+            dbg_t = now_;                                                                                \
+        }                                                                                                \
     } while (0)
 
 __device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
@@ -44,55 +54,38 @@ __device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 
-// ---- global -> registers -> LDS staging, split so the loads fly during the previous GEMM -----------
-template <int V, int KC>
-struct StageRegs {
-    static constexpr int C4 = KC / 4;
-    static constexpr int TOTAL = 32 * V * C4;
-    static constexpr int ITERS = (TOTAL + 255) / 256;
-    f32x4v v[ITERS];
-};
+// ---- global -> LDS staging by LDS-DMA ------------------------------------------------------------------
+// Source rows (one per (sample, view)) hold KROW hi halves followed by KROW lo halves.  Columns
+// [coff, coff + KC) of both planes are copied into the LDS images hi/lo (row = view*32 + sample, stride STR
+// bytes).  global_load_lds_dwordx4 writes LDS at a wave-uniform base + lane*16, reading a per-lane global
+// address: every wave fills 1 KiB slices of the plane image and each lane derives the (row, column) its
+// 16-byte slot belongs to; slots in the 16-byte row pad fetch column 0 (never read back).  Rows past the
+// end of a ragged last tile re-read the last valid sample (their results are never stored).
+typedef __attribute__((address_space(1))) const void* fm_gptr;
+typedef __attribute__((address_space(3))) void* fm_lptr;
 
-// rows: r -> sample (r & 31), view (r >> 5); source row = (pbase + sample) * V + view
-template <int V, int KC>
-__device__ __forceinline__ void stage_issue(StageRegs<V, KC>& r, const float* __restrict__ src, int ld, int coff,
-                                            int pbase, int npts, int tid) {
-    constexpr int C4 = StageRegs<V, KC>::C4;
-#pragma unroll
-    for (int i = 0; i < StageRegs<V, KC>::ITERS; ++i) {
-        int idx = tid + 256 * i;
-        int row = idx / C4, c4 = idx % C4;
-        int p = row & 31, vw = row >> 5;
-        r.v[i] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-        if (idx < StageRegs<V, KC>::TOTAL && p < npts)
-#ifndef FM_NT_STAGE_LOADS
-            r.v[i] = *reinterpret_cast<const f32x4v*>(src + ((long long)(pbase + p) * V + vw) * ld + coff + 4 * c4);
-#else
-            r.v[i] = __builtin_nontemporal_load(
-                reinterpret_cast<const f32x4v*>(src + ((long long)(pbase + p) * V + vw) * ld + coff + 4 * c4));
-#endif
-    }
-    __builtin_amdgcn_sched_barrier(0);   // keep the loads here (in flight under the following GEMM)
-}
-
-template <int V, int KC, int STR>
-__device__ __forceinline__ void stage_commit(const StageRegs<V, KC>& r, char* __restrict__ hi, char* __restrict__ lo,
-                                             int tid) {
-    constexpr int C4 = StageRegs<V, KC>::C4;
-#pragma unroll
-    for (int i = 0; i < StageRegs<V, KC>::ITERS; ++i) {
-        int idx = tid + 256 * i;
-        if (idx < StageRegs<V, KC>::TOTAL) {
-            int row = idx / C4, c4 = idx % C4;
-            h4 a, b;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                _Float16 x, y;
-                split_h(r.v[i][q], x, y);
-                a[q] = x; b[q] = y;
-            }
-            *reinterpret_cast<h4*>(hi + row * STR + 8 * c4) = a;
-            *reinterpret_cast<h4*>(lo + row * STR + 8 * c4) = b;
+template <int V, int KROW, int KC, int STR>
+__device__ __forceinline__ void stage_glds(const _Float16* __restrict__ src, int coff, int pbase, int npts,
+                                           char* __restrict__ hi, char* __restrict__ lo, int wave, int lane) {
+    constexpr int PLANE = 32 * V * STR;
+    constexpr int NCH = (PLANE + 1023) / 1024;
+    static_assert(2 * KC + 16 == STR || 2 * KC + 16 < STR, "row stride too small");
+#pragma unroll 1
+    for (int ch = wave; ch < 2 * NCH; ch += 4) {
+        const int plane = ch >= NCH ? 1 : 0;
+        const int c = ch - plane * NCH;
+        const int o = c * 1024 + lane * 16;
+        if (o < PLANE) {
+            const int row = o / STR;
+            int col = o - row * STR;                 // bytes into the LDS row
+            if (col >= 2 * KC) col = 0;
+            int p = row & 31;
+            const int vw = row >> 5;
+            if (p >= npts) p = npts - 1;
+            const char* g = reinterpret_cast<const char*>(src) + ((long long)(pbase + p) * V + vw) * (4 * KROW) +
+                            plane * (2 * KROW) + 2 * coff + col;
+            char* dst = (plane ? lo : hi) + c * 1024;
+            __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)dst, 16, 0, 0);
         }
     }
 }
@@ -142,26 +135,15 @@ __device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb,
 
 #define FM_SB() __builtin_amdgcn_sched_barrier(0)
 
-// staging policy: the loads of an operand are issued right before they are committed to LDS.  (Issuing them
-// one GEMM earlier was measured slower: vmcnt retires in order, so the GEMM's first weight wait then also
-// waits for the whole staging burst.)
-template <int V, int KC, int STR>
-__device__ __forceinline__ void stage_now(const float* __restrict__ src, int ld, int coff, int pbase, int npts,
-                                          char* __restrict__ hi, char* __restrict__ lo, int tid) {
-    StageRegs<V, KC> r;
-    stage_issue<V, KC>(r, src, ld, coff, pbase, npts, tid);
-    stage_commit<V, KC, STR>(r, hi, lo, tid);
-}
-
-// Layout of the pixel-feature rows f and how their K range is split over two ABUF fillings:
-//   FM = 0  full rows, 384 floats (pixel_feat_map as the reference builds it):        192 + 192, 12 + 12 k-blocks
-//   FM = 1  compact rows, 272 floats = 256 latent | r g b | 0 (colour lift folded into the weights):
-//                                                                                      128 + 144,  8 +  9 k-blocks
-// LDS row strides must be == 16 mod 128 B (conflict-free ds_read_b128): 272 B for K = 128; K = 144 uses the
-// 400 B stride of K = 192.
+// Layout of the pixel-feature rows f and how their K range maps onto ABUF fillings:
+//   FM = 0  full rows, K = 384 (pixel_feat_map as the reference builds it): two fillings 192 + 192, 12 + 12 k-blocks
+//   FM = 1  compact rows, K = 272 = 256 latent | r g b | 0 (colour lift folded into the weights): ONE filling,
+//           17 k-blocks (the second "filling" is empty)
+// LDS row strides are 2K + 16 B, i.e. an odd number of 16-byte slots: the 16 lanes of a ds_read_b128 lane
+// group (16 different rows, same column) then hit 16 different slots of the 256-byte bank row.
 template <int FM> struct FLay;
 template <> struct FLay<0> { static constexpr int LD = 384, KA = 192, KB2 = 192, SA = STR192, SB = STR192, NA = 12, NB = 12; };
-template <> struct FLay<1> { static constexpr int LD = 272, KA = 128, KB2 = 144, SA = STR128, SB = STR192, NA = 8, NB = 9; };
+template <> struct FLay<1> { static constexpr int LD = 272, KA = 272, KB2 = 0, SA = STR272, SB = STR272, NA = 17, NB = 0; };
 
 // acc[ct][rt] += W_tile(ct) * A_rows(rt)^T over KB k-blocks of 16.
 //  * weight fragments stream from the (L2-resident) packed image through a ring of D register sets: block
@@ -169,7 +151,13 @@ template <> struct FLay<1> { static constexpr int LD = 272, KA = 128, KB2 = 144,
 //    of latency tolerance, no register copies (loop unrolled by D, D even);
 //  * activation fragments (LDS, ds_read_b128) ping-pong between two register sets: block k+1 is read
 //    while block k multiplies, so no burst starts with an exposed LDS round trip.
-template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = 4, bool XPP = true>
+#ifndef FM_RING_D
+#define FM_RING_D 4       // weight ring depth of the 3-column-tile (key/value) phases: register-tight
+#endif
+#ifndef FM_RING_D2
+#define FM_RING_D2 4      // ... of the 1- and 2-column-tile phases
+#endif
+template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = (CT >= 3 ? FM_RING_D : FM_RING_D2), bool XPP = true>
 __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const char* __restrict__ alo,
                                            const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
     static_assert((D & 1) == 0, "ring depth must be even (activation ping-pong parity)");
@@ -311,8 +299,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     float* misc = reinterpret_cast<float*>(lds + ABUF_BYTES + MBUF_BYTES);
     float* probs = misc;                  // [V*V][32]
     float* sig = misc + 9 * 32;           // [32] (+ padding)
-    float* vds = sig + 128;               // [32][28]
-    float* part = vds + 32 * 28;          // [4 waves][32][4]
+    float* part = sig + 128;              // [4 waves][32][4]
     int* flag = reinterpret_cast<int*>(part + 4 * 32 * 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -329,23 +316,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         long long wait = (long long)(blockIdx.x & 15) * P.skew_cycles;
         while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
     }
-    int dbg_i = 0;
-    if (P.dbg != nullptr && tid == 0 && blockIdx.x == gridDim.x / 2) P.dbg[dbg_i++] = clock64();
+    int dbg_i = 1;                      // dbg[0] counts sampled tiles, dbg[i] accumulates the cycles of interval i
+    long long dbg_t = 0;
+    if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg), 1ull);
+        dbg_t = clock64();
+    }
 
     char* a256_lo = abuf + ROWS * STR256;
     char* fa_lo = abuf + ROWS * FL::SA;      // lo planes of the two f fillings
     char* fb_lo = abuf + ROWS * FL::SB;
 
     // ================= token branch: s = relu(fc_0 h); ks|vs = kv1(s) =================
-    {
-        StageRegs<V, 256> rh;
-        stage_issue<V, 256>(rh, P.h, 256, 0, pbase, npts, tid);
-        for (int i = tid; i < 32 * 28; i += 256) {
-            int p = i / 28, c = i % 28;
-            vds[i] = (p < npts && c < 27) ? P.vd[(long long)(pbase + p) * 27 + c] : 0.f;
-        }
-        stage_commit<V, 256, STR256>(rh, abuf, a256_lo, tid);
-    }
+    stage_glds<V, 256, 256, STR256>(P.h, 0, pbase, npts, abuf, a256_lo, wave, lane);
     FM_SYNC();
     f32x16 acc2[2][V];
     zero_acc<2, V>(acc2);
@@ -380,14 +363,16 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
     zero_acc<2, V>(acc2);
-    stage_now<V, FL::KA, FL::SA>(P.f, FL::LD, 0, pbase, npts, abuf, fa_lo, tid);
+    stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
     FM_SYNC();
     gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2);
     FM_SYNC();
-    stage_now<V, FL::KB2, FL::SB>(P.f, FL::LD, FL::KA, pbase, npts, abuf, fb_lo, tid);
-    FM_SYNC();
-    gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.ar0, wave, 2, FL::NA), FL::NB, lane, acc2);
-    FM_SYNC();
+    if constexpr (FL::NB > 0) {
+        stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
+        FM_SYNC();
+        gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.ar0, wave, 2, FL::NA), FL::NB, lane, acc2);
+        FM_SYNC();
+    }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         finish_tile<V>(acc2[c], P.ar0.bias, wave * 64 + c * 32, P.ar0.inv_scale, true, lane);
@@ -531,16 +516,25 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         zero_acc<1, V>(r1);
         gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.feat, wave, 2, 0), P.feat.KB, lane, acc2);
         FM_SYNC();
-        stage_now<V, FL::KA, FL::SA>(P.f, FL::LD, 0, pbase, npts, abuf, fa_lo, tid);
+        // view directions of the tile (27 of 32 columns used), fetched now, split into MBUF after the f passes
+        float vdv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int i = tid + 256 * q, row = i >> 5, c = i & 31;
+            vdv[q] = (c < 27 && row < npts) ? P.vd[(long long)(pbase + row) * 27 + c] : 0.f;
+        }
+        stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
         FM_SYNC();
         gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.rr0, wave, 2, 0), FL::NA, lane, acc2);
         gemm_phase<V, 1, FL::SA, 32 * FL::SA, 6>(abuf, fa_lo, wslice(P.rr1, wave, 1, 0), FL::NA, lane, r1);
         FM_SYNC();
-        stage_now<V, FL::KB2, FL::SB>(P.f, FL::LD, FL::KA, pbase, npts, abuf, fb_lo, tid);
-        FM_SYNC();
-        gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.rr0, wave, 2, FL::NA), FL::NB, lane, acc2);
-        gemm_phase<V, 1, FL::SB, 32 * FL::SB, 6>(abuf, fb_lo, wslice(P.rr1, wave, 1, FL::NA), FL::NB, lane, r1);
-        FM_SYNC();
+        if constexpr (FL::NB > 0) {
+            stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
+            FM_SYNC();
+            gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.rr0, wave, 2, FL::NA), FL::NB, lane, acc2);
+            gemm_phase<V, 1, FL::SB, 32 * FL::SB, 6>(abuf, fb_lo, wslice(P.rr1, wave, 1, FL::NA), FL::NB, lane, r1);
+            FM_SYNC();
+        }
         // feat (+ both biases) -> ABUF [ROWS][256]; the 27 view-direction inputs of view_fc -> MBUF [32][32]
         char* vd_hi = mbuf + MBUF_VD_OFF;
         char* vd_lo = vd_hi + 32 * STRVD;
@@ -560,9 +554,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             for (int r = 0; r < V; ++r)
                 store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
         }
-        for (int i = tid; i < 32 * 32; i += 256) {
-            int row = i >> 5, c = i & 31;
-            float x = (c < 27) ? vds[row * 28 + c] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int i = tid + 256 * q, row = i >> 5, c = i & 31;
+            float x = vdv[q];
             _Float16 a, b;
             split_h(x, a, b);
             *reinterpret_cast<_Float16*>(vd_hi + row * STRVD + 2 * c) = a;

@@ -335,7 +335,7 @@ int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, i
     float* fold = ar.take<float>((size_t)out_f * 260 + out_f);
     TH_REQUIRE(fold != nullptr, "workspace carve failed");
     // sample the channels-last map at the projected vertices, then the 1x1 conv on those rows only
-    TH_TRY(th_pixgather_launch(map_nhwc, V, C, H, W, verts, nullptr, nullptr, nv, cams, scale, g, C, s));
+    TH_TRY(th_pixgather_launch(map_nhwc, V, C, H, W, verts, nullptr, nullptr, nv, cams, scale, g, C, TH_ROWS_F32, s));
     ThPacked P;
     th_linear red = *reduction;
     if (compact) {
@@ -360,7 +360,7 @@ int th_vit_forward(th_ctx* c, const float* x, const float* pe, int V, int N, flo
 int th_dparf_encode(th_ctx* c, const float* pts, const int32_t* sel, int P, const float* centres, const float* rot,
                     const float* tokens, int V, int nc, float* out, th_stream stream) {
     TH_REQUIRE(c && pts && centres && rot && tokens && out, "null argument");
-    return th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, P, centres, rot, tokens, V, nc, 0.5f, out,
+    return th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, P, centres, rot, tokens, V, nc, 0.5f, out, TH_ROWS_F32,
                            (hipStream_t)stream);
 }
 
@@ -372,7 +372,8 @@ int th_nchw_to_nhwc(th_ctx* c, const float* src, int V, int C, int H, int W, flo
 int th_pixel_gather(th_ctx* c, const float* map, int V, int C, int H, int W, const float* pts, const int32_t* sel,
                     int P, const float* cams, const float* scale, float* out, int ldo, th_stream stream) {
     TH_REQUIRE(c && map && pts && cams && scale && out, "null argument");
-    return th_pixgather_launch(map, V, C, H, W, pts, nullptr, sel, P, cams, scale, out, ldo, (hipStream_t)stream);
+    return th_pixgather_launch(map, V, C, H, W, pts, nullptr, sel, P, cams, scale, out, ldo, TH_ROWS_F32,
+                               (hipStream_t)stream);
 }
 
 int th_composite(th_ctx* c, const float* raw, const float* z, const th_points* rays, int white, float* rgb,
@@ -433,9 +434,13 @@ static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
 
 // K6 dispatch: fused fp16x3-split kernel (default, V <= 3) or the layer-by-layer fp32 MFMA form
 // f_ld: floats per pixel-feature row of cb.f (384 full / 272 compact)
+// which K6 form runs for V views, and therefore which row format the producers must emit into cb.h / cb.f
+static bool mlp_is_fused(const th_ctx* c, int V) { return c->mlp_mode == 1 && c->fused_ready && V <= 3; }
+static int mlp_row_format(const th_ctx* c, int V) { return mlp_is_fused(c, V) ? TH_ROWS_SPLIT : TH_ROWS_F32; }
+
 static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, int rgb_all, hipStream_t s) {
     TH_REQUIRE(c->mlp.ready, "MLP weights not set (th_set_mlp_weights)");
-    if (c->mlp_mode == 1 && c->fused_ready && V <= 3)
+    if (mlp_is_fused(c, V))
         return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.f, f_ld, cb.vdc, rgb_all, cb.raw_c, s);
     return th_mlp_forward(c->mlp, V, m, cb.h, cb.f, f_ld, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s);
 }
@@ -473,12 +478,13 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
         int m = (n - o) < CH ? (n - o) : CH;
         const int32_t* sel = idx ? idx + o : nullptr;
         const float* pts = idx ? pts_smpl : pts_smpl + 3LL * o;
-        TH_TRY(th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, m, centres, rot, tokens, V, nc, 0.5f, cb.h, s));
+        const int fmt = mlp_row_format(c, V);
+        TH_TRY(th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, m, centres, rot, tokens, V, nc, 0.5f, cb.h, fmt, s));
         if (idx) {
-            TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, s));
+            TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, fmt, s));
             TH_TRY(th_gather_rows_launch(viewdir, 27, sel, 1, m, cb.vdc, s));
         } else {
-            TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, s));
+            TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, fmt, s));
             TH_TRY(th_gather_rows_launch(viewdir + 27LL * o, 27, nullptr, 1, m, cb.vdc, s));
         }
         TH_TRY(mlp_dispatch(c, V, m, cb, 384, idx ? 0 : 1, s));
@@ -514,6 +520,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     const int R = ps.R, S = ps.S, V = f->V;
     const bool compact = f->map_channels == TH_MAP_COMPACT;
     const int f_ld = compact ? 272 : 384;
+    const int fmt = mlp_row_format(c, V);
     TH_REQUIRE(!compact || c->mlp.compact_ready,
                "compact pixel map needs th_mlp_weights.upsample_color (colour-folded layers) to be uploaded");
     uint8_t* mask = ar.take<uint8_t>((size_t)P);
@@ -561,12 +568,12 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         {
             ProfScope ps1(pf, TH_PROF_DPARF, s);
             TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, sel, m, f->centres, f->rot, f->tokens, V,
-                                   f->n_clusters, 0.5f, cb.h, s));
+                                   f->n_clusters, 0.5f, cb.h, fmt, s));
         }
         {
             ProfScope ps2(pf, TH_PROF_GATHER, s);
             TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, sel, m, f->cams,
-                                       f->scale_xy, cb.f, f_ld, s));
+                                       f->scale_xy, cb.f, f_ld, fmt, s));
             if (ray_mode) TH_TRY(th_gather_rows_launch(vd_all, 27, sel, S, m, cb.vdc, s));
         }
         {

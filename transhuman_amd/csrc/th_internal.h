@@ -190,8 +190,9 @@ struct FusedParams {
     FusedLayer ar0c, rr0c, rr1c;   // colour-folded (K = 272) forms; the launcher copies them over ar0/rr0/rr1
     bool compact_ready;
     const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
-    const float* h;     // [P][V][256]
-    const float* f;     // [P][V][384] (full) or [P][V][272] (compact: 256 latent | r g b | 0...)
+    // split-f16 rows written by the producers (TH_ROWS_SPLIT): K hi halves then K lo halves per (sample, view)
+    const _Float16* h;  // [P][V][2][256]
+    const _Float16* f;  // [P][V][2][384] (full) or [P][V][2][272] (compact: 256 latent | r g b | 0...)
     const float* vd;    // [P][27]
     float* raw_c;       // [P][4]
     int P;
@@ -202,8 +203,9 @@ struct FusedParams {
 size_t th_fused_pack_bytes();
 // folded: nullptr or the three colour-folded fp32 layers {alpha_res_0, rgb_res_0, rgb_res_1} (in_f 260)
 int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store, FusedParams* out, hipStream_t s);
-int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* h,
-                         const float* f, int f_ld, const float* vd, int rgb_all, float* raw_c, hipStream_t s);
+// h / f: TH_ROWS_SPLIT rows (same byte size as the fp32 rows: 4 * K bytes per (sample, view))
+int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const void* h,
+                         const void* f, int f_ld, const float* vd, int rgb_all, float* raw_c, hipStream_t s);
 
 struct th_ctx {
     void* fused_store = nullptr;
@@ -243,16 +245,21 @@ int th_segmean_rot_launch(const double* blend, const int32_t* off, const int32_t
                           hipStream_t s);
 int th_nchw_to_nhwc_launch(const float* src, int V, int C, int H, int W, float* dst, hipStream_t s);
 
+// Row format of the per-(sample, view) operand rows h / f handed from the producer kernels to the MLP stage:
+//   TH_ROWS_F32    K fp32 values (layer-by-layer fp32 MFMA path, public th_dparf_encode / th_pixel_gather)
+//   TH_ROWS_SPLIT  K fp16 "hi" halves followed by K fp16 "lo" halves, x = hi + lo to 2^-22 (fused kernel: the
+//                  operand is copied to LDS by LDS-DMA with no conversion pass); same 4K bytes per row
+enum { TH_ROWS_F32 = 0, TH_ROWS_SPLIT = 1 };
 // k_dparf.hip
 int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh, const float* Th,
                     const int32_t* sel, int P, const float* centres, const float* rot, const float* tokens,
-                    int V, int nc, float alpha, float* out, hipStream_t s);
+                    int V, int nc, float alpha, float* out, int fmt, hipStream_t s);
 // k_pixfeat.hip
 int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world,
                         const ThPointSrc* ps, const int32_t* sel, int P, const float* cams, const float* scale,
-                        float* out, int ldo, hipStream_t s);
+                        float* out, int ldo, int fmt, hipStream_t s);
 int th_gather_chan_major_launch(const float* pf /*[V,C,Pall]*/, int V, int C, long long Pall, const int32_t* sel,
-                                int P, float* out /*[P,V,C]*/, hipStream_t s);
+                                int P, float* out /*[P,V,C]*/, int fmt, hipStream_t s);
 // k_mlp.hip
 size_t th_mlp_ws(int V, int P);
 // h [P*V,256], f [P*V,f_ld] (f_ld 384: full rows, 272: compact rows + colour-folded layers), vd rows [P,27]

@@ -11,16 +11,23 @@ an xGMI link).  Hull rays are spatially clustered, hence the interleaved
 import torch
 
 
-def shard_ray_indices(H, W, world, rank, tile=8):
+def shard_ray_indices(H, W, world, rank, tile=8, tile_major=False):
     """Indices (into the row-major H*W ray list) of the rays owned by `rank`:
-    pixel tile t (row-major over the tile grid) belongs to rank t % world."""
+    pixel tile t (row-major over the tile grid) belongs to rank t % world.
+    tile_major=False: ascending ray index.  True: tile after tile (row-major inside a tile), so that rays
+    that are consecutive in the shard are 2-D neighbours in the image: their samples project to
+    neighbouring pixels of the reference views and the pixel gather re-uses cache lines in both directions."""
     ty = (H + tile - 1) // tile
     tx = (W + tile - 1) // tile
     y = torch.arange(H)
     x = torch.arange(W)
     tid = (y[:, None] // tile) * tx + (x[None, :] // tile)
     own = (tid % world) == rank
-    return torch.nonzero(own.reshape(-1), as_tuple=False).reshape(-1)
+    idx = torch.nonzero(own.reshape(-1), as_tuple=False).reshape(-1)
+    if tile_major:
+        key = tid.reshape(-1)[idx] * (H * W) + idx          # (tile, row-major position): unique
+        idx = idx[torch.argsort(key)]
+    return idx
 
 
 def shard_lengths(H, W, world, tile=8):
