@@ -59,17 +59,17 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches):
     of its 2.5 PFLOP/s dense peak; mode 0: fp32 MFMA GEMM launches, peak 157.3 TFLOP/s."""
     if mlp_mode == 1:
         peak = MFMA_F16_PEAK / 3.0
-        kernel = "mlp_fused_kernel<3> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0"
+        kernel = "mlp_fused_kernel<3,1> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0"
     else:
         peak = MFMA_F32_PEAK
         kernel = "per-point MLP stage (gemm_f32_mfma_kernel x14 + glue kernels), rank 0"
-    # HBM bytes per full launch (262144 samples) from the committed PMC passes (profiles/r01_b_pmc_hbm.txt:
-    # 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction applied); algorithmic = 262144 * (3 KB h + 2*4.5 KB f + 124 B)
-    traffic = 4.67e9 if mlp_mode == 1 else None
+    # HBM bytes per full launch (262144 samples) from the committed PMC passes (profiles/r01_d_pmc_hbm.txt:
+    # 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction applied); algorithmic = 262144 * 3 views * (1024 B h + 2 * 1088 B f)
+    traffic = 3.31e9 if mlp_mode == 1 else None
     return {"bound": "mfma", "kernel": kernel, "achieved": achieved / 1e12, "peak": peak / 1e12,
             "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "traffic_note": "HBM bytes per 262144-sample launch, rocprofv3 PMC (profiles/r01_b_pmc_hbm.txt); "
-                            "algorithmic 3.27e9",
+            "traffic_note": "HBM bytes per 262144-sample launch, rocprofv3 PMC (profiles/r01_d_pmc_hbm.txt); "
+                            "algorithmic 2.52e9",
             "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK,
             "algorithmic_flop_per_step": flops_step, "kernel_ms_per_step": stage_ms,
             "launches_per_step": launches}

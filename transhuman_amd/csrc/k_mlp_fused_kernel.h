@@ -85,7 +85,7 @@ __device__ __forceinline__ void stage_glds(const _Float16* __restrict__ src, int
             const char* g = reinterpret_cast<const char*>(src) + ((long long)(pbase + p) * V + vw) * (4 * KROW) +
                             plane * (2 * KROW) + 2 * coff + col;
             char* dst = (plane ? lo : hi) + c * 1024;
-            __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)dst, 16, 0, 0);   // (sc0 / nt / sc1 policy bits: no measurable effect)
         }
     }
 }
@@ -129,7 +129,11 @@ __device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb,
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         w[c][0] = p[(c * 2 + 0) * 64];
+#ifdef FM_EXP_HALFW      // timing experiment only (wrong results): half the weight bytes
+        w[c][1] = w[c][0];
+#else
         w[c][1] = p[(c * 2 + 1) * 64];
+#endif
     }
 }
 
@@ -188,9 +192,13 @@ __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const c
             // shadow of running MFMAs instead of in front of the burst.
             const int kw = (kb + j + D - 1 < KB) ? kb + j + D - 1 : KB - 1;
             const int kx = (kb + j + 1 < KB) ? kb + j + 1 : KB - 1;
+#ifndef FM_EXP_NOW       // timing experiments only (wrong results): drop the in-loop weight / activation loads
             load_wfrag<CT>(wl, kw, w[(j + D - 1) % D]);
+#endif
             if (XPP) {
+#ifndef FM_EXP_NOX
                 load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kx, xh[(j + 1) & 1], xl[(j + 1) & 1]);
+#endif
                 mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
             } else {   // register-tight phases: one activation set, read right before its burst
                 load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, xh[0], xl[0]);
