@@ -6,7 +6,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
-  timeout 200 rocprofv3 --pmc "$@" --kernel-include-regex "mlp_fused" --output-format csv -d $out -o pass_$name -- \
+  timeout 200 rocprofv3 --pmc "$@" --kernel-include-regex "${KREGEX:-mlp_fused}" --output-format csv -d $out -o pass_$name -- \
       python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pass_$name.log 2>&1
 }
 if [ -n "$2" ]; then shift; name=$1; shift; run $name "$@"; ls $out; exit 0; fi

@@ -13,7 +13,7 @@
 //   (staged in LDS, N_c*12 B <= 72 KB); the pair's lists are merged by (distance, index) -- same result as
 //   one ordered scan; softmax weights and the 7 rotated offsets go to LDS.
 //  Phase 2 (wave per sample, 32 samples per wave): lanes 0..47 fetch a token row as one float4 each
-//   (768 B coalesced, L2-resident table), lanes 0..62 evaluate one PE channel each (7 accurate sinf).
+//   (768 B coalesced, L2-resident table), lanes 0..62 evaluate one PE channel each (7 sines, dp_sin).
 // Output rows [sample][view][256] (255 + zero pad) feed fc_0; SPLIT = true writes them as 256 fp16 hi halves +
 // 256 fp16 lo halves (the fused MLP kernel's LDS-DMA operand format), same 1 KiB per row.
 // Bound: L2 gather of 7*V*768 B per sample; HBM write 3 KB per sample.
@@ -47,6 +47,20 @@ __device__ __forceinline__ void dp_split(float x, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(x - (float)hi);
 }
 typedef _Float16 dp_h4 __attribute__((ext_vector_type(4)));
+
+// sin(a) for |a| < 2^12 (the PE arguments are fma(x, pi*2^k, phase), k <= 9, |x| of the order of the body size).
+// Three-constant Cody-Waite reduction by 2*pi (every fma below is exact or rounds once at the 2^-22 level), then
+// the hardware sine of the reduced angle.  Absolute error measured against the fp64 sine of the same fp32
+// argument: < 1e-6 (tests/test_gpu_parity.py::test_dparf_vs_golden holds the channel tolerance 1e-4); about a
+// fifth of the instructions of the full-range library sinf, which made the PE channels the largest VALU block
+// of this kernel.
+__device__ __forceinline__ float dp_sin(float a) {
+    const float k = rintf(a * 0.15915494309189535f);
+    float r = fmaf(-k, 6.28125f, a);                       // 2*pi = 6.28125 + 1.93500518798828125e-3 + 3.0199159819e-7
+    r = fmaf(-k, 1.93500518798828125e-3f, r);
+    r = fmaf(-k, 3.0199159819e-7f, r);
+    return __builtin_amdgcn_sinf(r * 0.15915494309189535f);   // v_sin_f32 takes revolutions
+}
 
 template <bool SPLIT>
 __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restrict__ pts_smpl, ThPointSrc ps,
@@ -153,9 +167,8 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
 #pragma unroll
             for (int k = 0; k < DP_K; ++k) {
                 float xv = n.def[k][axis];
-                float val = (lane < 3) ? xv : sinf(fmaf(xv, freq, phase));
-                float t = w[k] * val;
-                pe = (k == 0) ? t : pe + t;
+                float val = (lane < 3) ? xv : dp_sin(fmaf(xv, freq, phase));
+                pe = (k == 0) ? w[k] * val : fmaf(w[k], val, pe);
             }
         }
         for (int v = 0; v < V; ++v) {
@@ -168,8 +181,8 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                 float4 acc = make_float4(w[0] * r[0].x, w[0] * r[0].y, w[0] * r[0].z, w[0] * r[0].w);
 #pragma unroll
                 for (int k = 1; k < DP_K; ++k) {
-                    acc.x = acc.x + w[k] * r[k].x; acc.y = acc.y + w[k] * r[k].y;
-                    acc.z = acc.z + w[k] * r[k].z; acc.w = acc.w + w[k] * r[k].w;
+                    acc.x = fmaf(w[k], r[k].x, acc.x); acc.y = fmaf(w[k], r[k].y, acc.y);
+                    acc.z = fmaf(w[k], r[k].z, acc.z); acc.w = fmaf(w[k], r[k].w, acc.w);
                 }
                 if (!SPLIT) *reinterpret_cast<float4*>(o + 4 * lane) = acc;
                 else {

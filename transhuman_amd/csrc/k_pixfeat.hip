@@ -7,7 +7,7 @@
 // corner) and masks afterwards (cross_transformer.py:235); here the map is
 // channels-last (th_nchw_to_nhwc, once per frame) so each corner is one
 // contiguous 1.5 KB read, and only hull-valid samples are gathered.
-// One wave per (sample, view) row; lanes span channels (float4 per lane).
+// One wave per 16 consecutive samples of one view; lanes span channels (float4 per lane).
 // The map has C channels per pixel (384 full / 260 compact, see k_encoder.hip); output rows are ldo floats
 // wide (>= C; the tail is zero-filled so the row can feed a K-padded GEMM directly: compact rows are 272).
 // Bound: L2/HBM gather, 4 * 4C B per (sample, view) in, 4*ldo B out.
@@ -21,6 +21,49 @@ __device__ __forceinline__ void pg_split(float x, _Float16& hi, _Float16& lo) {
 
 // SPLIT: rows are written as ldo fp16 hi halves followed by ldo fp16 lo halves (TH_ROWS_SPLIT) instead of ldo floats
 template <bool SPLIT>
+__device__ __forceinline__ void pg_store4(float* __restrict__ orow, int ldo, int c4, float4 r) {
+    if (!SPLIT) reinterpret_cast<float4*>(orow)[c4] = r;
+    else {
+        _Float16* oh = reinterpret_cast<_Float16*>(orow);
+        pg_h4 hv, lv;
+        _Float16 x, y;
+        pg_split(r.x, x, y); hv[0] = x; lv[0] = y;
+        pg_split(r.y, x, y); hv[1] = x; lv[1] = y;
+        pg_split(r.z, x, y); hv[2] = x; lv[2] = y;
+        pg_split(r.w, x, y); hv[3] = x; lv[3] = y;
+#ifndef PG_EXP_NOSTORE      // timing experiments only
+        *reinterpret_cast<pg_h4*>(oh + 4 * c4) = hv;
+#ifndef PG_EXP_NOLO
+        *reinterpret_cast<pg_h4*>(oh + ldo + 4 * c4) = lv;
+#endif
+#else
+        if (hv[0] == (_Float16)123.f && lv[1] == (_Float16)77.f) *reinterpret_cast<pg_h4*>(oh) = hv;
+#endif
+    }
+}
+// bilinear blend of four corner texels (grid_sample's term order; fused multiply-adds: the reference kernel is
+// compiled with FMA contraction too, and the parity bar for this stage is 2e-5)
+__device__ __forceinline__ float4 pg_blend(float4 a, float4 bb, float4 cc, float4 d, float w00, float w01, float w10,
+                                           float w11) {
+    float4 r;
+    r.x = fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(bb.x, w01, a.x * w00)));
+    r.y = fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(bb.y, w01, a.y * w00)));
+    r.z = fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(bb.z, w01, a.z * w00)));
+    r.w = fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(bb.w, w01, a.w * w00)));
+    return r;
+}
+
+// One wave = PG_G consecutive samples of ONE view (their projections are neighbours in that view's map).
+//  phase 1: lane i < PG_G projects sample i and derives its four corner indices + weights -- the per-row setup
+//           (two divisions, floor/clamp, ~140 instructions) runs once per PG_G rows instead of once per row in
+//           every lane (PMC: the row-per-wave form spent 78 % of its time in VALU issue, 325 instructions/row);
+//  phase 2: rows in batches of 4: the corner indices / weights come back as wave-uniform scalars
+//           (v_readlane), so the corner addresses are scalar arithmetic and the 16 corner loads of a batch
+//           (4 KiB each row) are all issued before the first blend.  Lanes span channels (float4 per lane:
+//           64 lanes = the 256 latent channels); columns >= 256 (compact map: r g b 0 + zero tail of the row)
+//           are produced for the 4 rows of a batch at once by lanes 0..15.
+#define PG_G 16
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict__ map, int V, int C, int H, int W,
                                                         const float* __restrict__ pts_world, ThPointSrc ps,
                                                         const int32_t* __restrict__ sel, int P,
@@ -28,55 +71,91 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
                                                         const float* __restrict__ scale, float* __restrict__ out,
                                                         int ldo) {
     const int lane = threadIdx.x & 63;
-    // XCD-aware remap (speed only): workgroup b runs on XCD b % 8, each XCD has its own L2.  Neighbouring
-    // samples of a ray share bilinear corners, so give every XCD a CONTIGUOUS range of rows: logical block
-    // = (b % 8) * ceil(nb / 8) + b / 8 (bijective incl. ragged tails via the bounds check below).
+    // XCD-aware remap (speed only): workgroup b runs on XCD b % 8, each XCD has its own L2: give every XCD a
+    // CONTIGUOUS range of groups: logical block = (b % 8) * ceil(nb / 8) + b / 8 (bijective incl. ragged tails
+    // via the bounds check below).
     const long long nb8 = ((long long)gridDim.x + 7) / 8;
     const long long lb = (long long)(blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
-    long long row = lb * 4 + (threadIdx.x >> 6);                          // (sample, view)
-    if (row >= (long long)P * V) return;
-    int p = (int)(row / V), v = (int)(row % V);
-    long long q = sel ? sel[p] : p;
-    float x, y, z;
-    if (pts_world) { x = pts_world[3 * q]; y = pts_world[3 * q + 1]; z = pts_world[3 * q + 2]; }
-    else th_get_point(ps, q, x, y, z);
-    float uu, vv;
-    th_project(cams + 21 * v, x, y, z, uu, vv);
-    Bilin b = th_bilinear_setup(uu, vv, scale[0], scale[1], H, W);
+    const long long grp = lb * 4 + (threadIdx.x >> 6);                    // (sample group, view)
+    const long long ngrp = (long long)((P + PG_G - 1) / PG_G) * V;
+    if (grp >= ngrp) return;
+    const int v = (int)(grp % V);
+    const int p0 = (int)(grp / V) * PG_G;
+    const int nrow = min(PG_G, P - p0);
     const float* m = map + (long long)v * H * W * C;
-    const float4* p00 = reinterpret_cast<const float4*>(m + (long long)b.i00 * C);
-    const float4* p01 = reinterpret_cast<const float4*>(m + (long long)b.i01 * C);
-    const float4* p10 = reinterpret_cast<const float4*>(m + (long long)b.i10 * C);
-    const float4* p11 = reinterpret_cast<const float4*>(m + (long long)b.i11 * C);
-    float4* o = reinterpret_cast<float4*>(out + row * ldo);
-    _Float16* oh = reinterpret_cast<_Float16*>(out + row * ldo);
-    // 16 B per lane: C = 384 -> 96 float4 per corner row = 1.5 wave-loads (the second one half masked)
-    for (int c4 = lane; c4 < ldo / 4; c4 += 64) {
-        if (c4 >= C / 4) {
-            if (!SPLIT) o[c4] = make_float4(0.f, 0.f, 0.f, 0.f);
-            else {
-                pg_h4 z = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                *reinterpret_cast<pg_h4*>(oh + 4 * c4) = z;
-                *reinterpret_cast<pg_h4*>(oh + ldo + 4 * c4) = z;
+    const int C4 = C / 4, L4 = ldo / 4;
+
+    // ---- phase 1 ----
+    Bilin b;
+    {
+        const int p = p0 + min(lane, nrow - 1);
+        long long s = sel ? sel[p] : p;
+        float x, y, z;
+        if (pts_world) { x = pts_world[3 * s]; y = pts_world[3 * s + 1]; z = pts_world[3 * s + 2]; }
+        else th_get_point(ps, s, x, y, z);
+        float uu, vv;
+        th_project(cams + 21 * v, x, y, z, uu, vv);
+        b = th_bilinear_setup(uu, vv, scale[0], scale[1], H, W);
+    }
+    // ---- phase 2 ----
+    for (int r0 = 0; r0 < nrow; r0 += 4) {
+        float4 q[4][4];
+        float w[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = min(r0 + j, nrow - 1);                           // ragged tail: duplicate loads, no store
+            const int i00 = __builtin_amdgcn_readlane(b.i00, i), i01 = __builtin_amdgcn_readlane(b.i01, i);
+            const int i10 = __builtin_amdgcn_readlane(b.i10, i), i11 = __builtin_amdgcn_readlane(b.i11, i);
+            w[j][0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b.w00), i));
+            w[j][1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b.w01), i));
+            w[j][2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b.w10), i));
+            w[j][3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b.w11), i));
+            if (lane < C4) {
+                q[j][0] = reinterpret_cast<const float4*>(m + (long long)i00 * C)[lane];
+                q[j][1] = reinterpret_cast<const float4*>(m + (long long)i01 * C)[lane];
+                q[j][2] = reinterpret_cast<const float4*>(m + (long long)i10 * C)[lane];
+                q[j][3] = reinterpret_cast<const float4*>(m + (long long)i11 * C)[lane];
             }
-            continue;
         }
-        float4 a = p00[c4], bb = p01[c4], cc = p10[c4], d = p11[c4];
-        float4 r;
-        r.x = a.x * b.w00; r.x = r.x + bb.x * b.w01; r.x = r.x + cc.x * b.w10; r.x = r.x + d.x * b.w11;
-        r.y = a.y * b.w00; r.y = r.y + bb.y * b.w01; r.y = r.y + cc.y * b.w10; r.y = r.y + d.y * b.w11;
-        r.z = a.z * b.w00; r.z = r.z + bb.z * b.w01; r.z = r.z + cc.z * b.w10; r.z = r.z + d.z * b.w11;
-        r.w = a.w * b.w00; r.w = r.w + bb.w * b.w01; r.w = r.w + cc.w * b.w10; r.w = r.w + d.w * b.w11;
-        if (!SPLIT) o[c4] = r;
-        else {
-            pg_h4 hv, lv;
-            _Float16 x, y;
-            pg_split(r.x, x, y); hv[0] = x; lv[0] = y;
-            pg_split(r.y, x, y); hv[1] = x; lv[1] = y;
-            pg_split(r.z, x, y); hv[2] = x; lv[2] = y;
-            pg_split(r.w, x, y); hv[3] = x; lv[3] = y;
-            *reinterpret_cast<pg_h4*>(oh + 4 * c4) = hv;
-            *reinterpret_cast<pg_h4*>(oh + ldo + 4 * c4) = lv;
+        // columns >= 256 of the 4 rows: lane = 4*t + j handles float4 column 64 + t of row r0 + j
+        if (C4 <= 65 && L4 <= 68) {
+            const int j = lane & 3, t = lane >> 2, i = min(r0 + j, nrow - 1);
+            const int c4 = 64 + t;
+            // this lane's row parameters live in lane i (phase 1): fetch them across lanes
+            const int i00 = __shfl(b.i00, i), i01 = __shfl(b.i01, i), i10 = __shfl(b.i10, i), i11 = __shfl(b.i11, i);
+            const float w00 = __shfl(b.w00, i), w01 = __shfl(b.w01, i), w10 = __shfl(b.w10, i), w11 = __shfl(b.w11, i);
+            if (lane < 16 && c4 < L4 && r0 + j < nrow) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c4 < C4)
+                    r = pg_blend(reinterpret_cast<const float4*>(m + (long long)i00 * C)[c4],
+                                 reinterpret_cast<const float4*>(m + (long long)i01 * C)[c4],
+                                 reinterpret_cast<const float4*>(m + (long long)i10 * C)[c4],
+                                 reinterpret_cast<const float4*>(m + (long long)i11 * C)[c4], w00, w01, w10, w11);
+                pg_store4<SPLIT>(out + ((long long)(p0 + r0 + j) * V + v) * ldo, ldo, c4, r);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (r0 + j >= nrow) break;
+            float* orow = out + ((long long)(p0 + r0 + j) * V + v) * ldo;
+            if (lane < C4)
+                pg_store4<SPLIT>(orow, ldo, lane, pg_blend(q[j][0], q[j][1], q[j][2], q[j][3], w[j][0], w[j][1], w[j][2], w[j][3]));
+            if (!(C4 <= 65 && L4 <= 68)) {
+                // wide maps (full 384-channel map): remaining columns row by row
+                const int i = r0 + j;
+                const int i00 = __builtin_amdgcn_readlane(b.i00, i), i01 = __builtin_amdgcn_readlane(b.i01, i);
+                const int i10 = __builtin_amdgcn_readlane(b.i10, i), i11 = __builtin_amdgcn_readlane(b.i11, i);
+                for (int c4 = 64 + lane; c4 < L4; c4 += 64) {
+                    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c4 < C4)
+                        r = pg_blend(reinterpret_cast<const float4*>(m + (long long)i00 * C)[c4],
+                                     reinterpret_cast<const float4*>(m + (long long)i01 * C)[c4],
+                                     reinterpret_cast<const float4*>(m + (long long)i10 * C)[c4],
+                                     reinterpret_cast<const float4*>(m + (long long)i11 * C)[c4], w[j][0], w[j][1], w[j][2],
+                                     w[j][3]);
+                    pg_store4<SPLIT>(orow, ldo, c4, r);
+                }
+            }
         }
     }
 }
@@ -87,8 +166,8 @@ int th_pixgather_launch(const float* map, int V, int C, int H, int W, const floa
     if (P <= 0) return 0;
     TH_REQUIRE((C & 3) == 0 && (ldo & 3) == 0 && ldo >= C, "channel count / row stride must be multiples of 4, ldo >= C");
     ThPointSrc src = ps ? *ps : ThPointSrc{};
-    long long rows = (long long)P * V;
-    const int nblk = 8 * th_cdiv(th_cdiv(rows, 4), 8);      // multiple of 8 so the XCD remap is onto
+    const long long groups = (long long)th_cdiv(P, PG_G) * V;
+    const int nblk = 8 * th_cdiv(th_cdiv(groups, 4), 8);     // multiple of 8 so the XCD remap is onto
     if (fmt == TH_ROWS_SPLIT)
         hipLaunchKernelGGL(pixgather_kernel<true>, dim3(nblk), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel, P,
                            cams, scale, out, ldo);
