@@ -220,6 +220,18 @@ int th_network_forward(th_ctx* ctx, const float* pixel_feat, const float* viewdi
 int th_composite(th_ctx* ctx, const float* raw, const float* z, const th_points* rays, int white_bkgd,
                  float* rgb, float* acc, float* depth, float* weights_out, th_stream stream);
 
+/* ---- K9: ray generation for a target camera --------------------------- */
+/* lib/utils/if_nerf/if_nerf_data_utils.py:11-30 (get_rays) + :65-97 (get_near_far) as the test split of
+ * sample_ray_h36m uses them (:271-283): one ray per pixel of an H x W camera (K [3,3], R [3,3], T [3] float32,
+ * HOST pointers -- 84 bytes of parameters), intersected with the box `bounds_host` = {min xyz, max xyz} of the
+ * posed body (padded by 0.01, float64 arithmetic like the reference).  Dense outputs over the H*W pixels in
+ * row-major order: ray_o/ray_d [H*W,3] (ray_d carries the reference's |d| < 1e-5 -> 1e-5 clamp), near/far [H*W]
+ * (0 where the ray misses), mask_at_box uint8[H*W] (1: exactly two faces hit).  Compact with the mask to get the
+ * reference's ray list. */
+int th_gen_rays(th_ctx* ctx, const float* K_host, const float* R_host, const float* T_host,
+                const float* bounds_host, int H, int W, float* ray_o, float* ray_d, float* near_out,
+                float* far_out, uint8_t* mask_at_box, th_stream stream);
+
 /* view-direction embedding, if_clight_renderer.py:525-526 + embedder.py:9-35:
  * ray_d [R,3] -> [R, 3 + 6*view_res] */
 int th_view_embed(th_ctx* ctx, const float* ray_d, int R, int view_res, float* out, th_stream stream);

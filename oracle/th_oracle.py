@@ -448,3 +448,42 @@ def encoder_forward(sd, images, prefix="encoder."):
     pix = torch.cat([pix, col], dim=1)
     hol = F.conv2d(pix, sd[prefix + "reduction_layer.weight"], sd[prefix + "reduction_layer.bias"])
     return hol, pix
+
+
+# ---------------------------------------------------------------------------
+# ray generation (numpy, the reference's dtypes)
+# ---------------------------------------------------------------------------
+def gen_rays(H, W, K, R, T, bounds):
+    """lib/utils/if_nerf/if_nerf_data_utils.py:11-30 (get_rays), :65-97 (get_near_far) chained as the test split
+    of sample_ray_h36m does (:271-283).  K, R, T, bounds float32 (can_smpl.py:640-645, :216-232).
+    Returns the dense per-pixel arrays {ray_o, ray_d [H*W,3] f32 (ray_d with the :70 clamp), near, far [H*W] f32
+    (0 outside), mask_at_box bool [H*W]}."""
+    rays_o = -np.dot(R.T, T).ravel()                                                   # :14
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy")
+    xy1 = np.stack([i, j, np.ones_like(i)], axis=2)
+    pixel_camera = np.dot(xy1, np.linalg.inv(K).T)                                     # :25
+    pixel_world = np.dot(pixel_camera - T.ravel(), R)                                  # :26
+    rays_d = pixel_world - rays_o[None, None]
+    ray_o = np.broadcast_to(rays_o, rays_d.shape).reshape(-1, 3).astype(np.float32)    # :273
+    ray_d = rays_d.reshape(-1, 3).astype(np.float32)                                   # :274
+    b = bounds + np.array([-0.01, 0.01])[:, None]                                      # :67 (promotes to float64)
+    nominator = b[None] - ray_o[:, None]
+    ray_d[np.abs(ray_d) < 1e-5] = 1e-5                                                 # :70 (in place)
+    d_intersect = (nominator / ray_d[:, None]).reshape(-1, 6)
+    p_intersect = d_intersect[..., None] * ray_d[:, None] + ray_o[:, None]
+    min_x, min_y, min_z, max_x, max_y, max_z = b.ravel()
+    eps = 1e-6
+    hit = (p_intersect[..., 0] >= (min_x - eps)) * (p_intersect[..., 0] <= (max_x + eps)) * \
+          (p_intersect[..., 1] >= (min_y - eps)) * (p_intersect[..., 1] <= (max_y + eps)) * \
+          (p_intersect[..., 2] >= (min_z - eps)) * (p_intersect[..., 2] <= (max_z + eps))
+    mask = hit.sum(-1) == 2                                                            # :84
+    p_int = p_intersect[mask][hit[mask]].reshape(-1, 2, 3)
+    o, d = ray_o[mask], ray_d[mask]
+    norm_ray = np.linalg.norm(d, axis=1)                                               # float32 (:92)
+    d0 = np.linalg.norm(p_int[:, 0] - o, axis=1) / norm_ray
+    d1 = np.linalg.norm(p_int[:, 1] - o, axis=1) / norm_ray
+    near = np.zeros(H * W, np.float32)
+    far = np.zeros(H * W, np.float32)
+    near[mask] = np.minimum(d0, d1).astype(np.float32)
+    far[mask] = np.maximum(d0, d1).astype(np.float32)
+    return dict(ray_o=ray_o, ray_d=ray_d, near=near, far=far, mask_at_box=mask)

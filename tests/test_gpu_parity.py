@@ -378,3 +378,47 @@ def test_pixel_gather_padded_rows(hip, gpu):
     w = hip.pixel_gather(m, pts, cams, scale, row_floats=272)
     assert w.shape == (777, 2, 272)
     assert torch.equal(w[..., :260], a) and (w[..., 260:] == 0).all()
+
+
+@pytest.mark.parametrize("case", ["axis", "oblique"])
+def test_ray_generation_vs_golden(hip, gpu, case):
+    """8f-2 on device: th_gen_rays vs the reference's get_rays / get_near_far outputs.  Directions agree to fp32
+    rounding (BLAS summation order / LAPACK inverse are not specified); the float64 box test then decides
+    identically except for rays that graze a box edge within that rounding."""
+    g = gold("g14_rays")
+    H, W = (int(x) for x in g[f"{case}_HW"])
+    K, R, T, b = (g[f"{case}_{k}"] for k in ("K", "R", "T", "bounds"))
+    dense = hip.gen_rays(K, R, T, b, H, W, device=gpu, compact=False)
+    m_ref = g[f"{case}_mask"].bool()
+    m = dense["mask_at_box"].cpu()
+    assert maxdiff(dense["ray_d"].cpu(), g[f"{case}_ray_d_all"]) < 2e-6
+    assert (dense["ray_d"].abs() >= 1e-5).all()
+    both = m & m_ref
+    assert int((m != m_ref).sum()) <= max(2, H * W // 500)
+    near_ref = torch.zeros(H * W); far_ref = torch.zeros(H * W)
+    near_ref[m_ref] = g[f"{case}_near"]; far_ref[m_ref] = g[f"{case}_far"]
+    assert maxdiff(dense["near"].cpu()[both], near_ref[both]) < 2e-5
+    assert maxdiff(dense["far"].cpu()[both], far_ref[both]) < 2e-5
+    assert (dense["near"].cpu()[~m] == 0).all()
+    c = hip.gen_rays(K, R, T, b, H, W, device=gpu)                # the reference's compacted ray list
+    assert c["ray_o"].shape == (int(m.sum()), 3) and torch.equal(c["near"], dense["near"][dense["mask_at_box"]])
+    assert maxdiff(c["ray_o"].cpu(), g[f"{case}_ray_o"][:1].expand(c["ray_o"].shape[0], 3)) < 1e-6
+
+
+def test_generated_rays_render(hip, gpu, net):
+    """rays made on device feed Renderer.render_fast exactly like rays from the batch"""
+    _cfg(32)
+    b = synth.batch_to(synth.make_batch(48, 48, 3, seed=0, all_rays=False), gpu)
+    cam = synth.make_cameras(48, 48, 3)
+    verts = b["tar_smpl_vertice"][0].cpu().numpy()
+    bounds = np.stack([verts.min(0), verts.max(0)]).astype(np.float32)
+    bounds[0, 2] -= 0.05; bounds[1, 2] += 0.05                    # can_smpl.py:228-230
+    rays = hip.gen_rays(cam["K"].astype(np.float32), cam["R"].astype(np.float32), cam["T"].astype(np.float32), bounds,
+                        48, 48, device=gpu)
+    bb = dict(b)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        bb[k] = rays[k][None]
+    r = _renderer(net)
+    out = r.render_fast(bb)
+    assert out["rgb_map"].shape == (1, rays["near"].numel(), 3) and torch.isfinite(out["rgb_map"]).all()
+    assert r.last_stats["hit_rays"] > 0

@@ -1,6 +1,7 @@
 """CPU: the oracle (oracle/th_oracle.py) against golden vectors produced by the
 REAL reference modules (oracle/gen_golden.py).  This is what pins the oracle."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import th_oracle as O
@@ -181,3 +182,19 @@ def test_g12_mesh_cube():
     cube = O.render_sigma_grid(sd, b, grid, hol, pix, off, mem, can_centres64(synth_assign(300)))
     assert maxdiff(cube, g["cube"]) < 2e-5
     assert int((g["cube"] != 0).sum()) > 500
+
+
+@pytest.mark.parametrize("case", ["axis", "oblique"])
+def test_ray_generation_vs_reference(case):
+    """8f-2: the numpy restatement of get_rays + get_near_far equals the reference's functions bit for bit
+    (same numpy, same dtypes) -- masked ray list, near/far and the box mask"""
+    g = gold("g14_rays")
+    H, W = (int(x) for x in g[f"{case}_HW"])
+    o = O.gen_rays(H, W, g[f"{case}_K"].numpy(), g[f"{case}_R"].numpy(), g[f"{case}_T"].numpy(),
+                   g[f"{case}_bounds"].numpy())
+    m = o["mask_at_box"]
+    assert np.array_equal(m, g[f"{case}_mask"].numpy())
+    assert np.array_equal(o["ray_d"], g[f"{case}_ray_d_all"].numpy())
+    assert np.array_equal(o["ray_o"][m], g[f"{case}_ray_o"].numpy())
+    assert np.array_equal(o["near"][m], g[f"{case}_near"].numpy()) and np.array_equal(o["far"][m], g[f"{case}_far"].numpy())
+    assert (np.abs(o["ray_d"]) >= 1e-5).all()                     # the :70 clamp is part of the contract

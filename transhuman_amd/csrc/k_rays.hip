@@ -1,0 +1,108 @@
+// K9: camera rays + box intersection on device.
+//
+// if_nerf_data_utils.py:11-30 (get_rays), :65-97 (get_near_far) and the test split of sample_ray_h36m
+// (:271-283): every pixel of the target camera becomes a ray; near/far are the two intersections with the
+// (0.01-padded) bounding box of the posed body; rays that do not hit it exactly twice are dropped.
+// The reference does this per frame in numpy inside the DataLoader; for free-viewpoint video (one camera per
+// frame, run.py --type visualize) it is the last host stage in front of the renderer.
+//
+// Precision follows the reference's dtypes: get_rays runs in float32 (K, R, T are float32, can_smpl.py:640-645);
+// get_near_far runs in FLOAT64 (bounds + np.array([-0.01, 0.01]) promotes everything, :67) on the float32 rays,
+// except the ray norm (np.linalg.norm of the float32 ray_d, :92) -- restated operation by operation so that the
+// "exactly two faces hit" rule (:84) and the 1e-6 slack (:77) decide identically.  Mutation of ray_d
+// (|d| < 1e-5 -> 1e-5, :70) is part of the contract: the returned directions carry it.
+// One thread per pixel; bound: 45 B written per pixel.
+#include "th_internal.h"
+
+struct RayCam {
+    float kinv[9];   // inverse intrinsics, row-major
+    float R[9];
+    float T[3];
+    float ro[3];     // -R^T T
+    double bmin[3], bmax[3];   // padded bounds (float32 bounds -/+ 0.01 in double)
+};
+
+__global__ __launch_bounds__(256) void gen_rays_kernel(RayCam c, int H, int W, float* __restrict__ ray_o,
+                                                       float* __restrict__ ray_d, float* __restrict__ near_out,
+                                                       float* __restrict__ far_out, uint8_t* __restrict__ mask_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const float i = (float)(idx % W), j = (float)(idx / W);
+    // pixel_camera = [i, j, 1] . Kinv^T ; pixel_world = (pixel_camera - T) . R ; d = pixel_world - o
+    float pc[3], d[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pc[a] = (i * c.kinv[3 * a] + j * c.kinv[3 * a + 1]) + c.kinv[3 * a + 2];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        float pw = (pc[0] - c.T[0]) * c.R[b];
+        pw = pw + (pc[1] - c.T[1]) * c.R[3 + b];
+        pw = pw + (pc[2] - c.T[2]) * c.R[6 + b];
+        d[b] = pw - c.ro[b];
+        if (fabsf(d[b]) < 1e-5f) d[b] = 1e-5f;                          // :70 (after the float32 cast of :274)
+    }
+    // six plane hits in the reference's order: min x, min y, min z, max x, max y, max z (:68-74)
+    const double eps = 1e-6;
+    double o64[3] = {(double)c.ro[0], (double)c.ro[1], (double)c.ro[2]};
+    double d64[3] = {(double)d[0], (double)d[1], (double)d[2]};
+    int nhit = 0;
+    double t_hit[2] = {0.0, 0.0};
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const int ax = f % 3;
+        const double plane = f < 3 ? c.bmin[ax] : c.bmax[ax];
+        const double t = (plane - o64[ax]) / d64[ax];
+        double p[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) p[a] = t * d64[a] + o64[a];          // mul, then add (two roundings, :72)
+        const bool in = p[0] >= c.bmin[0] - eps && p[0] <= c.bmax[0] + eps && p[1] >= c.bmin[1] - eps &&
+                        p[1] <= c.bmax[1] + eps && p[2] >= c.bmin[2] - eps && p[2] <= c.bmax[2] + eps;
+        if (in) {
+            if (nhit < 2) {
+                // step = |p - o| / |d| (:93-94): norm of the float64 offset over the FLOAT32 norm of d
+                double e0 = p[0] - o64[0], e1 = p[1] - o64[1], e2 = p[2] - o64[2];
+                double n = sqrt((e0 * e0 + e1 * e1) + e2 * e2);
+                float nd = __fsqrt_rn((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+                t_hit[nhit] = n / (double)nd;
+            }
+            ++nhit;
+        }
+    }
+    const bool ok = nhit == 2;                                           // :84
+    ray_o[3 * idx] = c.ro[0]; ray_o[3 * idx + 1] = c.ro[1]; ray_o[3 * idx + 2] = c.ro[2];
+    ray_d[3 * idx] = d[0]; ray_d[3 * idx + 1] = d[1]; ray_d[3 * idx + 2] = d[2];
+    near_out[idx] = ok ? (float)fmin(t_hit[0], t_hit[1]) : 0.f;
+    far_out[idx] = ok ? (float)fmax(t_hit[0], t_hit[1]) : 0.f;
+    mask_out[idx] = ok ? 1 : 0;
+}
+
+int th_gen_rays_launch(const float* K, const float* R, const float* T, const float* bounds, int H, int W, float* ray_o,
+                       float* ray_d, float* near_out, float* far_out, uint8_t* mask, hipStream_t s) {
+    TH_REQUIRE(H > 0 && W > 0 && (long long)H * W < (1LL << 31), "bad image size");
+    RayCam c;
+    // inverse intrinsics (np.linalg.inv(K), :25): adjugate in double, rounded once to float32
+    const double k[9] = {K[0], K[1], K[2], K[3], K[4], K[5], K[6], K[7], K[8]};
+    const double det = k[0] * (k[4] * k[8] - k[5] * k[7]) - k[1] * (k[3] * k[8] - k[5] * k[6]) +
+                       k[2] * (k[3] * k[7] - k[4] * k[6]);
+    TH_REQUIRE(det != 0.0, "singular intrinsics");
+    const double inv[9] = {(k[4] * k[8] - k[5] * k[7]) / det, (k[2] * k[7] - k[1] * k[8]) / det,
+                           (k[1] * k[5] - k[2] * k[4]) / det, (k[5] * k[6] - k[3] * k[8]) / det,
+                           (k[0] * k[8] - k[2] * k[6]) / det, (k[2] * k[3] - k[0] * k[5]) / det,
+                           (k[3] * k[7] - k[4] * k[6]) / det, (k[1] * k[6] - k[0] * k[7]) / det,
+                           (k[0] * k[4] - k[1] * k[3]) / det};
+    for (int i = 0; i < 9; ++i) { c.kinv[i] = (float)inv[i]; c.R[i] = R[i]; }
+    for (int a = 0; a < 3; ++a) {
+        c.T[a] = T[a];
+        // rays_o = -np.dot(R.T, T) in float32 (:14)
+        float acc = R[a] * T[0];
+        acc = acc + R[3 + a] * T[1];
+        acc = acc + R[6 + a] * T[2];
+        c.ro[a] = -acc;
+        c.bmin[a] = (double)bounds[a] + (-0.01);
+        c.bmax[a] = (double)bounds[3 + a] + 0.01;
+    }
+    const int n = H * W;
+    hipLaunchKernelGGL(gen_rays_kernel, dim3(th_cdiv(n, 256)), dim3(256), 0, s, c, H, W, ray_o, ray_d, near_out, far_out,
+                       mask);
+    TH_LAUNCH_CHECK();
+    return 0;
+}

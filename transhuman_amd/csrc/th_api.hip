@@ -384,6 +384,15 @@ int th_composite(th_ctx* c, const float* raw, const float* z, const th_points* r
     return th_composite_launch(raw, z, th_src(rays), white, rgb, acc, depth, wout, (hipStream_t)stream);
 }
 
+int th_gen_rays(th_ctx* c, const float* K_host, const float* R_host, const float* T_host, const float* bounds_host, int H,
+                int W, float* ray_o, float* ray_d, float* near_out, float* far_out, uint8_t* mask_at_box,
+                th_stream stream) {
+    TH_REQUIRE(c && K_host && R_host && T_host && bounds_host && ray_o && ray_d && near_out && far_out && mask_at_box,
+               "null argument");
+    return th_gen_rays_launch(K_host, R_host, T_host, bounds_host, H, W, ray_o, ray_d, near_out, far_out, mask_at_box,
+                              (hipStream_t)stream);
+}
+
 int th_view_embed(th_ctx* c, const float* d, int R, int res, float* out, th_stream stream) {
     TH_REQUIRE(c && d && out, "null argument");
     return th_view_embed_launch(d, R, res, out, (hipStream_t)stream);

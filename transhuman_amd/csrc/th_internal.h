@@ -278,6 +278,9 @@ size_t th_vit_ws(int V, int N, int dim, int heads);
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
                   size_t ws_bytes, hipStream_t s);
 
+// k_rays.hip
+int th_gen_rays_launch(const float* K, const float* R, const float* T, const float* bounds, int H, int W, float* ray_o,
+                       float* ray_d, float* near_out, float* far_out, uint8_t* mask, hipStream_t s);
 // k_encoder.hip
 int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
                               const int* dims, int V, int H, int W, const float* wc, const float* bc, float* out,

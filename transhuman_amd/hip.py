@@ -94,6 +94,8 @@ SYMBOLS = {
                                      C.c_void_p]),
     "th_composite": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ThPoints), C.c_int, C.c_void_p,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "th_gen_rays": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "th_view_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "th_render_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int, C.c_int]),
     "th_render_rays": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_void_p,
@@ -438,6 +440,37 @@ def composite(raw, z, ray_d, white_bkgd=False, return_weights=False):
     _check(lib.th_composite(ctx(raw.device), _p(raw), _p(z), C.byref(pts), int(white_bkgd), _p(rgb), _p(acc), _p(dep),
                             _p(w), _stream()))
     return (rgb, acc, dep, w) if return_weights else (rgb, acc, dep)
+
+
+def gen_rays(K, R, T, bounds, H, W, device=None, compact=True):
+    """Rays of one target camera + box near/far, if_nerf_data_utils.py:11-30, :65-97 (test split of
+    sample_ray_h36m :271-283).  K [3,3], R [3,3], T [3,1], bounds [2,3]: float32 numpy / torch (host values).
+    compact=True returns the reference's masked ray list {ray_o [R',3], ray_d [R',3], near [R'], far [R'],
+    mask_at_box bool [H*W]}; compact=False the dense per-pixel arrays."""
+    import numpy as np
+    lib = load_library()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+    def host(a, n):
+        a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1)
+        assert a.size == n
+        return a
+
+    k, r, t, b = host(K, 9), host(R, 9), host(T, 3), host(bounds, 6)
+    n = H * W
+    ray_o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    ray_d = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    near = torch.empty(n, dtype=torch.float32, device=dev)
+    far = torch.empty(n, dtype=torch.float32, device=dev)
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    fp = lambda a: a.ctypes.data_as(c_float_p)
+    _check(lib.th_gen_rays(ctx(dev), fp(k), fp(r), fp(t), fp(b), H, W, _p(ray_o), _p(ray_d), _p(near), _p(far), _p(mask),
+                           _stream()))
+    m = mask.bool()
+    if not compact:
+        return dict(ray_o=ray_o, ray_d=ray_d, near=near, far=far, mask_at_box=m)
+    return dict(ray_o=ray_o[m], ray_d=ray_d[m], near=near[m], far=far[m], mask_at_box=m)
 
 
 def view_embed(ray_d, view_res=4):
