@@ -15,6 +15,8 @@
 //   image, so one coalesced 1 KiB global_load_dwordx4 per wave fetches a whole
 //   16(k) x 16(n) block straight into the MFMA operand registers (weights are
 //   <= 1.2 MB per layer and stay L2-resident; no LDS round trip for them).
+#include <stdlib.h>
+
 #include "th_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -84,9 +86,26 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nchunks = (KB * 16 + GEMM_KC - 1) / GEMM_KC;
+    // weight fragments: ring of GEMM_PF + 1 register sets, fragment kb + GEMM_PF is requested while block kb
+    // multiplies (the ring index is static: a chunk has 8 = 2 * (GEMM_PF + 1) k-blocks and is fully unrolled)
+    constexpr int GEMM_PF = 3;
+    f32x4 bq[GEMM_PF + 1][NT];
+    auto load_b = [&](int kb, f32x4 (&dst)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            int nb = nb0 + j;
+            dst[j] = (nb < NB) ? *reinterpret_cast<const f32x4*>(Wp + ((long long)nb * KB + kb) * 256 + lane * 4)
+                               : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    if (wave_active) {
+#pragma unroll
+        for (int i = 0; i < GEMM_PF; ++i)
+            if (i < KB) load_b(i, bq[i]);
+    }
     for (int ch = 0; ch < nchunks; ++ch) {
         const int k0 = ch * GEMM_KC;
-        // ---- stage A[m0:m0+64, k0:k0+128] -> LDS (zero fill outside M x Kreal) ----
+        // ---- stage A[m0:m0+BM, k0:k0+128] -> LDS (zero fill outside M x Kreal) ----
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             int idx = tid + 256 * i;
@@ -109,40 +128,26 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
         }
         __syncthreads();
         if (wave_active) {
-            int kb_lo = ch * (GEMM_KC / 16);
-            int kb_hi = kb_lo + GEMM_KC / 16;
-            if (kb_hi > KB) kb_hi = KB;
-            f32x4 bcur[NT];
+            const int kb_lo = ch * (GEMM_KC / 16);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                int nb = nb0 + j;
-                bcur[j] = (nb < NB) ? *reinterpret_cast<const f32x4*>(Wp + ((long long)nb * KB + kb_lo) * 256 + lane * 4)
-                                    : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            for (int kb = kb_lo; kb < kb_hi; ++kb) {
-                f32x4 bnext[NT];
-                const bool more = (kb + 1 < kb_hi);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    int nb = nb0 + j;
-                    bnext[j] = (more && nb < NB)
-                                   ? *reinterpret_cast<const f32x4*>(Wp + ((long long)nb * KB + kb + 1) * 256 + lane * 4)
-                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                f32x4 a[MT];
-                const int kl = (kb - kb_lo) * 16 + 4 * (lane >> 4);
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    a[i] = *reinterpret_cast<const f32x4*>(&As[(i * 16 + (lane & 15)) * GEMM_LDS_STRIDE + kl]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
+            for (int kl8 = 0; kl8 < GEMM_KC / 16; ++kl8) {
+                const int kb = kb_lo + kl8;
+                if (kb < KB) {
+                    if (kb + GEMM_PF < KB) load_b(kb + GEMM_PF, bq[(kl8 + GEMM_PF) % (GEMM_PF + 1)]);
+                    f32x4 a[MT];
+                    const int kl = kl8 * 16 + 4 * (lane >> 4);
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
+                        a[i] = *reinterpret_cast<const f32x4*>(&As[(i * 16 + (lane & 15)) * GEMM_LDS_STRIDE + kl]);
 #pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], bcur[j][e], acc[i][j], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int j = 0; j < NT; ++j) bcur[j] = bnext[j];
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int j = 0; j < NT; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], bq[kl8 % (GEMM_PF + 1)][j][e],
+                                                                                 acc[i][j], 0, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -190,9 +195,12 @@ int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float*
     if (M <= 0) return 0;
     TH_REQUIRE((lda & 3) == 0 && (((uintptr_t)A) & 15) == 0, "A must be 16-byte aligned with lda % 4 == 0");
     TH_REQUIRE(W.w != nullptr, "weights not packed");
-    int nt = pick_nt(W.NB);
-    // few rows (the ViT: V*N_c = 900..4500 tokens): 16-row workgroups so the launch still covers the chip
+    // few rows (the ViT: V*N_c = 900..4500 tokens): 16-row workgroups of 64 columns so the launch still covers
+    // the chip several times over (these launches are latency-bound: co-resident workgroups hide the L2 round
+    // trips of each other's weight fragments)
     const bool small = M <= 8192;
+    static const int small_nt = getenv("TH_GEMM_SMALL_NT") ? atoi(getenv("TH_GEMM_SMALL_NT")) : 1;
+    int nt = small ? (small_nt >= 1 && small_nt <= 4 ? small_nt : pick_nt(W.NB)) : pick_nt(W.NB);
     const int bm = small ? 16 : GEMM_BM;
     dim3 grid(th_cdiv(M, bm), th_cdiv(W.NB, 4 * nt));
     size_t lds = (size_t)bm * GEMM_LDS_STRIDE * sizeof(float);

@@ -201,33 +201,30 @@ int th_hull_mask_launch(const ThPointSrc& ps, long long P, const float* verts, i
 // the network WITHOUT pts_mask, i.e. every sample of every hit ray is shaded
 // (MLP_forward_ori).  Reproduced on device: no host round trip.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void count_hits_kernel(const int32_t* __restrict__ ray_hit, int R, int thr,
-                                                          int32_t* __restrict__ info) {
-    __shared__ int ws[16];
+// info[0] (zeroed by the caller) += number of hit rays; integer atomics: the sum is order-independent
+__global__ __launch_bounds__(256) void count_hits_kernel(const int32_t* __restrict__ ray_hit, int R,
+                                                         int32_t* __restrict__ info) {
     int c = 0;
-    for (int i = threadIdx.x; i < R; i += blockDim.x) c += ray_hit[i] != 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) c += ray_hit[i] != 0;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int w = 0; w < 16; ++w) t += ws[w];
-        info[0] = t;
-        info[1] = (t <= thr) ? 1 : 0;
-    }
+    if ((threadIdx.x & 63) == 0 && c != 0) atomicAdd(&info[0], c);
 }
-__global__ void small_frame_apply_kernel(uint8_t* __restrict__ mask, const int32_t* __restrict__ ray_hit,
-                                         long long P, int S, const int32_t* __restrict__ info) {
-    if (info[1] == 0) return;
-    long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i < P) mask[i] = ray_hit[(int)(i / S)] ? 1 : 0;
+// if #hit rays <= thr: mask := ray_hit for every sample of the ray; info[1] = 1 records the mode
+__global__ __launch_bounds__(256) void small_frame_apply_kernel(uint8_t* __restrict__ mask,
+                                                                const int32_t* __restrict__ ray_hit, long long P, int S,
+                                                                int thr, int32_t* __restrict__ info) {
+    if (info[0] > thr) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) info[1] = 1;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < P; i += (long long)gridDim.x * blockDim.x)
+        mask[i] = ray_hit[(int)(i / S)] ? 1 : 0;
 }
 int th_small_frame_rule(uint8_t* mask, const int32_t* ray_hit, int R, int S, int thr, int32_t* dev_info,
                         hipStream_t s) {
-    hipLaunchKernelGGL(count_hits_kernel, dim3(1), dim3(1024), 0, s, ray_hit, R, thr, dev_info);
+    // dev_info[0..1] must be zero on entry (shade_points clears the block)
+    hipLaunchKernelGGL(count_hits_kernel, dim3(R >= 65536 ? 256 : th_cdiv(R, 256)), dim3(256), 0, s, ray_hit, R, dev_info);
     long long P = (long long)R * S;
-    hipLaunchKernelGGL(small_frame_apply_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, mask, ray_hit, P, S,
-                       dev_info);
+    const int nb = (int)(P >= (1LL << 20) ? 1024 : th_cdiv(P, 256));
+    hipLaunchKernelGGL(small_frame_apply_kernel, dim3(nb), dim3(256), 0, s, mask, ray_hit, P, S, thr, dev_info);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -217,7 +217,8 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
 }
 
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const void* h, const void* f,
-                         int f_ld, const float* vd, int rgb_all, float* raw_c, hipStream_t s) {
+                         int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all, float* raw_c,
+                         hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(V >= 1 && V <= 3, "fused MLP supports 1..3 reference views");
     TH_REQUIRE(f_ld == 384 || (f_ld == 272 && base.compact_ready),
@@ -226,7 +227,7 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     FusedParams p = base;
     if (cf) { p.ar0 = base.ar0c; p.rr0 = base.rr0c; p.rr1 = base.rr1c; }
     p.alpha_w = heads.alpha_w; p.alpha_b = heads.alpha_b; p.rgb_w = heads.rgb_w; p.rgb_b = heads.rgb_b;
-    p.h = (const _Float16*)h; p.f = (const _Float16*)f; p.vd = vd; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
+    p.h = (const _Float16*)h; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
     static bool attr = false;
     if (!attr) {
 #define FM_ATTR(V_, F_)                                                                                       \

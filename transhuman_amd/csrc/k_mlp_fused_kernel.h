@@ -529,7 +529,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int i = tid + 256 * q, row = i >> 5, c = i & 31;
-            vdv[q] = (c < 27 && row < npts) ? P.vd[(long long)(pbase + row) * 27 + c] : 0.f;
+            float x = 0.f;
+            if (c < 27 && row < npts) {
+                const long long vr = P.vd_sel ? (long long)(P.vd_sel[pbase + row] / P.vd_div) : (long long)(pbase + row);
+                x = P.vd[vr * 27 + c];
+            }
+            vdv[q] = x;
         }
         stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
         FM_SYNC();

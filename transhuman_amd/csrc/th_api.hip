@@ -442,16 +442,25 @@ static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
 }
 
 // K6 dispatch: fused fp16x3-split kernel (default, V <= 3) or the layer-by-layer fp32 MFMA form
-// f_ld: floats per pixel-feature row of cb.f (384 full / 272 compact)
 // which K6 form runs for V views, and therefore which row format the producers must emit into cb.h / cb.f
 static bool mlp_is_fused(const th_ctx* c, int V) { return c->mlp_mode == 1 && c->fused_ready && V <= 3; }
 static int mlp_row_format(const th_ctx* c, int V) { return mlp_is_fused(c, V) ? TH_ROWS_SPLIT : TH_ROWS_F32; }
 
-static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, int rgb_all, hipStream_t s) {
+// f_ld: floats per pixel-feature row of cb.f (384 full / 272 compact).  View directions: `vd_table` rows are
+// addressed as vd_sel[p] / vd_div (vd_sel == nullptr: row p); the fused kernel reads the table in place, the
+// per-layer form wants them gathered into cb.vdc first.
+static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, const float* vd_table,
+                        const int32_t* vd_sel, int vd_div, int rgb_all, hipStream_t s) {
     TH_REQUIRE(c->mlp.ready, "MLP weights not set (th_set_mlp_weights)");
     if (mlp_is_fused(c, V))
-        return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.f, f_ld, cb.vdc, rgb_all, cb.raw_c, s);
-    return th_mlp_forward(c->mlp, V, m, cb.h, cb.f, f_ld, cb.vdc, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s);
+        return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.f, f_ld, vd_table, vd_sel, vd_div, rgb_all, cb.raw_c,
+                                    s);
+    const float* vd = vd_table;
+    if (vd_sel != nullptr || vd_table != cb.vdc) {
+        TH_TRY(th_gather_rows_launch(vd_table, 27, vd_sel, vd_div, m, cb.vdc, s));
+        vd = cb.vdc;
+    }
+    return th_mlp_forward(c->mlp, V, m, cb.h, cb.f, f_ld, vd, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s);
 }
 
 size_t th_network_workspace_bytes(int V, int P) {
@@ -489,14 +498,10 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
         const float* pts = idx ? pts_smpl : pts_smpl + 3LL * o;
         const int fmt = mlp_row_format(c, V);
         TH_TRY(th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, m, centres, rot, tokens, V, nc, 0.5f, cb.h, fmt, s));
-        if (idx) {
-            TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, fmt, s));
-            TH_TRY(th_gather_rows_launch(viewdir, 27, sel, 1, m, cb.vdc, s));
-        } else {
-            TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, fmt, s));
-            TH_TRY(th_gather_rows_launch(viewdir + 27LL * o, 27, nullptr, 1, m, cb.vdc, s));
-        }
-        TH_TRY(mlp_dispatch(c, V, m, cb, 384, idx ? 0 : 1, s));
+        if (idx) TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, fmt, s));
+        else TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, fmt, s));
+        if (idx) TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir, sel, 1, 0, s));
+        else TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir + 27LL * o, nullptr, 1, 1, s));
         if (idx) TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, 0, raw_out, s));
         else TH_TRY(th_scatter_raw_launch(cb.raw_c, nullptr, m, 1, raw_out + 4LL * o, s));
     }
@@ -583,11 +588,12 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
             ProfScope ps2(pf, TH_PROF_GATHER, s);
             TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, sel, m, f->cams,
                                        f->scale_xy, cb.f, f_ld, fmt, s));
-            if (ray_mode) TH_TRY(th_gather_rows_launch(vd_all, 27, sel, S, m, cb.vdc, s));
         }
         {
             ProfScope ps3(pf, TH_PROF_MLP, s);
-            TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, unmasked, s));
+            // ray mode: the [R,27] embedding table is indexed sample -> ray (sel / S); mesh mode: zero rows (cb.vdc)
+            if (ray_mode) TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, vd_all, sel, S, unmasked, s));
+            else TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, cb.vdc, nullptr, 1, unmasked, s));
         }
         ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));

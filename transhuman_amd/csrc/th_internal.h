@@ -193,7 +193,9 @@ struct FusedParams {
     // split-f16 rows written by the producers (TH_ROWS_SPLIT): K hi halves then K lo halves per (sample, view)
     const _Float16* h;  // [P][V][2][256]
     const _Float16* f;  // [P][V][2][384] (full) or [P][V][2][272] (compact: 256 latent | r g b | 0...)
-    const float* vd;    // [P][27]
+    const float* vd;    // view-direction rows [.][27]: row of compacted sample p = vd_sel ? vd_sel[p] / vd_div : p
+    const int32_t* vd_sel;
+    int vd_div;
     float* raw_c;       // [P][4]
     int P;
     int rgb_all;
@@ -204,8 +206,11 @@ size_t th_fused_pack_bytes();
 // folded: nullptr or the three colour-folded fp32 layers {alpha_res_0, rgb_res_0, rgb_res_1} (in_f 260)
 int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store, FusedParams* out, hipStream_t s);
 // h / f: TH_ROWS_SPLIT rows (same byte size as the fp32 rows: 4 * K bytes per (sample, view))
+// vd rows are addressed through vd_sel / vd_div (the per-RAY embedding table is read in place: sample index / S),
+// or directly by the compacted sample index when vd_sel == nullptr
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const void* h,
-                         const void* f, int f_ld, const float* vd, int rgb_all, float* raw_c, hipStream_t s);
+                         const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all,
+                         float* raw_c, hipStream_t s);
 
 struct th_ctx {
     void* fused_store = nullptr;
