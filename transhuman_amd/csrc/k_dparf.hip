@@ -139,7 +139,7 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
     __syncthreads();
 
     // ---- phase 2: wave per sample ----
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar)
     const float PI_F = 3.14159274101257324219f;          // fp32(pi)
     const float HALF_PI_F = 1.57079637050628662109f;     // fp32(pi/2)
     // PE channel `lane` (0..62): 0..2 raw xyz; then per octave f: sin xyz, cos xyz
@@ -161,7 +161,12 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
         float w[DP_K];
         int id[DP_K];
 #pragma unroll
-        for (int k = 0; k < DP_K; ++k) { w[k] = n.w[k]; id[k] = n.idx[k]; }
+        for (int k = 0; k < DP_K; ++k) {
+            // wave-uniform (one sample per wave): keep them in scalar registers so the row addresses are scalar
+            // arithmetic and the weights are scalar operands of the FMAs
+            w[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, n.w[k])));
+            id[k] = __builtin_amdgcn_readfirstlane(n.idx[k]);
+        }
         float pe = 0.f;
         if (lane < 63) {
 #pragma unroll

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
     // via the bounds check below).
     const long long nb8 = ((long long)gridDim.x + 7) / 8;
     const long long lb = (long long)(blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
-    const long long grp = lb * 4 + (threadIdx.x >> 6);                    // (sample group, view)
+    const long long grp = lb * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (sample group, view): scalar
     const long long ngrp = (long long)((P + PG_G - 1) / PG_G) * V;
     if (grp >= ngrp) return;
     const int v = (int)(grp % V);
