@@ -422,3 +422,41 @@ def test_generated_rays_render(hip, gpu, net):
     out = r.render_fast(bb)
     assert out["rgb_map"].shape == (1, rays["near"].numel(), 3) and torch.isfinite(out["rgb_map"]).all()
     assert r.last_stats["hit_rays"] > 0
+
+
+def _render_vs_oracle(hip, gpu, net, V, nc, assign, H=32, S=32, focal=None):
+    """whole render_fast on the device vs the CPU oracle on the same synthetic frame (encoder included)"""
+    from oracle import th_oracle as O
+    from transhuman_amd.config import get_cfg
+    from transhuman_amd.networks.renderer import if_clight_renderer
+    get_cfg().N_samples, get_cfg().num_class = S, nc
+    b = synth.make_batch(H, H, V, seed=0, focal=focal)
+    r = if_clight_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=assign)
+    out = r.render_fast(synth.batch_to(b, gpu), is_train=False)
+    sd = make_sd()
+    off, mem = csr(assign)
+    with torch.no_grad():
+        hol, pix = O.encoder_forward(sd, b["input_imgs"][0][0])
+        ref, _ = O.render_fast(sd, b, hol, pix, off, mem, can_centres64(assign), n_samples=S)
+    assert float(ref["acc_map"].max()) > 0.05, "degenerate frame"
+    assert maxdiff(out["rgb_map"].cpu(), ref["rgb_map"]) < 1e-4
+    assert maxdiff(out["acc_map"].cpu(), ref["acc_map"]) < 1e-4
+    return r.last_stats
+
+
+def test_render_single_view_vs_oracle(hip, gpu, net):
+    """BASELINE configs[0] shape of the path: V = 1 reference view (fused kernel <1,1>), N_c = 300"""
+    st = _render_vs_oracle(hip, gpu, net, V=1, nc=300, assign=synth_assign(300))
+    assert st["hit_rays"] > 0
+
+
+def test_render_two_views_vs_oracle(hip, gpu, net):
+    st = _render_vs_oracle(hip, gpu, net, V=2, nc=300, assign=synth_assign(300), H=64, focal=210.0)
+    assert st["unmasked"] == 0          # large-frame (masked, chunked) branch
+
+
+def test_render_nc1500_real_kmeans_vs_oracle(hip, gpu, net):
+    """N_c = 1500 with the reference's own kmeans cluster file (ragged clusters):
+    1500 centres in the DPaRF LDS table, 1500-token ViT attention"""
+    st = _render_vs_oracle(hip, gpu, net, V=3, nc=1500, assign=real_assign(1500))
+    assert st["hit_rays"] > 0
