@@ -232,6 +232,28 @@ int th_gen_rays(th_ctx* ctx, const float* K_host, const float* R_host, const flo
                 const float* bounds_host, int H, int W, float* ray_o, float* ray_d, float* near_out,
                 float* far_out, uint8_t* mask_at_box, th_stream stream);
 
+/* ---- K10: SMPL linear blend skinning ------------------------------------ */
+/* SMPL._call, lib/utils/SMPL.py:114-186, float64 like the reference.  Model arrays (DEVICE pointers, the fields
+ * the reference reads from the SMPL pickle, :83-89): v_template [nv,3], shapedirs [nv,3,10], posedirs [nv,3,207],
+ * J_regressor [24,nv] dense, weights [nv,24], parent int32[24] (parent[0] = -1).
+ * Pose: either pose_aa = 72 float32 axis-angle values (cv2.Rodrigues form, :135-139) or rot = [24,3,3] float32
+ * rotation matrices (:131-132); exactly one of the two is non-NULL.  beta: 10 float64 (device).
+ * Outputs (device, float64): verts [nv,3] (SMPL-space posed vertices, :186), joints [24,3] (:163),
+ * T [nv,4,4] (= the path's blend_mtx, :176). */
+typedef struct {
+    const double* v_template;
+    const double* shapedirs;
+    const double* posedirs;
+    const double* J_regressor;
+    const double* weights;
+    const int32_t* parent;
+    int n_verts;
+} th_smpl_model;
+size_t th_smpl_workspace_bytes(int n_verts);
+int th_smpl_lbs(th_ctx* ctx, const th_smpl_model* model, const float* pose_aa, const float* rot, const double* beta,
+                double* verts, double* joints, double* T, void* workspace, size_t workspace_bytes,
+                th_stream stream);
+
 /* view-direction embedding, if_clight_renderer.py:525-526 + embedder.py:9-35:
  * ray_d [R,3] -> [R, 3 + 6*view_res] */
 int th_view_embed(th_ctx* ctx, const float* ray_d, int R, int view_res, float* out, th_stream stream);

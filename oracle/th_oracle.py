@@ -487,3 +487,56 @@ def gen_rays(H, W, K, R, T, bounds):
     near[mask] = np.minimum(d0, d1).astype(np.float32)
     far[mask] = np.maximum(d0, d1).astype(np.float32)
     return dict(ray_o=ray_o, ray_d=ray_d, near=near, far=far, mask_at_box=mask)
+
+
+# ---------------------------------------------------------------------------
+# SMPL linear blend skinning (numpy float64, lib/utils/SMPL.py:114-186)
+# ---------------------------------------------------------------------------
+def rodrigues(r):
+    """cv2.Rodrigues(rotation vector) -> 3x3 (third-party, absent here: OpenCV's documented formula
+    R = cos(t) I + (1 - cos(t)) n n^T + sin(t) [n]x with t = |r|, n = r / t; identity for t = 0).
+    Parity unpinned against cv2 itself; tests pin it against scipy's Rotation.from_rotvec."""
+    r = np.asarray(r, np.float64).reshape(3)
+    t = np.sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2])
+    if t < np.finfo(np.float64).eps:
+        return np.eye(3)
+    n = r / t
+    c, s = np.cos(t), np.sin(t)
+    K = np.array([[0, -n[2], n[1]], [n[2], 0, -n[0]], [-n[1], n[0], 0]])
+    return c * np.eye(3) + (1 - c) * np.outer(n, n) + s * K
+
+
+def smpl_lbs(model, pose, beta):
+    """SMPL._call, lib/utils/SMPL.py:114-186.  model: dict of float64 arrays (synth.make_smpl_model layout,
+    parent[0] = -1); pose: [24,3,3] rotation matrices or 72 axis-angle values; beta [10].
+    Returns (v [nv,3], joints [24,3], T [nv,4,4]) float64."""
+    nv = model["v_template"].shape[0]
+    shapedirs = model["shapedirs"].reshape(-1, 10)
+    v_shaped = shapedirs.dot(np.asarray(beta, np.float64)[:, None]).reshape(nv, 3) + model["v_template"]   # :122
+    J = model["J_regressor"].dot(v_shaped)                                                                  # :127
+    pose = np.asarray(pose)
+    if pose.shape == (24, 3, 3):
+        R = pose
+    else:
+        R = np.array([rodrigues(p) for p in pose.reshape(-1, 3)], dtype="float32")                          # :135-139
+    Is = np.eye(3, dtype="float32")[None, :]
+    lrotmin = (R[1:, :] - Is).reshape(-1, 1)                                                                # :147
+    v_posed = v_shaped + model["posedirs"].reshape(-1, 207).dot(lrotmin).reshape(nv, 3)                     # :149
+    parent = model["parent"][1:]
+    J_ = J.copy()
+    J_[1:, :] = J[1:, :] - J[parent, :]                                                                     # :153
+    G_ = np.concatenate([R, J_[:, :, None]], axis=-1)
+    pad = np.repeat(np.array([[0, 0, 0, 1]], dtype="float32"), 24, axis=0).reshape(-1, 1, 4)
+    G_ = np.concatenate([G_, pad], axis=1)
+    G = [G_[0].copy()]
+    for i in range(1, 24):
+        G.append(G[parent[i - 1]].dot(G_[i, :, :]))                                                         # :160-161
+    G = np.stack(G, axis=0)
+    joints = G[:, :3, 3]
+    rest = np.concatenate([J, np.zeros((24, 1))], axis=-1)[:, :, None]
+    rest_mtx = np.concatenate([np.zeros((24, 4, 3), dtype="float32"), rest], axis=-1)
+    G = G - np.matmul(G, rest_mtx)                                                                          # :169-170
+    rest_h = np.concatenate([v_posed, np.ones(nv)[:, None]], axis=-1)
+    T = model["weights"].dot(G.reshape(24, -1)).reshape(nv, 4, 4)                                           # :176
+    v = np.matmul(T, rest_h[:, :, None])[:, :3, 0]                                                          # :177,:186
+    return v, joints, T

@@ -460,3 +460,16 @@ def test_render_nc1500_real_kmeans_vs_oracle(hip, gpu, net):
     1500 centres in the DPaRF LDS table, 1500-token ViT attention"""
     st = _render_vs_oracle(hip, gpu, net, V=3, nc=1500, assign=real_assign(1500))
     assert st["hit_rays"] > 0
+
+
+def test_smpl_lbs_vs_golden(hip, gpu):
+    """8f-3 on device: th_smpl_lbs (float64) vs the reference's SMPL._call outputs, both pose input forms"""
+    g = gold("g15_smpl")
+    model = hip.SmplModel(synth.make_smpl_model(), device=gpu)
+    pose, beta = synth.make_smpl_pose()
+    for form in (g["R"], torch.from_numpy(pose)):
+        v, j, T = model(form, beta)
+        assert v.dtype == torch.float64 and T.shape == (6890, 4, 4)
+        assert maxdiff(v.cpu(), g["v"]) < 1e-10 and maxdiff(j.cpu(), g["joints"]) < 1e-10
+        assert maxdiff(T.cpu()[::16], g["T_sub"]) < 1e-10
+        assert maxdiff(T.cpu().sum(0), g["T_sum"]) < 1e-8

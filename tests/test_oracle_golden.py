@@ -198,3 +198,22 @@ def test_ray_generation_vs_reference(case):
     assert np.array_equal(o["ray_o"][m], g[f"{case}_ray_o"].numpy())
     assert np.array_equal(o["near"][m], g[f"{case}_near"].numpy()) and np.array_equal(o["far"][m], g[f"{case}_far"].numpy())
     assert (np.abs(o["ray_d"]) >= 1e-5).all()                     # the :70 clamp is part of the contract
+
+
+def test_smpl_lbs_vs_reference():
+    """8f-3: numpy restatement of SMPL._call == the reference's own (golden from SMPL.__call__ with rotation
+    matrices) on the synthetic body model; Rodrigues pinned against scipy (cv2 is absent)"""
+    from scipy.spatial.transform import Rotation
+    g = gold("g15_smpl")
+    m = synth.make_smpl_model()
+    pose, beta = synth.make_smpl_pose()
+    R = np.array([O.rodrigues(p) for p in pose.reshape(-1, 3)], dtype="float32")
+    assert np.array_equal(R, g["R"].numpy())
+    for p in pose.reshape(-1, 3):
+        assert np.abs(O.rodrigues(p) - Rotation.from_rotvec(p.astype(np.float64)).as_matrix()).max() < 1e-14
+    for form in (R, pose):                                   # both input forms of :130-141
+        v, j, T = O.smpl_lbs(m, form, beta)
+        assert np.abs(v - g["v"].numpy()).max() < 1e-12 and np.abs(j - g["joints"].numpy()).max() < 1e-12
+        assert np.abs(T[::16] - g["T_sub"].numpy()).max() < 1e-12
+        assert np.abs(T.sum(0) - g["T_sum"].numpy()).max() < 1e-9
+    assert np.abs(v - m["v_template"]).max() > 0.01          # the pose actually moves the body

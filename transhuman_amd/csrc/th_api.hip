@@ -393,6 +393,17 @@ int th_gen_rays(th_ctx* c, const float* K_host, const float* R_host, const float
                               (hipStream_t)stream);
 }
 
+size_t th_smpl_workspace_bytes(int n_verts) { return th_smpl_ws(n_verts); }
+
+int th_smpl_lbs(th_ctx* c, const th_smpl_model* m, const float* pose_aa, const float* rot, const double* beta,
+                double* verts, double* joints, double* T, void* ws, size_t ws_bytes, th_stream stream) {
+    TH_REQUIRE(c && m && beta && verts && joints && T && ws, "null argument");
+    TH_REQUIRE(m->v_template && m->shapedirs && m->posedirs && m->J_regressor && m->weights && m->parent && m->n_verts > 0,
+               "incomplete th_smpl_model");
+    TH_REQUIRE((pose_aa != nullptr) != (rot != nullptr), "give exactly one of pose_aa (72 axis-angle) / rot ([24,3,3])");
+    return th_smpl_launch(*m, pose_aa, rot, beta, verts, joints, T, ws, ws_bytes, (hipStream_t)stream);
+}
+
 int th_view_embed(th_ctx* c, const float* d, int R, int res, float* out, th_stream stream) {
     TH_REQUIRE(c && d && out, "null argument");
     return th_view_embed_launch(d, R, res, out, (hipStream_t)stream);

@@ -283,6 +283,10 @@ size_t th_vit_ws(int V, int N, int dim, int heads);
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
                   size_t ws_bytes, hipStream_t s);
 
+// k_smpl.hip
+size_t th_smpl_ws(int nv);
+int th_smpl_launch(const th_smpl_model& m, const float* pose_aa, const float* R, const double* beta, double* verts,
+                   double* joints, double* T, void* ws, size_t ws_bytes, hipStream_t s);
 // k_rays.hip
 int th_gen_rays_launch(const float* K, const float* R, const float* T, const float* bounds, int H, int W, float* ray_o,
                        float* ray_d, float* near_out, float* far_out, uint8_t* mask, hipStream_t s);

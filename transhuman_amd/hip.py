@@ -27,6 +27,11 @@ class ThMlpWeights(C.Structure):
     _fields_ = [(n, ThLinear) for n in _names]
 
 
+class ThSmplModel(C.Structure):
+    _fields_ = [("v_template", C.c_void_p), ("shapedirs", C.c_void_p), ("posedirs", C.c_void_p),
+                ("J_regressor", C.c_void_p), ("weights", C.c_void_p), ("parent", C.c_void_p), ("n_verts", C.c_int)]
+
+
 class ThVitBlock(C.Structure):
     _fields_ = [("ln1_w", C.c_void_p), ("ln1_b", C.c_void_p), ("ln2_w", C.c_void_p), ("ln2_b", C.c_void_p),
                 ("qkv", ThLinear), ("proj", ThLinear), ("fc1", ThLinear), ("fc2", ThLinear)]
@@ -96,6 +101,9 @@ SYMBOLS = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "th_gen_rays": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "th_smpl_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "th_smpl_lbs": (C.c_int, [C.c_void_p, C.POINTER(ThSmplModel), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "th_view_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "th_render_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int, C.c_int]),
     "th_render_rays": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_void_p,
@@ -471,6 +479,39 @@ def gen_rays(K, R, T, bounds, H, W, device=None, compact=True):
     if not compact:
         return dict(ray_o=ray_o, ray_d=ray_d, near=near, far=far, mask_at_box=m)
     return dict(ray_o=ray_o[m], ray_d=ray_d[m], near=near[m], far=far[m], mask_at_box=m)
+
+
+class SmplModel:
+    """Device copy of the SMPL model arrays (the fields lib/utils/SMPL.py:83-89 reads), float64."""
+
+    def __init__(self, arrays, device=None):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        f64 = lambda k: torch.as_tensor(arrays[k], dtype=torch.float64).contiguous().to(dev)
+        self.v_template, self.shapedirs, self.posedirs = f64("v_template"), f64("shapedirs"), f64("posedirs")
+        self.J_regressor, self.weights = f64("J_regressor"), f64("weights")
+        self.parent = torch.as_tensor(arrays["parent"], dtype=torch.int32).contiguous().to(dev)
+        self.nv = self.v_template.shape[0]
+        assert self.shapedirs.shape == (self.nv, 3, 10) and self.posedirs.shape == (self.nv, 3, 207)
+        assert self.J_regressor.shape == (24, self.nv) and self.weights.shape == (self.nv, 24)
+        self.c = ThSmplModel(_p(self.v_template), _p(self.shapedirs), _p(self.posedirs), _p(self.J_regressor),
+                             _p(self.weights), _p(self.parent), self.nv)
+
+    def __call__(self, pose, beta):
+        """SMPL.__call__ (lib/utils/SMPL.py:107-186): pose = 72 axis-angle values or [24,3,3] rotation matrices;
+        beta [10].  -> (v [nv,3], joints [24,3], T [nv,4,4]) float64 device tensors."""
+        lib = load_library()
+        dev = self.v_template.device
+        p = torch.as_tensor(pose, dtype=torch.float32).contiguous().to(dev)
+        b = torch.as_tensor(beta, dtype=torch.float64).reshape(10).contiguous().to(dev)
+        is_rot = tuple(p.shape) == (24, 3, 3)
+        assert is_rot or p.numel() == 72, "Unsupported Pose Inputs"
+        v = torch.empty((self.nv, 3), dtype=torch.float64, device=dev)
+        j = torch.empty((24, 3), dtype=torch.float64, device=dev)
+        T = torch.empty((self.nv, 4, 4), dtype=torch.float64, device=dev)
+        ws = _ws(lib.th_smpl_workspace_bytes(self.nv), dev)
+        _check(lib.th_smpl_lbs(ctx(dev), C.byref(self.c), None if is_rot else _p(p), _p(p) if is_rot else None, _p(b),
+                               _p(v), _p(j), _p(T), _p(ws), ws.numel(), _stream()))
+        return v, j, T
 
 
 def view_embed(ray_d, view_res=4):

@@ -383,3 +383,45 @@ def batch_to(batch, device):
         else:
             out[k] = v
     return out
+
+
+# --------------------------------------------------------------------------
+# synthetic SMPL-shaped body model (the real SMPL pickle is not redistributable / absent)
+# --------------------------------------------------------------------------
+SMPL_PARENT = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21], np.int64)
+
+
+def make_smpl_model(seed=5, nv=NV):
+    """Arrays with the shapes / dtypes of the SMPL pickle fields lib/utils/SMPL.py:83-89 reads (float64):
+    v_template [nv,3], shapedirs [nv,3,10], posedirs [nv,3,207], J_regressor [24,nv] (rows sum to 1),
+    weights [nv,24] (rows sum to 1), parent [24] (the SMPL kinematic tree).  Geometry = the capsule body."""
+    rs = np.random.RandomState(seed)
+    v, _ = make_body(0, nv)
+    v = v.astype(np.float64)
+    # 24 joint seeds spread over the body: farthest-point sample of the vertices, ordered root-first by height
+    idx = [int(np.argmin(np.abs(v[:, 1] - np.median(v[:, 1])) + np.abs(v[:, 0])))]
+    dmin = ((v - v[idx[0]]) ** 2).sum(1)
+    for _ in range(23):
+        idx.append(int(np.argmax(dmin)))
+        dmin = np.minimum(dmin, ((v - v[idx[-1]]) ** 2).sum(1))
+    jpos = v[idx]
+    d = np.linalg.norm(v[:, None, :] - jpos[None], axis=2)                 # [nv,24]
+    w = np.exp(-(d - d.min(1, keepdims=True)) / 0.06)
+    w[w < 1e-4] = 0.0
+    w /= w.sum(1, keepdims=True)
+    jr = np.exp(-(d.T / 0.05) ** 2)                                        # [24,nv]
+    jr[jr < 1e-3] = 0.0
+    jr /= jr.sum(1, keepdims=True)
+    shapedirs = (rs.standard_normal((nv, 3, 10)) * 0.004 + v[:, :, None] * rs.uniform(-0.02, 0.02, (1, 1, 10)))
+    posedirs = rs.standard_normal((nv, 3, 207)) * 0.002
+    return dict(v_template=v, shapedirs=shapedirs, posedirs=posedirs, J_regressor=jr, weights=w,
+                parent=SMPL_PARENT.copy())
+
+
+def make_smpl_pose(seed=7, scale=0.35):
+    """(poses [1,72] axis-angle float32 like the annots, betas [10] float64)"""
+    rs = np.random.RandomState(seed)
+    pose = (rs.uniform(-1, 1, (24, 3)) * scale).astype(np.float32)
+    pose[5] = 0.0                                                        # one exact-zero rotation (the theta = 0 branch)
+    beta = rs.uniform(-1.5, 1.5, 10)
+    return pose.reshape(1, 72), beta
