@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 from transhuman_amd import synth                                    # noqa: E402
 from transhuman_amd.config import get_cfg                           # noqa: E402
-from transhuman_amd.dist import shard_ray_indices, gather_image     # noqa: E402
+from transhuman_amd.dist import shard_ray_indices, gather_image, ImageGatherer     # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12        # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 SIGMA_BIAS = -1.7
@@ -185,6 +185,7 @@ def main():
         shard[k] = batch[k][:, my_idx].contiguous()
 
     hit_buf = torch.zeros(1, dtype=torch.int64, device=dev)
+    gatherer = ImageGatherer(my_idx, R, world) if dist_on else None      # shard layout exchanged once
 
     def step():
         frame = renderer.prepare_frame(batch)
@@ -203,7 +204,7 @@ def main():
                 out = renderer.render_fast(shard, frame=frame)
         local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
         if dist_on:
-            img = gather_image(local, my_idx, R, world)
+            img = gatherer(local)
         else:
             img = torch.zeros((R, 5), dtype=local.dtype, device=dev)
             img[my_idx] = local

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from transhuman_amd.dist import gather_image, shard_ray_indices
+from transhuman_amd.dist import ImageGatherer, gather_image, shard_ray_indices
 
 
 def _free_port():
@@ -36,6 +36,12 @@ def _worker(rank, world, port, H, W, q):
         dist.all_reduce(hits)
         img = gather_image(local, idx, H * W, world)
         ok = torch.equal(img, full) and int(hits) == int((full[:, 3] > 0.5).sum())
+        # tile-major shard order (what bench.py uses) through the cached-layout gatherer, two frames
+        idx2 = shard_ray_indices(H, W, world, rank, tile=8, tile_major=True)
+        ga = ImageGatherer(idx2, H * W, world)
+        for scale in (1.0, 2.0):
+            ok = ok and torch.equal(ga(full[idx2] * scale), full * scale)
+        ok = ok and torch.equal(torch.sort(idx2).values, idx)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

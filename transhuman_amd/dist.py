@@ -63,3 +63,44 @@ def gather_image(local, my_idx, n_rays, world, H=None, W=None, tile=8, group=Non
     img = torch.zeros((n_rays, C), dtype=local.dtype, device=local.device)
     img[all_idx[keep]] = all_val[keep]
     return img
+
+
+class ImageGatherer:
+    """gather_image with the shard layout exchanged ONCE: the ray -> rank assignment is a function of the camera
+    resolution only, so the per-frame exchange is a single all_gather_into_tensor of the padded [max_local, C]
+    blocks (one collective, no host synchronisation) followed by one index_copy into the dense image."""
+
+    def __init__(self, my_idx, n_rays, world, channels=5, group=None):
+        import torch.distributed as dist
+        self.world, self.n_rays, self.group, self.C = world, n_rays, group, channels
+        dev = my_idx.device
+        n_local = torch.tensor([my_idx.numel()], dtype=torch.int64, device=dev)
+        lens = [torch.zeros_like(n_local) for _ in range(world)]
+        dist.all_gather(lens, n_local, group=group)
+        self.lens = [int(l) for l in lens]
+        self.mx = max(self.lens)
+        pad_idx = torch.full((self.mx,), -1, dtype=torch.int64, device=dev)
+        pad_idx[: my_idx.numel()] = my_idx
+        idxs = [torch.empty_like(pad_idx) for _ in range(world)]
+        dist.all_gather(idxs, pad_idx, group=group)
+        all_idx = torch.cat(idxs)
+        self.keep = torch.nonzero(all_idx >= 0, as_tuple=False).reshape(-1)
+        self.dst = all_idx[self.keep]
+        self.n_local = my_idx.numel()
+        self.pad = torch.zeros((self.mx, channels), dtype=torch.float32, device=dev)
+        self.all_val = torch.empty((world * self.mx, channels), dtype=torch.float32, device=dev)
+
+    def __call__(self, local):
+        import torch.distributed as dist
+        assert local.shape == (self.n_local, self.C)
+        self.pad[: self.n_local] = local
+        if local.is_cuda:
+            dist.all_gather_into_tensor(self.all_val, self.pad, group=self.group)
+            vals = self.all_val
+        else:  # gloo (CPU tests)
+            vs = [torch.empty_like(self.pad) for _ in range(self.world)]
+            dist.all_gather(vs, self.pad, group=self.group)
+            vals = torch.cat(vs)
+        img = torch.zeros((self.n_rays, self.C), dtype=local.dtype, device=local.device)
+        img.index_copy_(0, self.dst, vals.index_select(0, self.keep))
+        return img
