@@ -188,20 +188,20 @@ def main():
     gatherer = ImageGatherer(my_idx, R, world) if dist_on else None      # shard layout exchanged once
 
     def step():
-        frame = renderer.prepare_frame(batch)
-        if dist_on:
+        # Renderer.render_fast queues: ray-only stage (hull mask, compaction) -> per-frame constants (encoder, paint,
+        # TransHE) -> shading + compositing.
+        if not dist_on:
+            out = renderer.render_fast(shard)
+        else:
             # The reference's R' <= 2400 switch (if_clight_renderer.py:551) looks at the WHOLE frame.  Render the
             # shard in the (overwhelmingly common) masked mode, sum the per-rank hit-ray counts that
             # th_render_rays reports anyway (8-byte all-reduce), and only if the frame total is <= 2400 render
             # again in the reference's un-masked mode.
-            frame.c.small_frame_rays = -1
-        out = renderer.render_fast(shard, frame=frame)
-        if dist_on:
+            out = renderer.render_fast(shard, small_frame_rays=-1)
             hit_buf.fill_(int(renderer.last_stats["hit_rays"]))
             dist.all_reduce(hit_buf)
             if int(hit_buf) <= 2400:
-                frame.c.small_frame_rays = 1 << 30
-                out = renderer.render_fast(shard, frame=frame)
+                out = renderer.render_fast(shard, small_frame_rays=1 << 30)
         local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
         if dist_on:
             img = gatherer(local)

@@ -288,6 +288,15 @@ int th_render_rays(th_ctx* ctx, const th_frame* f, const th_points* rays, float*
                    float* depth, int white_bkgd, void* workspace, size_t workspace_bytes,
                    int64_t* stats_host, th_stream stream);
 
+/* Optional: run the ray-only front of th_render_rays (sample placement + hull mask :440-444, the R' <= 2400
+ * rule :551, compaction, view-direction embedding) ahead of time.  It needs only the rays and, of `f`, the
+ * fields verts_world / n_verts / V / hull_thresh / small_frame_rays -- so it can be queued BEFORE the per-frame
+ * constants (encoder, tokens) are produced; its sample count then reaches the host while that work runs and the
+ * following th_render_rays (same ctx, same workspace, same ray arrays and stream) neither repeats the stage nor
+ * stalls the queue on the read-back.  Results are identical with or without it. */
+int th_render_prepass(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
+                      size_t workspace_bytes, th_stream stream);
+
 /* if_mesh_renderer.Renderer.render :46-100 up to `cube`: sigma_raw per grid
  * point (0 outside the hull).  pts [P,3] world space. */
 size_t th_sigma_grid_workspace_bytes(const th_frame* f, int P);

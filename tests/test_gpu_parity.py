@@ -473,3 +473,29 @@ def test_smpl_lbs_vs_golden(hip, gpu):
         assert maxdiff(v.cpu(), g["v"]) < 1e-10 and maxdiff(j.cpu(), g["joints"]) < 1e-10
         assert maxdiff(T.cpu()[::16], g["T_sub"]) < 1e-10
         assert maxdiff(T.cpu().sum(0), g["T_sum"]) < 1e-8
+
+
+def test_prepass_equals_plain_render(hip, gpu, net):
+    """th_render_prepass only reorders the queue: with the same frame constants the image and the statistics are
+    bit-identical, a stale token (other rays) is ignored, and Renderer.render_fast's automatic
+    prepass -> prepare_frame -> shading order gives the frame of the plain order"""
+    _cfg(32)
+    b = synth.batch_to(synth.make_batch(64, 64, 3, seed=0, focal=210.0), gpu)
+    r = _renderer(net)
+    frame = r.prepare_frame(b)
+
+    def pts(n=None):
+        return hip.Points(b["ray_o"][0][:n], b["ray_d"][0][:n], b["near"][0][:n], b["far"][0][:n], n_samples=32)
+
+    rgb0, acc0, dep0, st0 = hip.render_rays(net, frame, pts())
+    P1 = pts()
+    hip.render_prepass(P1, b["tar_smpl_vertice"][0], 3)
+    torch.zeros(1 << 20, device=gpu).normal_()            # unrelated work queued in between
+    rgb1, acc1, dep1, st1 = hip.render_rays(net, frame, P1)
+    assert torch.equal(rgb0, rgb1) and torch.equal(acc0, acc1) and torch.equal(dep0, dep1) and st0 == st1
+    hip.render_prepass(pts(100), b["tar_smpl_vertice"][0], 3)      # token for OTHER rays: must not be used
+    rgb2, _, _, st2 = hip.render_rays(net, frame, pts())
+    assert torch.equal(rgb0, rgb2) and st0 == st2
+    auto = r.render_fast(b)                               # prepass -> prepare_frame -> shading
+    assert r.last_stats == st0
+    assert maxdiff(auto["rgb_map"][0].cpu(), rgb0.cpu()) < 1e-5    # (frame constants recomputed: MIOpen conv order)

@@ -70,6 +70,7 @@ void th_ctx_destroy(th_ctx* c) {
     if (c->vit_store) (void)hipFree(c->vit_store);
     if (c->fused_store) (void)hipFree(c->fused_store);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    if (c->prepass_ev) (void)hipEventDestroy(c->prepass_ev);
     delete[] c->vit.blocks;
     if (c->prof) {
         ThProf* p = (ThProf*)c->prof;
@@ -540,13 +541,16 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
 }
 
 // hull mask -> (small-frame rule) -> compaction -> chunked DPaRF + gather + MLP -> dense raw[P,4]
+// stage A (hull mask, small-frame rule, compaction, view embedding, cleared raw) may run ahead of time
+// (th_render_prepass): it needs only the rays, the posed vertices and the two thresholds.  `prepass` = 1: run
+// stage A only and leave the counts on their way to host_pinned[16..]; 2: stage A already ran into this workspace.
 static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long long P, bool ray_mode, ThArena& ar,
-                        float** raw_out, int64_t* stats_host, hipStream_t s) {
+                        float** raw_out, int64_t* stats_host, hipStream_t s, int prepass = 0) {
     const int R = ps.R, S = ps.S, V = f->V;
     const bool compact = f->map_channels == TH_MAP_COMPACT;
     const int f_ld = compact ? 272 : 384;
     const int fmt = mlp_row_format(c, V);
-    TH_REQUIRE(!compact || c->mlp.compact_ready,
+    TH_REQUIRE(prepass == 1 || !compact || c->mlp.compact_ready,
                "compact pixel map needs th_mlp_weights.upsample_color (colour-folded layers) to be uploaded");
     uint8_t* mask = ar.take<uint8_t>((size_t)P);
     int32_t* ray_hit = ar.take<int32_t>((size_t)R);
@@ -564,6 +568,11 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     TH_TRY(chunk_carve(ar, V, CH, &cb));
 
     ThProf* pf = prof_of(c);
+    int32_t* hp = c->host_pinned;
+    if (prepass == 2) {
+        hp = c->host_pinned + 16;
+        TH_HIP(hipEventSynchronize(c->prepass_ev));
+    } else {
     ProfScope* sc = new ProfScope(pf, TH_PROF_HULL, s);
     TH_HIP(hipMemsetAsync(info, 0, 16 * 4, s));
     const bool no_hull = f->hull_thresh < 0.f;   // Renderer.render (:486-498): every sample shaded, RGB everywhere
@@ -582,9 +591,16 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     TH_TRY(th_compact_mask(mask, P, idx, info + 2, cws, cws_b, s));
     TH_HIP(hipMemsetAsync(raw, 0, (size_t)P * 16, s));
     delete sc;
+    if (prepass == 1) {
+        TH_HIP(hipMemcpyAsync(c->host_pinned + 16, info, 4 * 4, hipMemcpyDeviceToHost, s));
+        if (!c->prepass_ev) TH_HIP(hipEventCreateWithFlags(&c->prepass_ev, hipEventDisableTiming));
+        TH_HIP(hipEventRecord(c->prepass_ev, s));
+        return 0;
+    }
     TH_HIP(hipMemcpyAsync(c->host_pinned, info, 4 * 4, hipMemcpyDeviceToHost, s));
     TH_HIP(hipStreamSynchronize(s));
-    const int hit_rays = c->host_pinned[0], unmasked = c->host_pinned[1], n = c->host_pinned[2];
+    }
+    const int hit_rays = hp[0], unmasked = hp[1], n = hp[2];
     if (stats_host) { stats_host[0] = hit_rays; stats_host[1] = n; stats_host[2] = -1; stats_host[3] = unmasked; }
     if (!ray_mode) TH_HIP(hipMemsetAsync(cb.vdc, 0, (size_t)CH * 27 * 4, s));   // zero view dirs, if_mesh_renderer.py:62
     for (int o = 0; o < n; o += CH) {
@@ -633,9 +649,35 @@ int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* r
     ThArena ar(ws, ws_bytes);
     ThPointSrc ps = th_src(rays);
     float* raw = nullptr;
-    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, stats_host, s));
+    // a matching th_render_prepass (same workspace, same ray arrays) already ran the hull / compaction stage
+    const bool pre = c->prepass_valid && c->prepass_ws == ws && c->prepass_rays == (const void*)rays->ray_o &&
+                     c->prepass_R == R && c->prepass_S == S;
+    c->prepass_valid = false;
+    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, stats_host, s, pre ? 2 : 0));
     ProfScope sc(prof_of(c), TH_PROF_COMPOSITE, s);
     return th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, s);
+}
+
+int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, th_stream stream) {
+    TH_REQUIRE(c && f && rays && ws, "null argument");
+    TH_REQUIRE(f->verts_world && f->n_verts > 0 && f->V >= 1 && f->V <= 4, "prepass needs verts_world, n_verts and V");
+    TH_REQUIRE(rays->pts == nullptr && rays->ray_o && rays->ray_d && rays->near && rays->far && rays->t_vals &&
+                   rays->one_minus_t,
+               "th_render_prepass needs a complete ray description");
+    hipStream_t s = (hipStream_t)stream;
+    const int R = rays->R, S = rays->S;
+    c->prepass_valid = false;
+    if (R <= 0) return 0;
+    long long P = (long long)R * S;
+    TH_REQUIRE(P < (1LL << 31), "R*S must fit in int32");
+    TH_REQUIRE(ws_bytes >= shade_ws_bytes(f, P, R), "workspace too small");
+    ThArena ar(ws, ws_bytes);
+    ThPointSrc ps = th_src(rays);
+    float* raw = nullptr;
+    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, nullptr, s, 1));
+    c->prepass_ws = ws; c->prepass_rays = rays->ray_o; c->prepass_R = R; c->prepass_S = S;
+    c->prepass_valid = true;
+    return 0;
 }
 
 __global__ void extract_sigma_kernel(const float4* __restrict__ raw, long long P, float* __restrict__ out) {

@@ -222,7 +222,13 @@ struct th_ctx {
     void* vit_store = nullptr;
     ThMlpPacked mlp;
     ThVitPacked vit;
-    int32_t* host_pinned = nullptr;   // small pinned read-back buffer
+    int32_t* host_pinned = nullptr;   // small pinned read-back buffer ([0..15] immediate reads, [16..31] prepass)
+    // th_render_prepass token: the hull / compaction stage of the next th_render_rays already ran into `ws`
+    hipEvent_t prepass_ev = nullptr;
+    const void* prepass_ws = nullptr;
+    const void* prepass_rays = nullptr;
+    int prepass_R = 0, prepass_S = 0;
+    bool prepass_valid = false;
     int n_cu = 256;
     void* prof = nullptr;             // ThProf (th_api.hip)
 };

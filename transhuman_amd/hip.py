@@ -108,6 +108,8 @@ SYMBOLS = {
     "th_render_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int, C.c_int]),
     "th_render_rays": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
+    "th_render_prepass": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
     "th_sigma_grid_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int]),
     "th_eval_sigma_grid": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
@@ -550,6 +552,20 @@ def _cached_ws(nbytes, device):
         cur = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         _ws_cache[key] = cur
     return cur
+
+
+def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=2400):
+    """th_render_prepass: queue the ray-only front of render_rays (hull mask, compaction, ...) before the
+    per-frame constants exist.  The following render_rays on the same `points` picks it up."""
+    lib = load_library()
+    v = _f32(verts_world).reshape(-1, 3)
+    dev = v.device
+    f = ThFrame()
+    f.verts_world, f.n_verts, f.V = v.data_ptr(), v.shape[0], V
+    f.hull_thresh, f.small_frame_rays, f.map_channels = hull_thresh, small_frame_rays, 384
+    ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(f), points.R, points.S), dev)
+    points._prepass_keep = (v, ws)
+    _check(lib.th_render_prepass(ctx(dev), C.byref(f), C.byref(points.c), _p(ws), ws.numel(), _stream()))
 
 
 def render_rays(net, frame, points, white_bkgd=False):

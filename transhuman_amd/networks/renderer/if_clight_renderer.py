@@ -143,14 +143,22 @@ class Renderer:
         return frame
 
     # ---- reference API -------------------------------------------------------------------
-    def render_fast(self, batch, is_train=True, frame=None, ray_slice=None):
-        """:429-484.  ``frame`` lets callers reuse per-frame constants;
-        ``ray_slice`` renders a sub-range of rays (multi-GPU sharding)."""
+    def render_fast(self, batch, is_train=True, frame=None, ray_slice=None, small_frame_rays=2400):
+        """:429-484.  ``frame`` lets callers reuse per-frame constants; ``ray_slice`` renders a sub-range of
+        rays (multi-GPU sharding); ``small_frame_rays`` is the R' threshold of :551 (-1 pins the masked
+        branch, used when a frame is sharded).
+        Without a ready ``frame`` the ray-only stage (hull mask, compaction) is queued first, then the
+        per-frame constants, then the shading: the sample count is on the host by the time it is needed."""
         cfg = get_cfg()
-        frame = frame if frame is not None else self.prepare_frame(batch)
         sl = slice(None) if ray_slice is None else ray_slice
         pts = hip.Points(batch["ray_o"][0][sl], batch["ray_d"][0][sl], batch["near"][0][sl], batch["far"][0][sl],
                          n_samples=cfg.N_samples)
+        if frame is None:
+            V = batch["input_imgs"][0].reshape(-1, *batch["input_imgs"][0].shape[2:]).shape[0]
+            if V <= 4 and pts.R > 0:
+                hip.render_prepass(pts, batch["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays)
+            frame = self.prepare_frame(batch)
+            frame.c.small_frame_rays = small_frame_rays
         rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd))
         self.last_stats = stats
         return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
