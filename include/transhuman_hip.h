@@ -292,8 +292,10 @@ int th_render_rays(th_ctx* ctx, const th_frame* f, const th_points* rays, float*
  * rule :551, compaction, view-direction embedding) ahead of time.  It needs only the rays and, of `f`, the
  * fields verts_world / n_verts / V / hull_thresh / small_frame_rays -- so it can be queued BEFORE the per-frame
  * constants (encoder, tokens) are produced; its sample count then reaches the host while that work runs and the
- * following th_render_rays (same ctx, same workspace, same ray arrays and stream) neither repeats the stage nor
- * stalls the queue on the read-back.  Results are identical with or without it. */
+ * following th_render_rays (same ctx, same workspace, same ray arrays) neither repeats the stage nor stalls the
+ * queue on the read-back.  `stream` may differ from the stream of th_render_rays (which waits on an event): on a
+ * side stream the hull pass fills the chip while the latency-bound encoder / TransHE launches run.  The caller
+ * orders the prepass after the previous use of the workspace.  Results are identical with or without it. */
 int th_render_prepass(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
                       size_t workspace_bytes, th_stream stream);
 

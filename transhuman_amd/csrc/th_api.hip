@@ -571,6 +571,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     int32_t* hp = c->host_pinned;
     if (prepass == 2) {
         hp = c->host_pinned + 16;
+        TH_HIP(hipStreamWaitEvent(s, c->prepass_ev, 0));      // the prepass may have run on another stream
         TH_HIP(hipEventSynchronize(c->prepass_ev));
     } else {
     ProfScope* sc = new ProfScope(pf, TH_PROF_HULL, s);
