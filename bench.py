@@ -137,7 +137,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="real", choices=["real", "dense"])
+    ap.add_argument("--workload", default="real", choices=["real", "dense", "orbit", "mesh"],
+                    help="real/dense: the headline frame (SURVEY 8d C2); orbit: C3, a new target camera every step, rays "
+                         "made on device (th_gen_rays); mesh: C5, sigma on a --grid^3 voxel grid (voxels/s)")
+    ap.add_argument("--grid", type=int, default=256)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--nc", type=int, default=500)
@@ -183,6 +186,9 @@ def main():
     shard = dict(batch)
     for k in ("ray_o", "ray_d", "near", "far"):
         shard[k] = batch[k][:, my_idx].contiguous()
+
+    if args.workload in ("orbit", "mesh"):
+        return run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_cpu, H, W, V)
 
     hit_buf = torch.zeros(1, dtype=torch.int64, device=dev)
     gatherer = ImageGatherer(my_idx, R, world) if dist_on else None      # shard layout exchanged once
@@ -270,6 +276,101 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(batch_cpu, assign, args.samples, stride=args.cpu_stride)
         print(json.dumps(res))
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_cpu, H, W, V):
+    """The two non-headline workloads of SURVEY 8d (their own metrics; no roofline / cpu_baseline blocks)."""
+    import math
+    from transhuman_amd import hip
+    if dist_on:
+        import torch.distributed as dist
+    verts = batch_cpu["tar_smpl_vertice"][0].numpy()
+    if args.workload == "orbit":
+        # C3: 60-view orbit around the body (run.py --type visualize): per step a new target camera -> rays on
+        # device (th_gen_rays, the reference's get_rays + get_near_far) -> the masked ray list is dealt to the
+        # ranks in contiguous 64-ray runs -> render -> one all_gather.
+        bounds = np.stack([verts.min(0), verts.max(0)]).astype(np.float32)
+        bounds[0, 2] -= 0.05; bounds[1, 2] += 0.05                                   # can_smpl.py:228-230
+        centre = 0.5 * (bounds[0] + bounds[1]).astype(np.float64)
+        K = np.array([[600.0 * W / 512, 0, W / 2], [0, 600.0 * W / 512, H / 2], [0, 0, 1]], np.float32)
+        n_views = 60
+
+        def camera(i):
+            th = 2 * math.pi * (i % n_views) / n_views
+            ca, sa = math.cos(th), math.sin(th)
+            R = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]], np.float64)
+            T = -R @ centre + np.array([0, 0, 3.0])
+            return K, R.astype(np.float32), T.reshape(3, 1).astype(np.float32)
+
+        def step(i):
+            rays = hip.gen_rays(*camera(i), bounds, H, W, device=dev)
+            n = rays["near"].numel()
+            mine = torch.arange(n, device=dev)
+            if world > 1:
+                mine = mine[((mine // 64) % world) == rank]
+            sh = dict(batch)
+            for k in ("ray_o", "ray_d", "near", "far"):
+                sh[k] = rays[k][mine][None]
+            out = renderer.render_fast(sh, small_frame_rays=-1 if dist_on else 2400)
+            local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
+            if dist_on:
+                from transhuman_amd.dist import gather_image
+                local = gather_image(local, mine, n, world)
+            img = torch.zeros((H * W, 5), dtype=torch.float32, device=dev)
+            img[rays["mask_at_box"]] = local
+            return img, n
+        units, unit_name = H * W, "rays/sec (512x512 orbit, 64 samples/ray, rays generated on device)"
+    else:
+        # C5: mesh extraction grid (if_mesh_renderer.py:46-100): sigma on grid^3 voxel centres over the body box,
+        # voxels dealt to the ranks in contiguous 4096-voxel runs
+        from transhuman_amd.networks.renderer.if_mesh_renderer import Renderer as MeshRenderer
+        mr = MeshRenderer(net, vertex_can=renderer.vertex_can.numpy(), pc2voxel_ind=renderer.pc2voxel_ind.cpu().numpy())
+        g = args.grid
+        mb = dict(batch_cpu)
+        mb["pts"] = synth.make_grid_pts(batch_cpu, g)
+        mb = synth.batch_to(mb, dev)
+        nvox = g * g * g
+        mine = torch.arange(nvox, device=dev)
+        if world > 1:
+            mine = mine[((mine // 4096) % world) == rank]
+
+        def step(i):
+            out = mr.render(mb, pts_slice=mine)
+            sig = out["sigma"]
+            if dist_on:
+                from transhuman_amd.dist import gather_image
+                sig = gather_image(sig[:, None], mine, nvox, world)[:, 0]
+            return sig, nvox
+        units, unit_name = nvox, f"voxels/sec ({g}^3 sigma grid)"
+
+    for i in range(args.warmup):
+        step(i)
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res, n_last = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist_on:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    if rank == 0:
+        print(json.dumps({
+            "metric": unit_name, "value": units * args.steps / dt, "unit": unit_name.split(" ")[0].replace("sec", "s"),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"S-{args.workload} (SURVEY 8d {'C3' if args.workload == 'orbit' else 'C5'}), V={V}, "
+                                   f"N_c={args.nc}", "units_last_step": int(n_last),
+                       "stats": {k: int(v) for k, v in (renderer.last_stats if args.workload == 'orbit' else mr.last_stats).items()},
+                       "parallelism": f"x{world}" if world > 1 else "single"}}))
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
