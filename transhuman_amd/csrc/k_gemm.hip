@@ -103,9 +103,11 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
         for (int i = 0; i < GEMM_PF; ++i)
             if (i < KB) load_b(i, bq[i]);
     }
-    for (int ch = 0; ch < nchunks; ++ch) {
+    // A chunk [BM][128]: fetched into registers one chunk ahead (the loads of chunk ch+1 fly while chunk ch
+    // multiplies), written to LDS at the top of its own iteration
+    float4 areg[2 * MT];
+    auto load_a = [&](int ch) {
         const int k0 = ch * GEMM_KC;
-        // ---- stage A[m0:m0+BM, k0:k0+128] -> LDS (zero fill outside M x Kreal) ----
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             int idx = tid + 256 * i;
@@ -124,9 +126,18 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
                     if (gk + 2 < Kreal) v.z = src[2];
                 }
             }
-            *reinterpret_cast<float4*>(&As[row * GEMM_LDS_STRIDE + 4 * c4]) = v;
+            areg[i] = v;
+        }
+    };
+    load_a(0);
+    for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+        for (int i = 0; i < 2 * MT; ++i) {
+            int idx = tid + 256 * i;
+            *reinterpret_cast<float4*>(&As[(idx >> 5) * GEMM_LDS_STRIDE + 4 * (idx & 31)]) = areg[i];
         }
         __syncthreads();
+        if (ch + 1 < nchunks) load_a(ch + 1);
         if (wave_active) {
             const int kb_lo = ch * (GEMM_KC / 16);
 #pragma unroll

@@ -89,23 +89,35 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mrun[r] = -3.0e38f; lrun[r] = 0.f; }
 
-    for (int k0 = 0; k0 < N; k0 += AT_K) {
-        __syncthreads();
-        // stage K and V tiles: 64 rows x 64 floats each = 1024 float4 per tile
+    // K / V tiles (64 keys x 64 floats each = 1024 float4 per tile): fetched into registers one tile ahead so
+    // the L2 round trip of tile t+1 overlaps the two MFMA passes and the softmax of tile t
+    float4 kreg[4], vreg[4];
+    auto fetch_kv = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int idx = tid + 256 * i;
             int row = idx >> 4, c4 = idx & 15;
             int key = k0 + row;
-            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            kreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vreg[i] = kreg[i];
             if (key < N) {
-                kv = *reinterpret_cast<const float4*>(base + (long long)key * ld + kcol + 4 * c4);
-                vv = *reinterpret_cast<const float4*>(base + (long long)key * ld + vcol + 4 * c4);
+                kreg[i] = *reinterpret_cast<const float4*>(base + (long long)key * ld + kcol + 4 * c4);
+                vreg[i] = *reinterpret_cast<const float4*>(base + (long long)key * ld + vcol + 4 * c4);
             }
-            *reinterpret_cast<float4*>(&Ks[row * AT_STR + 4 * c4]) = kv;
-            *reinterpret_cast<float4*>(&Vs[row * AT_STR + 4 * c4]) = vv;
+        }
+    };
+    fetch_kv(0);
+    for (int k0 = 0; k0 < N; k0 += AT_K) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int idx = tid + 256 * i;
+            int row = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<float4*>(&Ks[row * AT_STR + 4 * c4]) = kreg[i];
+            *reinterpret_cast<float4*>(&Vs[row * AT_STR + 4 * c4]) = vreg[i];
         }
         __syncthreads();
+        if (k0 + AT_K < N) fetch_kv(k0 + AT_K);
         // S = Q K^T : B[k=d][j=key]  lane (j = lane&15, kq = lane>>4) reads K[key][16kb+4kq .. +3]
         f32x4 sacc[4];
 #pragma unroll
