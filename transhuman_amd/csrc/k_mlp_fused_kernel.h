@@ -161,9 +161,21 @@ template <> struct FLay<1> { static constexpr int LD = 272, KA = 272, KB2 = 0, S
 #ifndef FM_RING_D2
 #define FM_RING_D2 4      // ... of the 1- and 2-column-tile phases
 #endif
-template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = (CT >= 3 ? FM_RING_D : FM_RING_D2), bool XPP = true>
-__device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const char* __restrict__ alo,
-                                           const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
+template <int CT, int RT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[CT][RT]) {
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[c][r][e] = 0.f;
+}
+
+//  * ZERO: the accumulators are cleared AFTER the first weight / activation fragments have been requested, so the
+//    96..144 accumulator writes run under that (otherwise exposed) L2 / LDS round trip.
+template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, bool ZERO>
+__device__ __forceinline__ void gemm_phase_impl(const char* __restrict__ ahi, const char* __restrict__ alo,
+                                                const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
     static_assert((D & 1) == 0, "ring depth must be even (activation ping-pong parity)");
     const uint4* wl = wp + lane;     // this wave's stream: per kb: CT x {hi, lo} x 64 lanes x 16 B
     const int aoff = (lane & 31) * STR + (lane >> 5) * 16;
@@ -174,6 +186,10 @@ __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const c
         if (j < KB) load_wfrag<CT>(wl, j, w[j]);
     load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, 0, xh[0], xl[0]);
     FM_SB();
+    if (ZERO) {
+        zero_acc<CT, RT>(acc);
+        FM_SB();
+    }
     int kb = 0;
 #pragma unroll 1
     for (; kb + D <= KB; kb += D) {
@@ -232,14 +248,17 @@ __device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const c
         }
 }
 
-template <int CT, int RT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[CT][RT]) {
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int r = 0; r < RT; ++r)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[c][r][e] = 0.f;
+// acc += W * A^T
+template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = (CT >= 3 ? FM_RING_D : FM_RING_D2), bool XPP = true>
+__device__ __forceinline__ void gemm_phase(const char* __restrict__ ahi, const char* __restrict__ alo,
+                                           const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
+    gemm_phase_impl<RT, CT, STR, ROWSTEP, D, XPP, false>(ahi, alo, wp, KB, lane, acc);
+}
+// acc = W * A^T
+template <int RT, int CT, int STR, int ROWSTEP = 32 * STR, int D = (CT >= 3 ? FM_RING_D : FM_RING_D2), bool XPP = true>
+__device__ __forceinline__ void gemm_phase_z(const char* __restrict__ ahi, const char* __restrict__ alo,
+                                             const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
+    gemm_phase_impl<RT, CT, STR, ROWSTEP, D, XPP, true>(ahi, alo, wp, KB, lane, acc);
 }
 
 // channel of accumulator register e (within a 32-wide column tile) for this lane
@@ -339,8 +358,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     stage_glds<V, 256, 256, STR256>(P.h, 0, pbase, npts, abuf, a256_lo, wave, lane);
     FM_SYNC();
     f32x16 acc2[2][V];
-    zero_acc<2, V>(acc2);
-    gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_0, wave, 2, 0), P.fc_0.KB, lane, acc2);
+    gemm_phase_z<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_0, wave, 2, 0), P.fc_0.KB, lane, acc2);
     FM_SYNC();
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -355,8 +373,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     float* ksb = reinterpret_cast<float*>(mbuf);                    // [ROWS][KSTR] fp32 keys of the token branch
     {
         f32x16 acc3[3][V];
-        zero_acc<3, V>(acc3);
-        gemm_phase<V, 3, STR256>(abuf, a256_lo, wslice(P.kv1, wave, 3, 0), P.kv1.KB, lane, acc3);
+        gemm_phase_z<V, 3, STR256>(abuf, a256_lo, wslice(P.kv1, wave, 3, 0), P.kv1.KB, lane, acc3);
         finish_tile<V>(acc3[0], P.kv1.bias, wave * 32, P.kv1.inv_scale, false, lane);
         finish_tile<V>(acc3[1], P.kv1.bias, 128 + wave * 64, P.kv1.inv_scale, false, lane);
         finish_tile<V>(acc3[2], P.kv1.bias, 128 + wave * 64 + 32, P.kv1.inv_scale, false, lane);
@@ -370,10 +387,9 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     FM_SYNC();
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
-    zero_acc<2, V>(acc2);
     stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
     FM_SYNC();
-    gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2);
+    gemm_phase_z<V, 2, FL::SA>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2);
     FM_SYNC();
     if constexpr (FL::NB > 0) {
         stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
@@ -392,8 +408,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     f32x16 vp[2][V];
     {
         f32x16 acc3[3][V];
-        zero_acc<3, V>(acc3);
-        gemm_phase<V, 3, STR256>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane, acc3);
+        gemm_phase_z<V, 3, STR256>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane, acc3);
         finish_tile<V>(acc3[0], P.kv0.bias, wave * 32, P.kv0.inv_scale, false, lane);
         finish_tile<V>(acc3[1], P.kv0.bias, 128 + wave * 64, P.kv0.inv_scale, false, lane);
         finish_tile<V>(acc3[2], P.kv0.bias, 128 + wave * 64 + 32, P.kv0.inv_scale, false, lane);
@@ -470,8 +485,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     }
 
     // ================= fc_2 (fc_1 is folded into the value projections) =================
-    zero_acc<2, V>(acc2);
-    gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_2, wave, 2, 0), P.fc_2.KB, lane, acc2);
+    gemm_phase_z<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_2, wave, 2, 0), P.fc_2.KB, lane, acc2);
     FM_SYNC();
     // inter = relu(.) -> ABUF (operand of feature_fc); its view mean -> MBUF (operand of fc_3)
 #pragma unroll
@@ -495,8 +509,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     // ================= sigma head: relu(fc_3 m) . alpha_w + b =================
     {
         f32x16 a1[2][1];
-        zero_acc<2, 1>(a1);
-        gemm_phase<1, 2, STR256, 32 * STR256, 6>(mbuf, mbuf + 32 * STR256, wslice(P.fc_3, wave, 2, 0), P.fc_3.KB, lane, a1);
+        gemm_phase_z<1, 2, STR256, 32 * STR256, 6>(mbuf, mbuf + 32 * STR256, wslice(P.fc_3, wave, 2, 0), P.fc_3.KB, lane, a1);
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -520,9 +533,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         // ================= RGB branch (cross_transformer.py:330-353) =================
         // feat = feature_fc(inter) + rgb_res_0(f)   (one accumulator: both layers share a scale)
         f32x16 r1[1][V];
-        zero_acc<2, V>(acc2);
-        zero_acc<1, V>(r1);
-        gemm_phase<V, 2, STR256>(abuf, a256_lo, wslice(P.feat, wave, 2, 0), P.feat.KB, lane, acc2);
+        gemm_phase_z<V, 2, STR256>(abuf, a256_lo, wslice(P.feat, wave, 2, 0), P.feat.KB, lane, acc2);
         FM_SYNC();
         // view directions of the tile (27 of 32 columns used), fetched now, split into MBUF after the f passes
         float vdv[4];
@@ -539,7 +550,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
         FM_SYNC();
         gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.rr0, wave, 2, 0), FL::NA, lane, acc2);
-        gemm_phase<V, 1, FL::SA, 32 * FL::SA, 6>(abuf, fa_lo, wslice(P.rr1, wave, 1, 0), FL::NA, lane, r1);
+        gemm_phase_z<V, 1, FL::SA, 32 * FL::SA, 6>(abuf, fa_lo, wslice(P.rr1, wave, 1, 0), FL::NA, lane, r1);
         FM_SYNC();
         if constexpr (FL::NB > 0) {
             stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
@@ -579,8 +590,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         FM_SYNC();
         // view_fc over [feat(256) | viewdir(27 -> 32)]: 16 k-blocks from ABUF + 2 from the shared viewdir rows
         f32x16 vf[1][V];
-        zero_acc<1, V>(vf);
-        gemm_phase<V, 1, STR256, 32 * STR256, 6>(abuf, a256_lo, wslice(P.vfc, wave, 1, 0), 16, lane, vf);
+        gemm_phase_z<V, 1, STR256, 32 * STR256, 6>(abuf, a256_lo, wslice(P.vfc, wave, 1, 0), 16, lane, vf);
         gemm_phase<V, 1, STRVD, 0>(vd_hi, vd_lo, wslice(P.vfc, wave, 1, 16), 2, lane, vf);
         finish_tile<V>(vf[0], P.vfc.bias, wave * 32, P.vfc.inv_scale, true, lane);
         finish_tile<V>(r1[0], P.rr1.bias, wave * 32, P.rr1.inv_scale, false, lane);
@@ -599,8 +609,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         }
         FM_SYNC();
         f32x16 a4[1][1];
-        zero_acc<1, 1>(a4);
-        gemm_phase<1, 1, STR128, 32 * STR128, 8>(f4_hi, f4_lo, wslice(P.fc_4, wave, 1, 0), P.fc_4.KB, lane, a4);
+        gemm_phase_z<1, 1, STR128, 32 * STR128, 8>(f4_hi, f4_lo, wslice(P.fc_4, wave, 1, 0), P.fc_4.KB, lane, a4);
         finish_tile<1>(a4[0], P.fc_4.bias, wave * 32, P.fc_4.inv_scale, true, lane);
         float s3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
