@@ -91,7 +91,7 @@ int th_set_mlp_weights(th_ctx* ctx, const th_mlp_weights* w, th_stream stream);
  * v_mfma_f32_32x32x16_f16 with fp16 hi/lo operand splitting (3 products, fp32 accumulate: fp32-class
  * accuracy); 0 = one fp32-MFMA GEMM launch per layer (exact fp32 products; also the path for V = 4). */
 int th_set_mlp_mode(th_ctx* ctx, int mode);
-/* Samples shaded per pass of the per-sample stage (process-wide; default 262144, the reference's
+/* Samples shaded per pass of the per-sample stage (process-wide; default 524288, the reference's
  * batchify_rays chunk is 32768, if_clight_renderer.py:575).  Results do not depend on it; workspace
  * sizes do, so call it before the *_workspace_bytes() queries. */
 int th_set_chunk_samples(int n);

@@ -69,4 +69,4 @@ def test_no_fallback_without_a_device(lib):
 def test_errors_are_reported_not_crashed(lib):
     bad = lib.th_set_chunk_samples(3)
     assert bad != 0 and b"chunk" in lib.th_last_error()
-    assert lib.th_set_chunk_samples(262144) == 0
+    assert lib.th_set_chunk_samples(524288) == 0

@@ -415,13 +415,15 @@ int th_view_embed(th_ctx* c, const float* d, int R, int res, float* out, th_stre
 // ---------------------------------------------------------------------------
 // Samples per pass of the per-sample stage.  The reference chunks at 32768 (batchify_rays :575) to fit a
 // 2021 GPU; results are chunk-size invariant (the network is strictly per-sample).  With 288 GB of HBM a
-// pass of 256 Ki samples (2 GB of h/f staging) keeps every launch >= 8 waves of tiles per CU: measured
-// DPaRF 10.7 -> 3.2 ms/frame vs 32 Ki chunks.  th_set_chunk_samples() / TH_CHUNK_SAMPLES override.
+// pass of 512 Ki samples (3.3 GB of h/f rows; 12 GB of workspace incl. the per-layer path's scratch) makes every
+// launch several full waves of workgroups: the DPaRF kernel (6 workgroups/CU resident) loses a third of a 256 Ki
+// launch to its partial last wave.  Measured frame 58 -> 33.1 -> 32.1 ms for 32 Ki / 256 Ki / 512 Ki chunks (1 Mi: no
+// further gain).  th_set_chunk_samples() / TH_CHUNK_SAMPLES override.
 static int th_chunk_init() {
     const char* e = getenv("TH_CHUNK_SAMPLES");
     long v = e ? atol(e) : 0;
     if (v >= 1024 && v <= (1L << 24)) return (int)v;
-    return 262144;
+    return 524288;
 }
 static int TH_CHUNK = th_chunk_init();
 

@@ -603,7 +603,7 @@ def set_mlp_mode(mode, device=None):
 
 
 def set_chunk_samples(n):
-    """Samples per pass of the per-sample stage (default 262144; results are invariant to it)."""
+    """Samples per pass of the per-sample stage (default 524288; results are invariant to it)."""
     _check(load_library().th_set_chunk_samples(int(n)))
 
 
