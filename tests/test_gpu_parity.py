@@ -499,3 +499,28 @@ def test_prepass_equals_plain_render(hip, gpu, net):
     auto = r.render_fast(b)                               # prepass -> prepare_frame -> shading
     assert r.last_stats == st0
     assert maxdiff(auto["rgb_map"][0].cpu(), rgb0.cpu()) < 1e-5    # (frame constants recomputed: MIOpen conv order)
+
+
+def test_weight_updates_are_picked_up(hip, gpu, net):
+    """the per-frame weight check (version counters of a cached parameter list) sees in-place updates
+    (optimiser step / load_state_dict) and re-uploads the packed images"""
+    g = gold("g8_forward")
+    torch.manual_seed(0)
+    P = 512
+    pf = torch.randn(3, 384, P, device=gpu)
+    vd = torch.randn(P, 27, device=gpu)
+    ps = torch.randn(P, 3, device=gpu) * 0.3
+    cen = torch.randn(300, 3, device=gpu) * 0.4
+    rot = torch.eye(3, device=gpu).reshape(1, 9).repeat(300, 1)
+    tok = torch.randn(3, 300, 192, device=gpu)
+    raw0 = hip.network_forward(net, pf, vd, ps, cen, rot, tok)
+    with torch.no_grad():
+        net.alpha_fc.bias.add_(0.25)
+    try:
+        raw1 = hip.network_forward(net, pf, vd, ps, cen, rot, tok)
+        assert maxdiff((raw1[:, 3] - raw0[:, 3]).cpu(), torch.full((P,), 0.25)) < 1e-5
+    finally:
+        with torch.no_grad():
+            net.alpha_fc.bias.sub_(0.25)
+    raw2 = hip.network_forward(net, pf, vd, ps, cen, rot, tok)
+    assert torch.equal(raw2, raw0)
