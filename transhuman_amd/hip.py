@@ -281,13 +281,22 @@ class Points:
         self.ray_o, self.ray_d = _f32(ray_o).reshape(-1, 3), _f32(ray_d).reshape(-1, 3)
         self.near, self.far = _f32(near).reshape(-1), _f32(far).reshape(-1)
         dev = self.ray_o.device
-        # t_vals exactly as torch.linspace builds them (if_clight_renderer.py:273-274)
-        t = torch.linspace(0.0, 1.0, steps=n_samples)
-        self.t = t.to(dev)
-        self.omt = (1.0 - t).to(dev)
+        # t_vals exactly as torch.linspace builds them (if_clight_renderer.py:273-274); cached per (S, device)
+        self.t, self.omt = _t_vals(n_samples, dev)
         self.R, self.S = self.ray_o.shape[0], n_samples
         self.c = ThPoints(None, _p(self.ray_o), _p(self.ray_d), _p(self.near), _p(self.far), _p(self.t), _p(self.omt),
                           self.R, self.S)
+
+
+_t_cache = {}
+
+
+def _t_vals(n_samples, dev):
+    key = (int(n_samples), str(dev))
+    if key not in _t_cache:
+        t = torch.linspace(0.0, 1.0, steps=n_samples)
+        _t_cache[key] = (t.to(dev), (1.0 - t).to(dev))
+    return _t_cache[key]
 
 
 def hull_mask(points, verts_world, thresh=0.1):
@@ -312,7 +321,13 @@ def feat_scale(scale_np, image_shape, device):
     """sample_from_feature_map, if_clight_renderer.py:193-195 (float64 divide, cast to fp32)."""
     import numpy as np
     s = np.asarray(scale_np, dtype=np.float64) / np.asarray(image_shape, dtype=np.float64)
-    return torch.tensor(s).to(dtype=torch.float32, device=device)
+    key = (float(s[0]), float(s[1]), str(device))
+    if key not in _scale_cache:
+        _scale_cache[key] = torch.tensor(s).to(dtype=torch.float32, device=device)
+    return _scale_cache[key]
+
+
+_scale_cache = {}
 
 
 def csr_to_device(offsets, members, device):
