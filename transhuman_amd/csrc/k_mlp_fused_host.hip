@@ -249,8 +249,6 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     static int dbg_state = getenv("TH_FUSED_DBG") ? 1 : 0;
     static long long* dbg_dev = nullptr;
     p.dbg = nullptr;
-    static int skew = getenv("TH_FUSED_SKEW") ? atoi(getenv("TH_FUSED_SKEW")) : 12000;
-    p.skew_cycles = (grid.x >= 1024) ? skew : 0;     // only worth it when every CU runs several tiles
     const bool dbg_now = dbg_state == 1 && P >= 4096;
     if (dbg_now) {
         if (!dbg_dev) TH_HIP(hipMalloc((void**)&dbg_dev, 64 * sizeof(long long)));

@@ -334,15 +334,6 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     const int npts = min(FM_PTS, P.P - pbase);
     constexpr int ROWS = 32 * V;
     const int myrow = lane & 31;
-    // De-phase the CUs once per launch: all workgroups do identical work, so without a skew every CU
-    // hits its HBM staging bursts (96..147 KB each) at the same instant and the bursts run bandwidth-bound
-    // while the matrix pipes idle.  The first wave of workgroups starts staggered by up to ~15 x 12k
-    // cycles; later workgroups inherit the skew (they start when an earlier one retires).
-    if (P.skew_cycles > 0 && blockIdx.x < 256) {
-        long long t0 = clock64();
-        long long wait = (long long)(blockIdx.x & 15) * P.skew_cycles;
-        while (clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
     int dbg_i = 1;                      // dbg[0] counts sampled tiles, dbg[i] accumulates the cycles of interval i
     long long dbg_t = 0;
     if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {

@@ -200,7 +200,6 @@ struct FusedParams {
     int P;
     int rgb_all;
     long long* dbg;     // optional cycle stamps (TH_FUSED_DBG)
-    int skew_cycles;    // start-up stagger unit of the first 256 workgroups (0 = off)
 };
 size_t th_fused_pack_bytes();
 // folded: nullptr or the three colour-folded fp32 layers {alpha_res_0, rgb_res_0, rgb_res_1} (in_f 260)
