@@ -539,7 +539,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             sig[tid] = part[tid * 4] + part[(32 + tid) * 4] + part[(64 + tid) * 4] + part[(96 + tid) * 4] + P.alpha_b[0];
         if (tid == 0) *flag = 0;
         FM_SYNC();
-        if (tid < npts && (P.rgb_all || sig[tid] > 0.f)) *flag = 1;
+        // rgb_all: 0 progressive (sigma > 0 only, :296-305), 1 every sample (MLP_forward_ori), 2 none (sigma grid)
+        if (tid < npts && P.rgb_all != 2 && (P.rgb_all == 1 || sig[tid] > 0.f)) *flag = 1;
         FM_SYNC();
     }
     const bool need_rgb = *flag != 0;

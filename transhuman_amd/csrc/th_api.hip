@@ -623,7 +623,9 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
             ProfScope ps3(pf, TH_PROF_MLP, s);
             // ray mode: the [R,27] embedding table is indexed sample -> ray (sel / S); mesh mode: zero rows (cb.vdc)
             if (ray_mode) TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, vd_all, sel, S, unmasked, s));
-            else TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, cb.vdc, nullptr, 1, unmasked, s));
+            // (the sigma grid never looks at colour: skip the RGB branch, which the reference evaluates and drops,
+            // if_mesh_renderer.py:84-99)
+            else TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, cb.vdc, nullptr, 1, 2, s));
         }
         ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));

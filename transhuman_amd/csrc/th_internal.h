@@ -198,7 +198,7 @@ struct FusedParams {
     int vd_div;
     float* raw_c;       // [P][4]
     int P;
-    int rgb_all;
+    int rgb_all;        // 0: RGB where sigma > 0, 1: everywhere, 2: nowhere (sigma-only consumers)
     long long* dbg;     // optional cycle stamps (TH_FUSED_DBG)
 };
 size_t th_fused_pack_bytes();
