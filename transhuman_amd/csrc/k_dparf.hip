@@ -14,8 +14,11 @@
 //   one ordered scan; softmax weights and the 7 rotated offsets go to LDS.
 //  Phase 2 (wave per sample, 32 samples per wave): lanes 0..47 fetch a token row as one float4 each
 //   (768 B coalesced, L2-resident table), lanes 0..62 evaluate one PE channel each (7 sines, dp_sin).
-// Output rows [sample][view][256] (255 + zero pad) feed fc_0; SPLIT = true writes them as 256 fp16 hi halves +
-// 256 fp16 lo halves (the fused MLP kernel's LDS-DMA operand format), same 1 KiB per row.
+// Output rows [sample][view][256] (255 + zero pad) feed fc_0.
+// FOLDED = true (fused MLP path): `tokens` is the per-frame table T' = tokens fc_0[:, :192]^T, 256 wide; since
+// fc_0 is linear, fc_0(h)'s token part is the same neighbour blend applied to T' rows.  Then out = that blend,
+// fp32 [sample][view][256] (64 lanes x float4: every lane busy), and pe_out = the blended 63-wide positional
+// encoding, ONE split-f16 row (64 hi + 64 lo halves) per sample -- it is the same for every view.
 // Bound: L2 gather of 7*V*768 B per sample; HBM write 3 KB per sample.
 #include "th_internal.h"
 
@@ -62,14 +65,15 @@ __device__ __forceinline__ float dp_sin(float a) {
     return __builtin_amdgcn_sinf(r * 0.15915494309189535f);   // v_sin_f32 takes revolutions
 }
 
-template <bool SPLIT>
+template <bool FOLDED>
 __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restrict__ pts_smpl, ThPointSrc ps,
                                                            const float* __restrict__ Rh, const float* __restrict__ Th,
                                                            const int32_t* __restrict__ sel, int P,
                                                            const float* __restrict__ centres,
                                                            const float* __restrict__ rot,
                                                            const float* __restrict__ tokens, int V, int nc,
-                                                           float alpha, float* __restrict__ out) {
+                                                           float alpha, float* __restrict__ out,
+                                                           float* __restrict__ pe_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* cen = lds;                                   // [nc*3]
     DpNbr* nb = reinterpret_cast<DpNbr*>(lds + ((nc * 3 + 3) & ~3));
@@ -176,6 +180,27 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                 pe = (k == 0) ? w[k] * val : fmaf(w[k], val, pe);
             }
         }
+        if (FOLDED) {
+            for (int v = 0; v < V; ++v) {
+                const float* tv = tokens + (long long)v * nc * 256;
+                float4 r[DP_K];
+#pragma unroll
+                for (int k = 0; k < DP_K; ++k) r[k] = *reinterpret_cast<const float4*>(tv + (long long)id[k] * 256 + 4 * lane);
+                float4 acc = make_float4(w[0] * r[0].x, w[0] * r[0].y, w[0] * r[0].z, w[0] * r[0].w);
+#pragma unroll
+                for (int k = 1; k < DP_K; ++k) {
+                    acc.x = fmaf(w[k], r[k].x, acc.x); acc.y = fmaf(w[k], r[k].y, acc.y);
+                    acc.z = fmaf(w[k], r[k].z, acc.z); acc.w = fmaf(w[k], r[k].w, acc.w);
+                }
+                *reinterpret_cast<float4*>(out + ((long long)gp * V + v) * 256 + 4 * lane) = acc;
+            }
+            _Float16* ph = reinterpret_cast<_Float16*>(pe_out) + (long long)gp * 128;
+            _Float16 x, y;
+            dp_split((lane < 63) ? pe : 0.f, x, y);
+            ph[lane] = x;
+            ph[64 + lane] = y;
+            continue;
+        }
         for (int v = 0; v < V; ++v) {
             const float* tv = tokens + (long long)v * nc * 192;
             float* o = out + ((long long)gp * V + v) * 256;
@@ -189,35 +214,16 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                     acc.x = fmaf(w[k], r[k].x, acc.x); acc.y = fmaf(w[k], r[k].y, acc.y);
                     acc.z = fmaf(w[k], r[k].z, acc.z); acc.w = fmaf(w[k], r[k].w, acc.w);
                 }
-                if (!SPLIT) *reinterpret_cast<float4*>(o + 4 * lane) = acc;
-                else {
-                    _Float16* oh = reinterpret_cast<_Float16*>(o);       // hi [0,256) | lo [256,512)
-                    dp_h4 a, b;
-                    _Float16 x, y;
-                    dp_split(acc.x, x, y); a[0] = x; b[0] = y;
-                    dp_split(acc.y, x, y); a[1] = x; b[1] = y;
-                    dp_split(acc.z, x, y); a[2] = x; b[2] = y;
-                    dp_split(acc.w, x, y); a[3] = x; b[3] = y;
-                    *reinterpret_cast<dp_h4*>(oh + 4 * lane) = a;
-                    *reinterpret_cast<dp_h4*>(oh + 256 + 4 * lane) = b;
-                }
+                *reinterpret_cast<float4*>(o + 4 * lane) = acc;
             }
-            const float pv = (lane < 63) ? pe : 0.f;
-            if (!SPLIT) o[192 + lane] = pv;
-            else {
-                _Float16* oh = reinterpret_cast<_Float16*>(o);
-                _Float16 x, y;
-                dp_split(pv, x, y);
-                oh[192 + lane] = x;
-                oh[256 + 192 + lane] = y;
-            }
+            o[192 + lane] = (lane < 63) ? pe : 0.f;
         }
     }
 }
 
 int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh, const float* Th,
                     const int32_t* sel, int P, const float* centres, const float* rot, const float* tokens, int V,
-                    int nc, float alpha, float* out, int fmt, hipStream_t s) {
+                    int nc, float alpha, float* out, float* pe_out, int fmt, hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(nc >= DP_K, "need at least 7 token centres");
     ThPointSrc src;
@@ -230,12 +236,13 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
         TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    if (fmt == TH_ROWS_SPLIT)
+    TH_REQUIRE(fmt == TH_ROWS_F32 || (fmt == TH_ROWS_FOLDED && pe_out != nullptr), "K4 writes fp32 rows or the folded form");
+    if (fmt == TH_ROWS_FOLDED)
         hipLaunchKernelGGL(dparf_kernel<true>, dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
-                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out);
+                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out);
     else
         hipLaunchKernelGGL(dparf_kernel<false>, dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
-                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out);
+                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -160,7 +160,15 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
 #define PACK_SIMPLE(LAYER, L, N_, K_, CT_, COLS)                                       \
     TH_TRY(layer_scale_log2((L).w, (long long)(N_) * (K_), amax, &sl2, s));            \
     TH_TRY(pack_layer((L).w, (L).b, N_, K_, CT_, COLS, sl2, cur, &out->LAYER, s))
-    PACK_SIMPLE(fc_0, w->fc_0, 256, 255, 2, c256);
+    {   // fc_0: only the 63 positional-encoding columns [192, 255) stay in the kernel (token columns -> T', th_api.hip)
+        float* wpe = nullptr;
+        TH_HIP(hipMalloc((void**)&wpe, 256 * 63 * 4));
+        TH_HIP(hipMemcpy2DAsync(wpe, 63 * 4, w->fc_0.w + 192, 255 * 4, 63 * 4, 256, hipMemcpyDeviceToDevice, s));
+        TH_TRY(layer_scale_log2(wpe, 256LL * 63, amax, &sl2, s));
+        TH_TRY(pack_layer(wpe, w->fc_0.b, 256, 63, 2, c256, sl2, cur, &out->fc_0pe, s));
+        TH_HIP(hipStreamSynchronize(s));
+        TH_HIP(hipFree(wpe));
+    }
     PACK_SIMPLE(ar0, w->alpha_res_0, 256, 384, 2, c256);
     PACK_SIMPLE(fc_1, w->fc_1, 256, 256, 2, c256);
     PACK_SIMPLE(fc_2, w->fc_2, 256, 256, 2, c256);
@@ -216,8 +224,8 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
     return 0;
 }
 
-int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const void* h, const void* f,
-                         int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all, float* raw_c,
+int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
+                         const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all, float* raw_c,
                          hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(V >= 1 && V <= 3, "fused MLP supports 1..3 reference views");
@@ -227,7 +235,7 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     FusedParams p = base;
     if (cf) { p.ar0 = base.ar0c; p.rr0 = base.rr0c; p.rr1 = base.rr1c; }
     p.alpha_w = heads.alpha_w; p.alpha_b = heads.alpha_b; p.rgb_w = heads.rgb_w; p.rgb_b = heads.rgb_b;
-    p.h = (const _Float16*)h; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
+    p.stok = stok; p.pe = (const _Float16*)pe; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
     static bool attr = false;
     if (!attr) {
 #define FM_ATTR(V_, F_)                                                                                       \
@@ -242,7 +250,7 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     // so the weight working set is 256 KB -> shows how much of a phase is L2-capacity/latency
     static int alias_w = getenv("TH_FUSED_ALIAS_W") ? 1 : 0;
     if (alias_w) {
-        FusedLayer* ls[] = {&p.fc_0, &p.kv1, &p.ar0, &p.kv0, &p.fc_2, &p.fc_3, &p.feat, &p.rr0, &p.vfc, &p.rr1, &p.fc_4};
+        FusedLayer* ls[] = {&p.kv1, &p.ar0, &p.kv0, &p.fc_2, &p.fc_3, &p.feat, &p.rr0, &p.vfc, &p.rr1, &p.fc_4};
         for (auto* l : ls) l->w = p.fc_1.w;
     }
     // developer aid: TH_FUSED_DBG=1 -> average cycles between barriers over every 16th tile (first big launch only)

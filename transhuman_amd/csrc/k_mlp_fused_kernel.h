@@ -9,9 +9,9 @@
 //   MBUF   50 688  ks (fp32 keys of the token branch, parked here so they do not occupy accumulators
 //                  during the pixel branch) -> later the view-mean operand of fc_3 -> later viewdir + fc_4 operand
 //   MISC    3 744  softmax probabilities, sigma, cross-wave partial sums
-// Inputs h and f arrive from the producer kernels (k_dparf / k_pixfeat) already split into fp16 hi|lo
-// halves per row, so an operand is staged by global_load_lds_dwordx4 (LDS-DMA): no staging registers,
-// no conversion pass, no ds_write.
+// The pixel features f arrive from the producer kernel (k_pixfeat) already split into fp16 hi|lo halves per
+// row, so that operand is staged by global_load_lds_dwordx4 (LDS-DMA): no staging registers, no conversion
+// pass, no ds_write.  The token-branch input arrives pre-multiplied (see the token branch below).
 #pragma once
 #include <hip/hip_fp16.h>
 
@@ -27,6 +27,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define STR256 528   // K = 256
 #define STR192 400   // K = 192
 #define STR128 272   // K = 128
+#define STR64 144    // K = 64 (positional-encoding rows of fc_0)
 #define STRVD 80     // K = 32 (view-direction block of view_fc)
 #define KSTR 132     // floats per row of the fp32 key buffers
 
@@ -346,17 +347,65 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     char* fb_lo = abuf + ROWS * FL::SB;
 
     // ================= token branch: s = relu(fc_0 h); ks|vs = kv1(s) =================
-    stage_glds<V, 256, 256, STR256>(P.h, 0, pbase, npts, abuf, a256_lo, wave, lane);
-    FM_SYNC();
+    // fc_0 is linear and h = sum_k w_k [token_v[k] | PE_k]: the token part of fc_0(h) is sum_k w_k (W_tok token_v[k]),
+    // i.e. the SAME 7-neighbour blend applied to the per-frame table T' = tokens W_tok^T (one small GEMM per frame,
+    // th_api.hip).  K4 therefore hands over `stok` = that blend (fp32, [P][V][256]) and the blended 63-wide
+    // positional encoding `pe` (one split-f16 row per SAMPLE: it is the same for every view); what is left of
+    // fc_0 here is W_pe pe: 4 k-blocks on 32 rows instead of 16 k-blocks on 32*V rows.
+    // Issue order matters (vmcnt returns in order): pe rows and the 4 weight blocks first, then the 96 KB of
+    // stok straight into the accumulator layout -- the small GEMM runs while stok is still arriving.
     f32x16 acc2[2][V];
-    gemm_phase_z<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_0, wave, 2, 0), P.fc_0.KB, lane, acc2);
-    FM_SYNC();
+    {
+        char* pe_hi = abuf;
+        char* pe_lo = abuf + 32 * STR64;
+        // pe: 32 rows x (64 hi | 64 lo halves) = 8 KiB: one 16-byte piece per thread and plane
+        const int prow = tid >> 3, pc = tid & 7;
+        const int psrc = min(prow, npts - 1);
+        const uint4 pe_h = *reinterpret_cast<const uint4*>(P.pe + (long long)(pbase + psrc) * 128 + 8 * pc);
+        const uint4 pe_l = *reinterpret_cast<const uint4*>(P.pe + (long long)(pbase + psrc) * 128 + 64 + 8 * pc);
+        uint4 wq[4][2][2];
+        const uint4* wl = wslice(P.fc_0pe, wave, 2, 0) + lane;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        finish_tile<V>(acc2[c], P.fc_0.bias, wave * 64 + c * 32, P.fc_0.inv_scale, true, lane);
+        for (int kb = 0; kb < 4; ++kb) load_wfrag<2>(wl, kb, wq[kb]);
+        float4 st[2][V][4];
+        const int srow = min(myrow, npts - 1);
 #pragma unroll
-        for (int r = 0; r < V; ++r)
-            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < V; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    st[c][r][g] = *reinterpret_cast<const float4*>(P.stok + ((long long)(pbase + srow) * V + r) * 256 +
+                                                                   wave * 64 + c * 32 + 8 * g + 4 * (lane >> 5));
+        FM_SB();
+        *reinterpret_cast<uint4*>(pe_hi + prow * STR64 + 16 * pc) = pe_h;
+        *reinterpret_cast<uint4*>(pe_lo + prow * STR64 + 16 * pc) = pe_l;
+        FM_SYNC();
+        f32x16 a1[2][1];
+        zero_acc<2, 1>(a1);
+        const int aoff = (lane & 31) * STR64 + (lane >> 5) * 16;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            h8 xh[1], xl[1];
+            load_xfrag<1, STR64, 0>(pe_hi, pe_lo, aoff, kb, xh, xl);
+            mfma_kblock<1, 2>(wq[kb], xh, xl, a1);
+        }
+        FM_SYNC();                                   // every wave has read the pe rows: ABUF may take s
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            finish_tile<1>(a1[c], P.fc_0pe.bias, wave * 64 + c * 32, P.fc_0pe.inv_scale, false, lane);
+#pragma unroll
+            for (int r = 0; r < V; ++r) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    acc2[c][r][4 * g + 0] = fmaxf(a1[c][0][4 * g + 0] + st[c][r][g].x, 0.f);
+                    acc2[c][r][4 * g + 1] = fmaxf(a1[c][0][4 * g + 1] + st[c][r][g].y, 0.f);
+                    acc2[c][r][4 * g + 2] = fmaxf(a1[c][0][4 * g + 2] + st[c][r][g].z, 0.f);
+                    acc2[c][r][4 * g + 3] = fmaxf(a1[c][0][4 * g + 3] + st[c][r][g].w, 0.f);
+                }
+                store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+            }
+        }
     }
     FM_SYNC();
     // kv layers: column tile 0 = key tile `wave` (cols wave*32..), tiles 1,2 = value cols 128 + wave*64 ..

@@ -139,6 +139,11 @@ int th_set_mlp_weights(th_ctx* c, const th_mlp_weights* w, th_stream stream) {
     if (have_lift) total += 2 * ThPacked::bytes(256, 260) + ThPacked::bytes(128, 260);
     const size_t cfold_off = total;
     if (have_lift) total += 3 * th_align((size_t)(256 * 260 + 256) * sizeof(float));
+    // token columns of fc_0 (no bias): packed layer + contiguous [256,192] copy
+    const size_t tokpk_off = total;
+    total += ThPacked::bytes(256, 192);
+    const size_t tokw_off = total;
+    total += th_align((size_t)256 * 192 * sizeof(float));
     size_t heads_off = total;
     total += th_align((256 + 1 + 3 * 128 + 3) * sizeof(float));
     size_t tmp_off = total;
@@ -177,6 +182,12 @@ int th_set_mlp_weights(th_ctx* c, const th_mlp_weights* w, th_stream stream) {
     else TH_HIP(hipMemsetAsync(M.alpha_b, 0, 4, s));
     if (w->rgb_fc.b) TH_HIP(hipMemcpyAsync(M.rgb_b, w->rgb_fc.b, 12, hipMemcpyDeviceToDevice, s));
     else TH_HIP(hipMemsetAsync(M.rgb_b, 0, 12, s));
+    {
+        float* tw = (float*)(base + tokw_off);
+        TH_HIP(hipMemcpy2DAsync(tw, 192 * 4, w->fc_0.w, 255 * 4, 192 * 4, 256, hipMemcpyDeviceToDevice, s));
+        th_linear tok{tw, nullptr, 256, 192};
+        TH_TRY(th_pack_linear(tok, base + tokpk_off, &M.fc_0tok, s));
+    }
     th_linear folded[3] = {};
     M.compact_ready = false;
     if (have_lift) {
@@ -361,8 +372,8 @@ int th_vit_forward(th_ctx* c, const float* x, const float* pe, int V, int N, flo
 int th_dparf_encode(th_ctx* c, const float* pts, const int32_t* sel, int P, const float* centres, const float* rot,
                     const float* tokens, int V, int nc, float* out, th_stream stream) {
     TH_REQUIRE(c && pts && centres && rot && tokens && out, "null argument");
-    return th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, P, centres, rot, tokens, V, nc, 0.5f, out, TH_ROWS_F32,
-                           (hipStream_t)stream);
+    return th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, P, centres, rot, tokens, V, nc, 0.5f, out, nullptr,
+                           TH_ROWS_F32, (hipStream_t)stream);
 }
 
 int th_nchw_to_nhwc(th_ctx* c, const float* src, int V, int C, int H, int W, float* dst, th_stream stream) {
@@ -435,13 +446,14 @@ int th_set_chunk_samples(int n) {
 
 struct ChunkBufs {
     float *h, *f, *vdc, *raw_c;
+    float* pe;          // [CH][2][64] halves: blended positional encoding of the folded K4 form
     void* mlp_ws;
     size_t mlp_ws_bytes;
 };
 static size_t chunk_bytes(int V, int CH) {
     size_t rows = (size_t)V * CH;
     return th_align(rows * 256 * 4) + th_align(rows * 384 * 4) + th_align((size_t)CH * 27 * 4) +
-           th_align((size_t)CH * 4 * 4) + th_mlp_ws(V, CH);
+           th_align((size_t)CH * 4 * 4) + th_align((size_t)CH * 64 * 4) + th_mlp_ws(V, CH);
 }
 static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
     size_t rows = (size_t)V * CH;
@@ -449,6 +461,7 @@ static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
     b->f = ar.take<float>(rows * 384);
     b->vdc = ar.take<float>((size_t)CH * 27);
     b->raw_c = ar.take<float>((size_t)CH * 4);
+    b->pe = ar.take<float>((size_t)CH * 64);
     b->mlp_ws_bytes = th_mlp_ws(V, CH);
     b->mlp_ws = ar.take<char>(b->mlp_ws_bytes);
     TH_REQUIRE(b->mlp_ws != nullptr, "workspace too small");
@@ -458,7 +471,17 @@ static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
 // K6 dispatch: fused fp16x3-split kernel (default, V <= 3) or the layer-by-layer fp32 MFMA form
 // which K6 form runs for V views, and therefore which row format the producers must emit into cb.h / cb.f
 static bool mlp_is_fused(const th_ctx* c, int V) { return c->mlp_mode == 1 && c->fused_ready && V <= 3; }
-static int mlp_row_format(const th_ctx* c, int V) { return mlp_is_fused(c, V) ? TH_ROWS_SPLIT : TH_ROWS_F32; }
+static int mlp_row_format(const th_ctx* c, int V) { return mlp_is_fused(c, V) ? TH_ROWS_SPLIT : TH_ROWS_F32; }      // K5
+static int dparf_row_format(const th_ctx* c, int V) { return mlp_is_fused(c, V) ? TH_ROWS_FOLDED : TH_ROWS_F32; }   // K4
+// Fused path: per-frame table T' = tokens fc_0[:, :192]^T ([V*N_c, 256] fp32, one small GEMM) that K4 blends instead
+// of the raw tokens (fc_0 is linear; see the token branch of the fused kernel).  Returns the table K4 must read.
+static int token_table(th_ctx* c, const float* tokens, int V, int nc, float* tprime, const float** table, hipStream_t s) {
+    *table = tokens;
+    if (!mlp_is_fused(c, V)) return 0;
+    TH_TRY(th_gemm(tokens, 192, V * nc, c->mlp.fc_0tok, TH_ACT_NONE, tprime, 256, s));
+    *table = tprime;
+    return 0;
+}
 
 // f_ld: floats per pixel-feature row of cb.f (384 full / 272 compact).  View directions: `vd_table` rows are
 // addressed as vd_sel[p] / vd_div (vd_sel == nullptr: row p); the fused kernel reads the table in place, the
@@ -467,8 +490,8 @@ static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, 
                         const int32_t* vd_sel, int vd_div, int rgb_all, hipStream_t s) {
     TH_REQUIRE(c->mlp.ready, "MLP weights not set (th_set_mlp_weights)");
     if (mlp_is_fused(c, V))
-        return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.f, f_ld, vd_table, vd_sel, vd_div, rgb_all, cb.raw_c,
-                                    s);
+        return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.pe, cb.f, f_ld, vd_table, vd_sel, vd_div, rgb_all,
+                                    cb.raw_c, s);
     const float* vd = vd_table;
     if (vd_sel != nullptr || vd_table != cb.vdc) {
         TH_TRY(th_gather_rows_launch(vd_table, 27, vd_sel, vd_div, m, cb.vdc, s));
@@ -477,9 +500,11 @@ static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, 
     return th_mlp_forward(c->mlp, V, m, cb.h, cb.f, f_ld, vd, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s);
 }
 
+#define TH_MAX_CLUSTERS 4096     // T' scratch of th_network_forward is sized for this many tokens per view
 size_t th_network_workspace_bytes(int V, int P) {
     int CH = P < TH_CHUNK ? (P > 0 ? P : 1) : TH_CHUNK;
-    return chunk_bytes(V, CH) + th_align((size_t)P * 4) + th_compact_ws(P) + th_align(64);
+    return chunk_bytes(V, CH) + th_align((size_t)P * 4) + th_compact_ws(P) + th_align(64) +
+           th_align((size_t)V * TH_MAX_CLUSTERS * 256 * 4);
 }
 
 int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir, const float* pts_smpl,
@@ -493,6 +518,11 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
     int CH = P < TH_CHUNK ? P : TH_CHUNK;
     ChunkBufs cb;
     TH_TRY(chunk_carve(ar, V, CH, &cb));
+    TH_REQUIRE(nc <= TH_MAX_CLUSTERS, "too many token clusters");
+    float* tprime = ar.take<float>((size_t)V * TH_MAX_CLUSTERS * 256);
+    TH_REQUIRE(tprime != nullptr, "workspace too small");
+    const float* table = nullptr;
+    TH_TRY(token_table(c, tokens, V, nc, tprime, &table, s));
     int32_t* idx = nullptr;
     int n = P;
     if (mask) {
@@ -511,7 +541,8 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
         const int32_t* sel = idx ? idx + o : nullptr;
         const float* pts = idx ? pts_smpl : pts_smpl + 3LL * o;
         const int fmt = mlp_row_format(c, V);
-        TH_TRY(th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, m, centres, rot, tokens, V, nc, 0.5f, cb.h, fmt, s));
+        TH_TRY(th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, m, centres, rot, table, V, nc, 0.5f, cb.h, cb.pe,
+                               dparf_row_format(c, V), s));
         if (idx) TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, fmt, s));
         else TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, fmt, s));
         if (idx) TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir, sel, 1, 0, s));
@@ -539,7 +570,7 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
     int CH = P < TH_CHUNK ? (int)(P > 0 ? P : 1) : TH_CHUNK;
     return th_align((size_t)P) + th_align((size_t)R * 4) + th_hull_ws(f->n_verts) + th_compact_ws(P) +
            th_align((size_t)P * 4) + th_align(64) + th_align((size_t)R * 27 * 4) + th_align((size_t)P * 16) +
-           chunk_bytes(f->V, CH);
+           th_align((size_t)f->V * TH_MAX_CLUSTERS * 256 * 4) + chunk_bytes(f->V, CH);
 }
 
 // hull mask -> (small-frame rule) -> compaction -> chunked DPaRF + gather + MLP -> dense raw[P,4]
@@ -564,9 +595,10 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     int32_t* info = ar.take<int32_t>(16);
     float* vd_all = ar.take<float>((size_t)R * 27);
     float* raw = ar.take<float>((size_t)P * 4);
+    float* tprime = ar.take<float>((size_t)V * TH_MAX_CLUSTERS * 256);
     int CH = P < TH_CHUNK ? (int)P : TH_CHUNK;
     ChunkBufs cb;
-    TH_REQUIRE(raw != nullptr, "workspace too small");
+    TH_REQUIRE(raw != nullptr && tprime != nullptr, "workspace too small");
     TH_TRY(chunk_carve(ar, V, CH, &cb));
 
     ThProf* pf = prof_of(c);
@@ -606,13 +638,16 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     const int hit_rays = hp[0], unmasked = hp[1], n = hp[2];
     if (stats_host) { stats_host[0] = hit_rays; stats_host[1] = n; stats_host[2] = -1; stats_host[3] = unmasked; }
     if (!ray_mode) TH_HIP(hipMemsetAsync(cb.vdc, 0, (size_t)CH * 27 * 4, s));   // zero view dirs, if_mesh_renderer.py:62
+    TH_REQUIRE(f->n_clusters <= TH_MAX_CLUSTERS, "too many token clusters");
+    const float* table = nullptr;
+    if (n > 0) TH_TRY(token_table(c, f->tokens, V, f->n_clusters, tprime, &table, s));
     for (int o = 0; o < n; o += CH) {
         int m = (n - o) < CH ? (n - o) : CH;
         const int32_t* sel = idx + o;
         {
             ProfScope ps1(pf, TH_PROF_DPARF, s);
-            TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, sel, m, f->centres, f->rot, f->tokens, V,
-                                   f->n_clusters, 0.5f, cb.h, fmt, s));
+            TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, sel, m, f->centres, f->rot, table, V,
+                                   f->n_clusters, 0.5f, cb.h, cb.pe, dparf_row_format(c, V), s));
         }
         {
             ProfScope ps2(pf, TH_PROF_GATHER, s);

@@ -159,6 +159,7 @@ __device__ __forceinline__ void th_project(const float* __restrict__ cam, float 
 // ---- context ----------------------------------------------------------------------
 struct ThMlpPacked {
     ThPacked fc_0, alpha_res_0, kv0, kv1, fc_1, fc_2, fc_3, feature_fc, rgb_res_0, view_fc, rgb_res_1, fc_4;
+    ThPacked fc_0tok;   // fc_0[:, :192] without bias: per-frame table T' = tokens W_tok^T of the fused path
     // colour-folded forms of the three layers that read the pixel feature (in_f 260, rows 272 floats wide)
     ThPacked alpha_res_0c, rgb_res_0c, rgb_res_1c;
     bool compact_ready = false;
@@ -186,12 +187,16 @@ struct FusedLayer {
     int CT, KB;
 };
 struct FusedParams {
-    FusedLayer fc_0, kv1, ar0, kv0, fc_1, fc_2, fc_3, feat, rr0, vfc, rr1, fc_4;
+    FusedLayer fc_0pe;             // fc_0[:, 192:255] (the positional-encoding columns) + the fc_0 bias
+    FusedLayer kv1, ar0, kv0, fc_1, fc_2, fc_3, feat, rr0, vfc, rr1, fc_4;
     FusedLayer ar0c, rr0c, rr1c;   // colour-folded (K = 272) forms; the launcher copies them over ar0/rr0/rr1
     bool compact_ready;
     const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
-    // split-f16 rows written by the producers (TH_ROWS_SPLIT): K hi halves then K lo halves per (sample, view)
-    const _Float16* h;  // [P][V][2][256]
+    // token branch, written by K4 in TH_ROWS_FOLDED form: the neighbour blend of T' = tokens W_tok^T (fp32) and
+    // the blended positional encoding (split-f16: 64 hi halves then 64 lo halves per sample)
+    const float* stok;      // [P][V][256]
+    const _Float16* pe;     // [P][2][64]
+    // split-f16 rows written by K5 (TH_ROWS_SPLIT): K hi halves then K lo halves per (sample, view)
     const _Float16* f;  // [P][V][2][384] (full) or [P][V][2][272] (compact: 256 latent | r g b | 0...)
     const float* vd;    // view-direction rows [.][27]: row of compacted sample p = vd_sel ? vd_sel[p] / vd_div : p
     const int32_t* vd_sel;
@@ -204,11 +209,11 @@ struct FusedParams {
 size_t th_fused_pack_bytes();
 // folded: nullptr or the three colour-folded fp32 layers {alpha_res_0, rgb_res_0, rgb_res_1} (in_f 260)
 int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store, FusedParams* out, hipStream_t s);
-// h / f: TH_ROWS_SPLIT rows (same byte size as the fp32 rows: 4 * K bytes per (sample, view))
+// stok / pe: TH_ROWS_FOLDED output of K4; f: TH_ROWS_SPLIT rows (4 * K bytes per (sample, view))
 // vd rows are addressed through vd_sel / vd_div (the per-RAY embedding table is read in place: sample index / S),
 // or directly by the compacted sample index when vd_sel == nullptr
-int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const void* h,
-                         const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all,
+int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
+                         const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all,
                          float* raw_c, hipStream_t s);
 
 struct th_ctx {
@@ -259,11 +264,14 @@ int th_nchw_to_nhwc_launch(const float* src, int V, int C, int H, int W, float* 
 //   TH_ROWS_F32    K fp32 values (layer-by-layer fp32 MFMA path, public th_dparf_encode / th_pixel_gather)
 //   TH_ROWS_SPLIT  K fp16 "hi" halves followed by K fp16 "lo" halves, x = hi + lo to 2^-22 (fused kernel: the
 //                  operand is copied to LDS by LDS-DMA with no conversion pass); same 4K bytes per row
-enum { TH_ROWS_F32 = 0, TH_ROWS_SPLIT = 1 };
+//   TH_ROWS_FOLDED (K4 only) the token table handed to K4 is T' = tokens fc_0[:, :192]^T (256 wide): `out` gets the
+//                  fp32 neighbour blend of T' rows [P][V][256], `pe_out` the blended 63-wide positional encoding
+//                  as one split-f16 row of 64 + 64 halves per SAMPLE (fused kernel, see its token branch)
+enum { TH_ROWS_F32 = 0, TH_ROWS_SPLIT = 1, TH_ROWS_FOLDED = 2 };
 // k_dparf.hip
 int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh, const float* Th,
                     const int32_t* sel, int P, const float* centres, const float* rot, const float* tokens,
-                    int V, int nc, float alpha, float* out, int fmt, hipStream_t s);
+                    int V, int nc, float alpha, float* out, float* pe_out, int fmt, hipStream_t s);
 // k_pixfeat.hip
 int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world,
                         const ThPointSrc* ps, const int32_t* sel, int P, const float* cams, const float* scale,
