@@ -524,3 +524,10 @@ def test_weight_updates_are_picked_up(hip, gpu, net):
             net.alpha_fc.bias.sub_(0.25)
     raw2 = hip.network_forward(net, pf, vd, ps, cen, rot, tok)
     assert torch.equal(raw2, raw0)
+
+
+def test_render_four_views_vs_oracle(hip, gpu, net):
+    """V = 4 reference views: beyond the fused kernel's register budget -> the layer-by-layer fp32 MFMA path
+    (plain fp32 rows from K4 / K5) is dispatched automatically"""
+    st = _render_vs_oracle(hip, gpu, net, V=4, nc=300, assign=synth_assign(300))
+    assert st["hit_rays"] > 0
