@@ -298,6 +298,9 @@ int th_render_rays(th_ctx* ctx, const th_frame* f, const th_points* rays, float*
  * orders the prepass after the previous use of the workspace.  Results are identical with or without it. */
 int th_render_prepass(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
                       size_t workspace_bytes, th_stream stream);
+/* Drops a pending prepass (a caller that abandons the frame it was queued for must not let a later
+ * th_render_rays that happens to reuse the same buffers pick it up). */
+int th_render_prepass_cancel(th_ctx* ctx);
 
 /* if_mesh_renderer.Renderer.render :46-100 up to `cube`: sigma_raw per grid
  * point (0 outside the hull).  pts [P,3] world space. */

@@ -720,6 +720,12 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     return 0;
 }
 
+int th_render_prepass_cancel(th_ctx* c) {
+    TH_REQUIRE(c, "null ctx");
+    c->prepass_valid = false;
+    return 0;
+}
+
 __global__ void extract_sigma_kernel(const float4* __restrict__ raw, long long P, float* __restrict__ out) {
     long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (i < P) out[i] = raw[i].w;

@@ -110,6 +110,7 @@ SYMBOLS = {
                                  C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
     "th_render_prepass": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
                                     C.c_void_p]),
+    "th_render_prepass_cancel": (C.c_int, [C.c_void_p]),
     "th_sigma_grid_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int]),
     "th_eval_sigma_grid": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
@@ -592,6 +593,7 @@ def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=240
     ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(f), points.R, points.S), dev)
     points._prepass_keep = (v, ws)
     _check(lib.th_render_prepass(ctx(dev), C.byref(f), C.byref(points.c), _p(ws), ws.numel(), _stream()))
+    points._prepass_pending = True          # only THIS Points object (it keeps the ray tensors alive) may consume it
 
 
 def render_rays(net, frame, points, white_bkgd=False):
@@ -604,6 +606,10 @@ def render_rays(net, frame, points, white_bkgd=False):
     acc = torch.empty(R, dtype=torch.float32, device=dev)
     dep = torch.empty(R, dtype=torch.float32, device=dev)
     ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(frame.c), R, points.S), dev)
+    if getattr(points, "_prepass_pending", False):
+        points._prepass_pending = False
+    else:
+        _check(lib.th_render_prepass_cancel(ctx(dev)))      # a token queued for other (possibly freed) rays
     stats = (C.c_int64 * 4)()
     _check(lib.th_render_rays(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(rgb), _p(acc), _p(dep), int(white_bkgd),
                               _p(ws), ws.numel(), stats, _stream()))
