@@ -56,15 +56,34 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // ---- attention -------------------------------------------------------------------
 // qkv rows: [T, 3*dim] with col = which*dim + head*64 + d  (:271).  head_dim = 64.
+// softmax(q k^T * 0.125) v per (view, head), flash-style: 64-key tiles, online softmax in registers, the
+// [V,3,N,N] probability tensor never exists.  Both products run on v_mfma_f32_16x16x32_f16 with the operands
+// split into fp16 hi + lo (x = hi + lo to 2^-22; three products hi*hi + hi*lo + lo*hi, fp32 accumulate -- the
+// same fp32-class scheme as the fused MLP): 48 MFMAs of 16 cycles per tile and wave instead of the
+// 128 fp32 MFMAs of 32 cycles the 16x16x4 form needs.
+//   S = Q K^T : A = Q [16 q][k = d]   (registers, split once per workgroup)
+//               B = K^T: lane (key = nt*16 + lane&15, d = 32 s + 8 (lane>>4) ..+7) -> 16 bytes of a K row in LDS
+//   O = P V   : A = P [16 q][k = key] (softmax output, C layout -> LDS -> A layout, split)
+//               B = V  : lane (d = dt*16 + lane&15, key = 32 s + 8 (lane>>4) ..+7) -> V is staged TRANSPOSED
+// One workgroup = 4 waves = 64 queries; K / V tiles are fetched into registers one tile ahead.
 #define AT_Q 64
 #define AT_K 64
-#define AT_STR 68      // LDS row stride (floats) for K, V and P tiles
+#define AT_HS 144      // LDS row stride in bytes of a 64-half row (+16: an odd number of 16-byte slots)
+
+typedef _Float16 at_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 at_h4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void at_split(float x, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)x;
+    lo = (_Float16)(x - (float)hi);
+}
 
 __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv, int N, int dim, float scale,
                                                    float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float Ks[AT_K * AT_STR];
-    __shared__ __attribute__((aligned(16))) float Vs[AT_K * AT_STR];
-    __shared__ __attribute__((aligned(16))) float Psh[4][16 * AT_STR];
+    // planes: [hi | lo][64 rows][AT_HS bytes]
+    __shared__ __attribute__((aligned(16))) char Ks[2 * AT_K * AT_HS];      // K  [key][d]
+    __shared__ __attribute__((aligned(16))) char Vt[2 * 64 * AT_HS];        // V^T [d][key]
+    __shared__ __attribute__((aligned(16))) char Ps[4][2 * 16 * AT_HS];     // P  [q][key] per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int head = blockIdx.y, view = blockIdx.z;
     const int q0 = blockIdx.x * AT_Q + wave * 16;
@@ -72,14 +91,26 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
     const float* base = qkv + (long long)view * N * ld;
     const int qcol = head * 64, kcol = dim + head * 64, vcol = 2 * dim + head * 64;
 
-    // Q fragments: A[i = lane&15][k = 16*kb + 4*(lane>>4) + e]
-    f32x4 qf[4];
+    // Q fragments (A operand): row q0 + (lane&15), d = 32 s + 8 (lane>>4) .. +7
+    at_h8 qh[2], ql[2];
     {
-        int qi = q0 + (lane & 15);
+        const int qi = q0 + (lane & 15);
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            if (qi < N) qf[kb] = *reinterpret_cast<const f32x4*>(base + (long long)qi * ld + qcol + kb * 16 + 4 * (lane >> 4));
-            else qf[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = 0.f;
+            if (qi < N) {
+                const float* src = base + (long long)qi * ld + qcol + 32 * s2 + 8 * (lane >> 4);
+                float4 a = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
+                v8[0] = a.x; v8[1] = a.y; v8[2] = a.z; v8[3] = a.w; v8[4] = b4.x; v8[5] = b4.y; v8[6] = b4.z; v8[7] = b4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 x, y;
+                at_split(v8[e], x, y);
+                qh[s2][e] = x; ql[s2][e] = y;
+            }
         }
     }
     f32x4 oacc[4];
@@ -89,8 +120,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mrun[r] = -3.0e38f; lrun[r] = 0.f; }
 
-    // K / V tiles (64 keys x 64 floats each = 1024 float4 per tile): fetched into registers one tile ahead so
-    // the L2 round trip of tile t+1 overlaps the two MFMA passes and the softmax of tile t
+    // K / V tiles (64 keys x 64 floats each = 1024 float4 per tile): fetched into registers one tile ahead
     float4 kreg[4], vreg[4];
     auto fetch_kv = [&](int k0) {
 #pragma unroll
@@ -107,31 +137,45 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
         }
     };
     fetch_kv(0);
+    char* Pw = Ps[wave];
     for (int k0 = 0; k0 < N; k0 += AT_K) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int idx = tid + 256 * i;
-            int row = idx >> 4, c4 = idx & 15;
-            *reinterpret_cast<float4*>(&Ks[row * AT_STR + 4 * c4]) = kreg[i];
-            *reinterpret_cast<float4*>(&Vs[row * AT_STR + 4 * c4]) = vreg[i];
+            int row = idx >> 4, c4 = idx & 15;                  // key row, 4 consecutive d
+            const float kv[4] = {kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w};
+            const float vv[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+            at_h4 kh, kl;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 x, y;
+                at_split(kv[e], x, y);
+                kh[e] = x; kl[e] = y;
+                at_split(vv[e], x, y);
+                *reinterpret_cast<_Float16*>(Vt + (4 * c4 + e) * AT_HS + 2 * row) = x;                     // V^T[d][key]
+                *reinterpret_cast<_Float16*>(Vt + 64 * AT_HS + (4 * c4 + e) * AT_HS + 2 * row) = y;
+            }
+            *reinterpret_cast<at_h4*>(Ks + row * AT_HS + 8 * c4) = kh;
+            *reinterpret_cast<at_h4*>(Ks + AT_K * AT_HS + row * AT_HS + 8 * c4) = kl;
         }
         __syncthreads();
         if (k0 + AT_K < N) fetch_kv(k0 + AT_K);
-        // S = Q K^T : B[k=d][j=key]  lane (j = lane&15, kq = lane>>4) reads K[key][16kb+4kq .. +3]
+        // ---- S = Q K^T (C layout: row q = 4*(lane>>4)+r, col key = nt*16 + (lane&15)) ----
         f32x4 sacc[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             sacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                f32x4 bf = *reinterpret_cast<const f32x4*>(&Ks[(nt * 16 + (lane & 15)) * AT_STR + kb * 16 + 4 * (lane >> 4)]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[kb][e], bf[e], sacc[nt], 0, 0, 0);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int off = (nt * 16 + (lane & 15)) * AT_HS + 64 * s2 + 16 * (lane >> 4);
+                const at_h8 bh = *reinterpret_cast<const at_h8*>(Ks + off);
+                const at_h8 bl = *reinterpret_cast<const at_h8*>(Ks + AT_K * AT_HS + off);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[s2], bh, sacc[nt], 0, 0, 0);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s2], bl, sacc[nt], 0, 0, 0);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s2], bh, sacc[nt], 0, 0, 0);
             }
         }
-        // C layout: row = 4*(lane>>4)+r, col = nt*16 + (lane&15)
         float mnew[4], corr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -148,7 +192,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
             corr[r] = expf(mrun[r] - mnew[r]);
             mrun[r] = mnew[r];
         }
-        float* Pw = Psh[wave];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float ls = 0.f;
@@ -157,7 +200,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
                 int key = k0 + nt * 16 + (lane & 15);
                 float pv = (key < N) ? expf(sacc[nt][r] - mnew[r]) : 0.f;
                 ls += pv;
-                Pw[(4 * (lane >> 4) + r) * AT_STR + nt * 16 + (lane & 15)] = pv;
+                _Float16 x, y;
+                at_split(pv, x, y);
+                const int po = (4 * (lane >> 4) + r) * AT_HS + 2 * (nt * 16 + (lane & 15));
+                *reinterpret_cast<_Float16*>(Pw + po) = x;
+                *reinterpret_cast<_Float16*>(Pw + 16 * AT_HS + po) = y;
             }
             for (int o = 1; o < 16; o <<= 1) ls += __shfl_xor(ls, o);
             lrun[r] = lrun[r] * corr[r] + ls;
@@ -166,17 +213,20 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): P tile of this wave is written
         __builtin_amdgcn_wave_barrier();
-        // O += P V : A[i=q][k=key] from Pw, B[k=key][j=d] = V[key][d]
+        // ---- O += P V ----
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            f32x4 af = *reinterpret_cast<const f32x4*>(&Pw[(lane & 15) * AT_STR + kb * 16 + 4 * (lane >> 4)]);
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int pof = (lane & 15) * AT_HS + 64 * s2 + 16 * (lane >> 4);
+            const at_h8 ph = *reinterpret_cast<const at_h8*>(Pw + pof);
+            const at_h8 pl = *reinterpret_cast<const at_h8*>(Pw + 16 * AT_HS + pof);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float bv = Vs[(kb * 16 + 4 * (lane >> 4) + e) * AT_STR + j * 16 + (lane & 15)];
-                    oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bv, oacc[j], 0, 0, 0);
-                }
+                const int vof = (j * 16 + (lane & 15)) * AT_HS + 64 * s2 + 16 * (lane >> 4);
+                const at_h8 vh = *reinterpret_cast<const at_h8*>(Vt + vof);
+                const at_h8 vl = *reinterpret_cast<const at_h8*>(Vt + 64 * AT_HS + vof);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, oacc[j], 0, 0, 0);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, oacc[j], 0, 0, 0);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, oacc[j], 0, 0, 0);
             }
         }
     }
