@@ -531,3 +531,31 @@ def test_render_four_views_vs_oracle(hip, gpu, net):
     (plain fp32 rows from K4 / K5) is dispatched automatically"""
     st = _render_vs_oracle(hip, gpu, net, V=4, nc=300, assign=synth_assign(300))
     assert st["hit_rays"] > 0
+
+
+def test_edge_cases_no_hits_single_ray_empty(hip, gpu, net):
+    """frames the reference handles through its early exits: no ray touches the hull (all outputs zero), a single
+    ray, an empty ray list"""
+    _cfg(32)
+    b = synth.batch_to(synth.make_batch(32, 32, 3, seed=0), gpu)
+    r = _renderer(net)
+    far_away = dict(b)
+    far_away["near"] = torch.full_like(b["near"], 40.0)
+    far_away["far"] = torch.full_like(b["far"], 41.0)
+    out = r.render_fast(far_away)
+    assert r.last_stats["hit_rays"] == 0 and r.last_stats["valid_samples"] == 0
+    assert float(out["rgb_map"].abs().max()) == 0.0 and float(out["acc_map"].abs().max()) == 0.0
+    full = r.render_fast(b)
+    hit = int(torch.nonzero(full["acc_map"][0] > 0)[0])
+    one = dict(b)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        one[k] = b[k][:, hit:hit + 1]
+    o1 = r.render_fast(one)
+    assert o1["rgb_map"].shape == (1, 1, 3) and r.last_stats["hit_rays"] == 1
+    # a single hit ray is a "small frame" (R' <= 2400, un-masked branch) exactly like the 32x32 frame it came from
+    assert maxdiff(o1["rgb_map"][0, 0].cpu(), full["rgb_map"][0, hit].cpu()) < 1e-5
+    none = dict(b)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        none[k] = b[k][:, :0]
+    o0 = r.render_fast(none)
+    assert o0["rgb_map"].shape == (1, 0, 3) and o0["acc_map"].shape == (1, 0)

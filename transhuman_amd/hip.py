@@ -605,6 +605,8 @@ def render_rays(net, frame, points, white_bkgd=False):
     rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
     acc = torch.empty(R, dtype=torch.float32, device=dev)
     dep = torch.empty(R, dtype=torch.float32, device=dev)
+    if R == 0:                                   # empty ray list: nothing to launch (zero-size tensors have no address)
+        return rgb, acc, dep, dict(hit_rays=0, valid_samples=0, unmasked=0)
     ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(frame.c), R, points.S), dev)
     if getattr(points, "_prepass_pending", False):
         points._prepass_pending = False
