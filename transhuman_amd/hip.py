@@ -459,6 +459,8 @@ def network_forward(net, pixel_feat, viewdir, pts_smpl, centres, rot, tokens, ma
     c, r, t = _f32(centres).reshape(-1, 3), _f32(rot).reshape(-1, 9), _f32(tokens)
     m = mask.reshape(-1).to(torch.uint8).contiguous() if mask is not None else None
     raw = torch.empty((P, 4), dtype=torch.float32, device=pf.device)
+    if P == 0:
+        return raw
     ws = _ws(lib.th_network_workspace_bytes(V, P), pf.device)
     _check(lib.th_network_forward(ctx(pf.device), _p(pf), _p(vd), _p(ps), _p(m), P, _p(c), _p(r), _p(t), V, t.shape[1],
                                   _p(raw), _p(ws), ws.numel(), _stream()))
@@ -624,6 +626,8 @@ def eval_sigma_grid(net, frame, pts):
     p = _f32(pts).reshape(-1, 3)
     P = p.shape[0]
     out = torch.empty(P, dtype=torch.float32, device=p.device)
+    if P == 0:
+        return out, dict(valid_samples=0)
     ws = _cached_ws(lib.th_sigma_grid_workspace_bytes(C.byref(frame.c), P), p.device)
     stats = (C.c_int64 * 4)()
     _check(lib.th_eval_sigma_grid(ctx(p.device), C.byref(frame.c), _p(p), P, _p(out), _p(ws), ws.numel(), stats,
