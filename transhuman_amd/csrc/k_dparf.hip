@@ -65,6 +65,140 @@ __device__ __forceinline__ float dp_sin(float a) {
     return __builtin_amdgcn_sinf(r * 0.15915494309189535f);   // v_sin_f32 takes revolutions
 }
 
+// ---- candidate grid over the token centres (exact pruning of the 7-NN scan) ---------------------------------
+// Cell size g; for a cell with centre q and half-diagonal h let d7(q) be the distance from q to its 7th nearest
+// token centre.  For any point p of the cell d7(p) <= d7(q) + |p - q| <= d7(q) + h, hence every one of p's 7
+// nearest centres t satisfies |t - q| <= |t - p| + |p - q| <= d7(q) + 2h.  The cell's list holds all centres
+// within that radius (plus a rounding margin), in ascending index order: scanning it gives the same 7
+// neighbours, distances and tie order as scanning all N_c centres, with ~70 instead of N_c candidates.  Points
+// outside the grid fall back to the full scan.  Built once per frame (thousands of tiny blocks, ~20 us).
+#define DPG_MAXCELLS 8192
+struct DpGrid {
+    float gmin[3];
+    float g, inv_g;
+    int dim[3];
+    int ncell;          // 0: grid disabled (too many cells)
+};
+
+__global__ __launch_bounds__(256) void dpgrid_setup_kernel(const float* __restrict__ centres, int nc, float g, float margin,
+                                                           DpGrid* __restrict__ gi) {
+    __shared__ float red[6][256];
+    float mn[3] = {3e38f, 3e38f, 3e38f}, mx[3] = {-3e38f, -3e38f, -3e38f};
+    for (int i = threadIdx.x; i < nc; i += 256)
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], centres[3 * i + a]); mx[a] = fmaxf(mx[a], centres[3 * i + a]); }
+    for (int a = 0; a < 3; ++a) { red[a][threadIdx.x] = mn[a]; red[3 + a][threadIdx.x] = mx[a]; }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+            for (int a = 0; a < 3; ++a) {
+                red[a][threadIdx.x] = fminf(red[a][threadIdx.x], red[a][threadIdx.x + s]);
+                red[3 + a][threadIdx.x] = fmaxf(red[3 + a][threadIdx.x], red[3 + a][threadIdx.x + s]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float ext[3];
+        for (int a = 0; a < 3; ++a) ext[a] = (red[3 + a][0] - red[a][0]) + 2.f * margin;
+        // grow the cell until the grid fits
+        for (int it = 0; it < 32; ++it) {
+            long long n = 1;
+            for (int a = 0; a < 3; ++a) n *= (long long)ceilf(ext[a] / g);
+            if (n <= DPG_MAXCELLS) break;
+            g *= 1.25f;
+        }
+        long long n = 1;
+        for (int a = 0; a < 3; ++a) {
+            gi->gmin[a] = red[a][0] - margin;
+            gi->dim[a] = max(1, (int)ceilf(ext[a] / g));
+            n *= gi->dim[a];
+        }
+        gi->g = g;
+        gi->inv_g = 1.0f / g;
+        gi->ncell = (n <= DPG_MAXCELLS && nc >= DP_K) ? (int)n : 0;
+    }
+}
+
+// one block per cell: radius = d7(cell centre) + 2h, list of the centres inside it (ascending index)
+__global__ __launch_bounds__(256) void dpgrid_fill_kernel(const float* __restrict__ centres, int nc,
+                                                          const DpGrid* __restrict__ gi, int* __restrict__ cell_count,
+                                                          int* __restrict__ cand) {
+    extern __shared__ float dsq[];                       // [nc] squared distances to the cell centre
+    __shared__ float rv[256];
+    __shared__ int ri[256];
+    __shared__ int scan[257];
+    const DpGrid g = *gi;
+    const int cell = blockIdx.x;
+    if (cell >= g.ncell) return;
+    const int cx = cell % g.dim[0], cy = (cell / g.dim[0]) % g.dim[1], cz = cell / (g.dim[0] * g.dim[1]);
+    const float qx = g.gmin[0] + (cx + 0.5f) * g.g, qy = g.gmin[1] + (cy + 0.5f) * g.g, qz = g.gmin[2] + (cz + 0.5f) * g.g;
+    for (int i = threadIdx.x; i < nc; i += 256) {
+        float dx = qx - centres[3 * i], dy = qy - centres[3 * i + 1], dz = qz - centres[3 * i + 2];
+        dsq[i] = dx * dx + dy * dy + dz * dz;
+    }
+    __syncthreads();
+    // 7th smallest squared distance: seven rounds of (min over values greater than the previous pick, by (value, index))
+    float pv = -1.f;
+    int pi = -1;
+    for (int round = 0; round < DP_K; ++round) {
+        float bv = 3e38f;
+        int bi = 0x7fffffff;
+        for (int i = threadIdx.x; i < nc; i += 256) {
+            float v = dsq[i];
+            bool after = (v > pv) || (v == pv && i > pi);
+            if (after && (v < bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        }
+        rv[threadIdx.x] = bv; ri[threadIdx.x] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+                float ov = rv[threadIdx.x + s];
+                int oi = ri[threadIdx.x + s];
+                if (ov < rv[threadIdx.x] || (ov == rv[threadIdx.x] && oi < ri[threadIdx.x])) { rv[threadIdx.x] = ov; ri[threadIdx.x] = oi; }
+            }
+            __syncthreads();
+        }
+        pv = rv[0]; pi = ri[0];
+        __syncthreads();
+    }
+    const float h = 0.8660254f * g.g;                    // half diagonal of the cell
+    float rad = sqrtf(pv) * 1.0001f + 2.f * h * 1.0001f + 1e-5f;
+    const float r2 = rad * rad;
+    // ordered compaction: thread t owns the contiguous index range [t*per, (t+1)*per)
+    const int per = (nc + 255) / 256;
+    const int lo = threadIdx.x * per, hi = min(nc, lo + per);
+    int cnt = 0;
+    for (int i = lo; i < hi; ++i) cnt += dsq[i] <= r2;
+    scan[threadIdx.x + 1] = cnt;
+    if (threadIdx.x == 0) scan[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int t = 1; t <= 256; ++t) scan[t] += scan[t - 1];
+    __syncthreads();
+    int o = scan[threadIdx.x];
+    int* dst = cand + (long long)cell * nc;
+    for (int i = lo; i < hi; ++i)
+        if (dsq[i] <= r2) dst[o++] = i;
+    if (threadIdx.x == 0) cell_count[cell] = scan[256];
+}
+
+size_t th_dparf_grid_ws(int nc) {
+    return th_align(sizeof(DpGrid)) + th_align((size_t)DPG_MAXCELLS * 4) + th_align((size_t)DPG_MAXCELLS * nc * 4);
+}
+
+int th_dparf_grid_build(const float* centres, int nc, void* ws, size_t ws_bytes, hipStream_t s) {
+    TH_REQUIRE(ws_bytes >= th_dparf_grid_ws(nc), "grid workspace too small");
+    TH_REQUIRE((size_t)nc * 4 <= 48 * 1024, "too many token centres for the grid builder");
+    ThArena ar(ws, ws_bytes);
+    DpGrid* gi = ar.take<DpGrid>(1);
+    int* cnt = ar.take<int>(DPG_MAXCELLS);
+    int* cand = ar.take<int>((size_t)DPG_MAXCELLS * nc);
+    TH_REQUIRE(cand != nullptr, "grid workspace carve failed");
+    hipLaunchKernelGGL(dpgrid_setup_kernel, dim3(1), dim3(256), 0, s, centres, nc, 0.1f, 0.25f, gi);
+    hipLaunchKernelGGL(dpgrid_fill_kernel, dim3(DPG_MAXCELLS), dim3(256), (size_t)nc * 4, s, centres, nc, gi, cnt, cand);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool FOLDED>
 __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restrict__ pts_smpl, ThPointSrc ps,
                                                            const float* __restrict__ Rh, const float* __restrict__ Th,
@@ -73,7 +207,9 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                                                            const float* __restrict__ rot,
                                                            const float* __restrict__ tokens, int V, int nc,
                                                            float alpha, float* __restrict__ out,
-                                                           float* __restrict__ pe_out) {
+                                                           float* __restrict__ pe_out, const DpGrid* __restrict__ gi,
+                                                           const int* __restrict__ cell_count,
+                                                           const int* __restrict__ cand) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* cen = lds;                                   // [nc*3]
     DpNbr* nb = reinterpret_cast<DpNbr*>(lds + ((nc * 3 + 3) & ~3));
@@ -101,7 +237,20 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
         int bi[DP_K];
 #pragma unroll
         for (int k = 0; k < DP_K; ++k) { bd[k] = 3.0e38f; bi[k] = 0x7fffffff; }
-        for (int c = half; c < nc; c += 2) {
+        // candidate list of this point's grid cell (exact superset of its 7 nearest centres), else all centres
+        const int* list = nullptr;
+        int nlist = nc;
+        if (gi != nullptr && gi->ncell > 0) {
+            const int cx = (int)floorf((x - gi->gmin[0]) * gi->inv_g), cy = (int)floorf((y - gi->gmin[1]) * gi->inv_g),
+                      cz = (int)floorf((z - gi->gmin[2]) * gi->inv_g);
+            if (cx >= 0 && cx < gi->dim[0] && cy >= 0 && cy < gi->dim[1] && cz >= 0 && cz < gi->dim[2]) {
+                const int cell = (cz * gi->dim[1] + cy) * gi->dim[0] + cx;
+                list = cand + (long long)cell * nc;
+                nlist = cell_count[cell];
+            }
+        }
+        for (int j = half; j < nlist; j += 2) {
+            const int c = list ? list[j] : j;
             float dx = x - cen[3 * c], dy = y - cen[3 * c + 1], dz = z - cen[3 * c + 2];
             float d2 = dx * dx + dy * dy;
             d2 = d2 + dz * dz;
@@ -223,7 +372,7 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
 
 int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh, const float* Th,
                     const int32_t* sel, int P, const float* centres, const float* rot, const float* tokens, int V,
-                    int nc, float alpha, float* out, float* pe_out, int fmt, hipStream_t s) {
+                    int nc, float alpha, float* out, float* pe_out, int fmt, const void* grid_ws, hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(nc >= DP_K, "need at least 7 token centres");
     ThPointSrc src;
@@ -237,12 +386,21 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
         attr_set = true;
     }
     TH_REQUIRE(fmt == TH_ROWS_F32 || (fmt == TH_ROWS_FOLDED && pe_out != nullptr), "K4 writes fp32 rows or the folded form");
+    // optional candidate grid (th_dparf_grid_build into grid_ws): same carve as the builder
+    const DpGrid* gi = nullptr;
+    const int *cnt = nullptr, *cand = nullptr;
+    if (grid_ws != nullptr) {
+        ThArena ar(const_cast<void*>(grid_ws), th_dparf_grid_ws(nc));
+        gi = ar.take<DpGrid>(1);
+        cnt = ar.take<int>(DPG_MAXCELLS);
+        cand = ar.take<int>((size_t)DPG_MAXCELLS * nc);
+    }
     if (fmt == TH_ROWS_FOLDED)
         hipLaunchKernelGGL(dparf_kernel<true>, dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
-                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out);
+                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out, gi, cnt, cand);
     else
         hipLaunchKernelGGL(dparf_kernel<false>, dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
-                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out);
+                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out, gi, cnt, cand);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -373,7 +373,7 @@ int th_dparf_encode(th_ctx* c, const float* pts, const int32_t* sel, int P, cons
                     const float* tokens, int V, int nc, float* out, th_stream stream) {
     TH_REQUIRE(c && pts && centres && rot && tokens && out, "null argument");
     return th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, P, centres, rot, tokens, V, nc, 0.5f, out, nullptr,
-                           TH_ROWS_F32, (hipStream_t)stream);
+                           TH_ROWS_F32, nullptr, (hipStream_t)stream);
 }
 
 int th_nchw_to_nhwc(th_ctx* c, const float* src, int V, int C, int H, int W, float* dst, th_stream stream) {
@@ -542,7 +542,7 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
         const float* pts = idx ? pts_smpl : pts_smpl + 3LL * o;
         const int fmt = mlp_row_format(c, V);
         TH_TRY(th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, m, centres, rot, table, V, nc, 0.5f, cb.h, cb.pe,
-                               dparf_row_format(c, V), s));
+                               dparf_row_format(c, V), nullptr, s));
         if (idx) TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, fmt, s));
         else TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, fmt, s));
         if (idx) TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir, sel, 1, 0, s));
@@ -570,7 +570,8 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
     int CH = P < TH_CHUNK ? (int)(P > 0 ? P : 1) : TH_CHUNK;
     return th_align((size_t)P) + th_align((size_t)R * 4) + th_hull_ws(f->n_verts) + th_compact_ws(P) +
            th_align((size_t)P * 4) + th_align(64) + th_align((size_t)R * 27 * 4) + th_align((size_t)P * 16) +
-           th_align((size_t)f->V * TH_MAX_CLUSTERS * 256 * 4) + chunk_bytes(f->V, CH);
+           th_align((size_t)f->V * TH_MAX_CLUSTERS * 256 * 4) + th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1) +
+           chunk_bytes(f->V, CH);
 }
 
 // hull mask -> (small-frame rule) -> compaction -> chunked DPaRF + gather + MLP -> dense raw[P,4]
@@ -596,9 +597,11 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     float* vd_all = ar.take<float>((size_t)R * 27);
     float* raw = ar.take<float>((size_t)P * 4);
     float* tprime = ar.take<float>((size_t)V * TH_MAX_CLUSTERS * 256);
+    const size_t gws_b = th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1);
+    void* gws = ar.take<char>(gws_b);
     int CH = P < TH_CHUNK ? (int)P : TH_CHUNK;
     ChunkBufs cb;
-    TH_REQUIRE(raw != nullptr && tprime != nullptr, "workspace too small");
+    TH_REQUIRE(raw != nullptr && tprime != nullptr && gws != nullptr, "workspace too small");
     TH_TRY(chunk_carve(ar, V, CH, &cb));
 
     ThProf* pf = prof_of(c);
@@ -641,13 +644,16 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     TH_REQUIRE(f->n_clusters <= TH_MAX_CLUSTERS, "too many token clusters");
     const float* table = nullptr;
     if (n > 0) TH_TRY(token_table(c, f->tokens, V, f->n_clusters, tprime, &table, s));
+    // exact candidate grid for the 7-NN scan of K4 (TH_DPARF_NOGRID=1: full scan, same result)
+    const bool use_grid = n > 0 && prepass != 1 && getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
+    if (use_grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s));
     for (int o = 0; o < n; o += CH) {
         int m = (n - o) < CH ? (n - o) : CH;
         const int32_t* sel = idx + o;
         {
             ProfScope ps1(pf, TH_PROF_DPARF, s);
             TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, sel, m, f->centres, f->rot, table, V,
-                                   f->n_clusters, 0.5f, cb.h, cb.pe, dparf_row_format(c, V), s));
+                                   f->n_clusters, 0.5f, cb.h, cb.pe, dparf_row_format(c, V), use_grid ? gws : nullptr, s));
         }
         {
             ProfScope ps2(pf, TH_PROF_GATHER, s);

@@ -271,7 +271,11 @@ enum { TH_ROWS_F32 = 0, TH_ROWS_SPLIT = 1, TH_ROWS_FOLDED = 2 };
 // k_dparf.hip
 int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh, const float* Th,
                     const int32_t* sel, int P, const float* centres, const float* rot, const float* tokens,
-                    int V, int nc, float alpha, float* out, float* pe_out, int fmt, hipStream_t s);
+                    int V, int nc, float alpha, float* out, float* pe_out, int fmt, const void* grid_ws,
+                    hipStream_t s);
+// exact candidate grid over the token centres for the 7-NN scan of K4 (per frame); grid_ws = nullptr: full scan
+size_t th_dparf_grid_ws(int nc);
+int th_dparf_grid_build(const float* centres, int nc, void* ws, size_t ws_bytes, hipStream_t s);
 // k_pixfeat.hip
 int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world,
                         const ThPointSrc* ps, const int32_t* sel, int P, const float* cams, const float* scale,

@@ -583,7 +583,7 @@ def _cached_ws(nbytes, device):
     return cur
 
 
-def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=2400):
+def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=2400, n_clusters=0):
     """th_render_prepass: queue the ray-only front of render_rays (hull mask, compaction, ...) before the
     per-frame constants exist.  The following render_rays on the same `points` picks it up."""
     lib = load_library()
@@ -592,6 +592,7 @@ def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=240
     f = ThFrame()
     f.verts_world, f.n_verts, f.V = v.data_ptr(), v.shape[0], V
     f.hull_thresh, f.small_frame_rays, f.map_channels = hull_thresh, small_frame_rays, 384
+    f.n_clusters = n_clusters                  # (sizes the workspace exactly like the frame that follows)
     ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(f), points.R, points.S), dev)
     points._prepass_keep = (v, ws)
     _check(lib.th_render_prepass(ctx(dev), C.byref(f), C.byref(points.c), _p(ws), ws.numel(), _stream()))

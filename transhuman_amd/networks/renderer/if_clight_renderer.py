@@ -156,7 +156,8 @@ class Renderer:
         if frame is None:
             V = batch["input_imgs"][0].reshape(-1, *batch["input_imgs"][0].shape[2:]).shape[0]
             if V <= 4 and pts.R > 0:
-                hip.render_prepass(pts, batch["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays)
+                hip.render_prepass(pts, batch["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
+                                   n_clusters=len(self.csr_offsets) - 1)
             frame = self.prepare_frame(batch)
             frame.c.small_frame_rays = small_frame_rays
         rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd))
