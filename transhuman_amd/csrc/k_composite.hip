@@ -14,7 +14,7 @@
 __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict__ raw, const float* __restrict__ zin,
                                                         ThPointSrc ps, int white, float* __restrict__ rgb,
                                                         float* __restrict__ acc, float* __restrict__ depth,
-                                                        float* __restrict__ wout) {
+                                                        float* __restrict__ wout, const uint8_t* __restrict__ mask) {
     const int lane = threadIdx.x & 63;
     int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= ps.R) return;
@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict
         }
         float delta = (s + 1 < S) ? (zn - z) : 1e10f;
         delta = delta * nd;
-        float4 r = ok ? raw[(long long)ray * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // mask given: samples outside the hull carry raw = 0 (cross_transformer.py:231) without being stored or read
+        const bool live = ok && (mask == nullptr || mask[(long long)ray * S + s] != 0);
+        float4 r = live ? raw[(long long)ray * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
         float alpha = ok ? 1.0f - expf(-fmaxf(r.w, 0.0f) * delta) : 0.0f;
         float t = (1.0f - alpha) + 1e-10f;                // factor contributed to later samples
         if (!ok) t = 1.0f;
@@ -66,10 +68,10 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict
 }
 
 int th_composite_launch(const float* raw, const float* z, const ThPointSrc& ps, int white, float* rgb, float* acc,
-                        float* depth, float* wout, hipStream_t s) {
+                        float* depth, float* wout, const uint8_t* mask, hipStream_t s) {
     if (ps.R <= 0) return 0;
     hipLaunchKernelGGL(composite_kernel, dim3(th_cdiv(ps.R, 4)), dim3(256), 0, s, (const float4*)raw, z, ps, white, rgb,
-                       acc, depth, wout);
+                       acc, depth, wout, mask);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -393,7 +393,7 @@ int th_composite(th_ctx* c, const float* raw, const float* z, const th_points* r
     TH_REQUIRE(c && raw && rays && rgb && acc && depth, "null argument");
     TH_REQUIRE(rays->ray_d != nullptr, "ray_d required");
     TH_REQUIRE(z || (rays->near && rays->far && rays->t_vals && rays->one_minus_t), "need z or near/far/t_vals");
-    return th_composite_launch(raw, z, th_src(rays), white, rgb, acc, depth, wout, (hipStream_t)stream);
+    return th_composite_launch(raw, z, th_src(rays), white, rgb, acc, depth, wout, nullptr, (hipStream_t)stream);
 }
 
 int th_gen_rays(th_ctx* c, const float* K_host, const float* R_host, const float* T_host, const float* bounds_host, int H,
@@ -579,7 +579,7 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
 // (th_render_prepass): it needs only the rays, the posed vertices and the two thresholds.  `prepass` = 1: run
 // stage A only and leave the counts on their way to host_pinned[16..]; 2: stage A already ran into this workspace.
 static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long long P, bool ray_mode, ThArena& ar,
-                        float** raw_out, int64_t* stats_host, hipStream_t s, int prepass = 0) {
+                        float** raw_out, const uint8_t** mask_out, int64_t* stats_host, hipStream_t s, int prepass = 0) {
     const int R = ps.R, S = ps.S, V = f->V;
     const bool compact = f->map_channels == TH_MAP_COMPACT;
     const int f_ld = compact ? 272 : 384;
@@ -627,7 +627,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         TH_TRY(th_view_embed_launch(ps.ray_d, R, 4, vd_all, s));
     }
     TH_TRY(th_compact_mask(mask, P, idx, info + 2, cws, cws_b, s));
-    TH_HIP(hipMemsetAsync(raw, 0, (size_t)P * 16, s));
+    // (raw is NOT cleared: its consumers read it through the mask -- 268 MB of memset + dense re-read saved per frame)
     delete sc;
     if (prepass == 1) {
         TH_HIP(hipMemcpyAsync(c->host_pinned + 16, info, 4 * 4, hipMemcpyDeviceToHost, s));
@@ -672,6 +672,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));
     }
     *raw_out = raw;
+    *mask_out = mask;
     return 0;
 }
 
@@ -695,13 +696,14 @@ int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* r
     ThArena ar(ws, ws_bytes);
     ThPointSrc ps = th_src(rays);
     float* raw = nullptr;
+    const uint8_t* mask = nullptr;
     // a matching th_render_prepass (same workspace, same ray arrays) already ran the hull / compaction stage
     const bool pre = c->prepass_valid && c->prepass_ws == ws && c->prepass_rays == (const void*)rays->ray_o &&
                      c->prepass_R == R && c->prepass_S == S;
     c->prepass_valid = false;
-    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, stats_host, s, pre ? 2 : 0));
+    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, stats_host, s, pre ? 2 : 0));
     ProfScope sc(prof_of(c), TH_PROF_COMPOSITE, s);
-    return th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, s);
+    return th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, mask, s);
 }
 
 int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, th_stream stream) {
@@ -720,7 +722,8 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     ThArena ar(ws, ws_bytes);
     ThPointSrc ps = th_src(rays);
     float* raw = nullptr;
-    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, nullptr, s, 1));
+    const uint8_t* mask = nullptr;
+    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, nullptr, s, 1));
     c->prepass_ws = ws; c->prepass_rays = rays->ray_o; c->prepass_R = R; c->prepass_S = S;
     c->prepass_valid = true;
     return 0;
@@ -732,9 +735,10 @@ int th_render_prepass_cancel(th_ctx* c) {
     return 0;
 }
 
-__global__ void extract_sigma_kernel(const float4* __restrict__ raw, long long P, float* __restrict__ out) {
+__global__ void extract_sigma_kernel(const float4* __restrict__ raw, const uint8_t* __restrict__ mask, long long P,
+                                     float* __restrict__ out) {
     long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i < P) out[i] = raw[i].w;
+    if (i < P) out[i] = mask[i] ? raw[i].w : 0.f;       // zero outside the hull (raw is only written where shaded)
 }
 
 size_t th_sigma_grid_workspace_bytes(const th_frame* f, int P) { return shade_ws_bytes(f, P, P); }
@@ -750,8 +754,9 @@ int th_eval_sigma_grid(th_ctx* c, const th_frame* f, const float* pts, int P, fl
     ThPointSrc ps{};
     ps.pts = pts; ps.R = P; ps.S = 1;
     float* raw = nullptr;
-    TH_TRY(shade_points(c, f, ps, P, false, ar, &raw, stats_host, s));
-    hipLaunchKernelGGL(extract_sigma_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, (const float4*)raw, (long long)P,
+    const uint8_t* mask = nullptr;
+    TH_TRY(shade_points(c, f, ps, P, false, ar, &raw, &mask, stats_host, s));
+    hipLaunchKernelGGL(extract_sigma_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, (const float4*)raw, mask, (long long)P,
                        sigma_out);
     TH_LAUNCH_CHECK();
     return 0;

@@ -292,8 +292,9 @@ int th_gather_rows_launch(const float* src, int width, const int32_t* sel, int d
 // raw[sel[p]] = raw_c[p] (rgb zeroed where sigma<=0 unless rgb_all)
 int th_scatter_raw_launch(const float* raw_c, const int32_t* sel, int P, int rgb_all, float* raw, hipStream_t s);
 // k_composite.hip
+// mask (optional, uint8 per sample): raw is only read where mask != 0, elsewhere it counts as zero
 int th_composite_launch(const float* raw, const float* z, const ThPointSrc& ps, int white, float* rgb, float* acc,
-                        float* depth, float* wout, hipStream_t s);
+                        float* depth, float* wout, const uint8_t* mask, hipStream_t s);
 int th_view_embed_launch(const float* d, int R, int res, float* out, hipStream_t s);
 // k_vit.hip
 size_t th_vit_ws(int V, int N, int dim, int heads);
