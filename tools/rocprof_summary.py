@@ -32,9 +32,12 @@ def main():
     frames = [e for n, s, e in rows if n.startswith("composite_kernel")]
     t_lo = frames[a.skip_frames - 1] if a.skip_frames and len(frames) >= a.skip_frames else 0
     nfr = len(frames) - (a.skip_frames if t_lo else 0)
+    # the timed frames end with their composite kernel: what bench.py launches after the last one (its sigma>0
+    # counting pass) is not part of a frame
+    t_hi = frames[-1] if frames else (rows[-1][2] if rows else 0)
     agg = defaultdict(lambda: [0, 0])
     for n, s, e in rows:
-        if s < t_lo:
+        if s < t_lo or s >= t_hi:
             continue
         agg[n][0] += 1
         agg[n][1] += e - s
