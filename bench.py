@@ -275,10 +275,26 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(batch_cpu, assign, args.samples, stride=args.cpu_stride)
-        print(json.dumps(res))
+    else:
+        res = None
+    finish(dist_on, res)
+
+
+def finish(dist_on, res):
+    """Tear the process group down first, flush whatever the C libraries (RCCL's version banner) still hold in
+    their stdio buffers, and only then print the ONE JSON line, so that it is the last line on stdout."""
     if dist_on:
+        import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if res is not None:
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_cpu, H, W, V):
@@ -362,18 +378,17 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    res = None
     if rank == 0:
-        print(json.dumps({
+        res = {
             "metric": unit_name, "value": units * args.steps / dt, "unit": unit_name.split(" ")[0].replace("sec", "s"),
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"S-{args.workload} (SURVEY 8d {'C3' if args.workload == 'orbit' else 'C5'}), V={V}, "
                                    f"N_c={args.nc}", "units_last_step": int(n_last),
                        "stats": {k: int(v) for k, v in (renderer.last_stats if args.workload == 'orbit' else mr.last_stats).items()},
-                       "parallelism": f"x{world}" if world > 1 else "single"}}))
-    if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+                       "parallelism": f"x{world}" if world > 1 else "single"}}
+    finish(dist_on, res)
 
 
 def count_sigma_positive(hip, net, frame, pts):
