@@ -49,10 +49,20 @@ def algorithmic_mlp_flops(V, n_valid, n_pos):
     return 2.0 * (n_valid * mac_sigma + n_pos * mac_rgb)
 
 
+def executed_mlp_flops(V, n_valid, n_pos):
+    """Dense MACs the fused kernel actually issues (per operand product triple counted once): the fc_0 token
+    part and fc_1 are folded away, the f-consuming layers have K = 272 (260 real), view_fc K = 288."""
+    row_sigma = 384 * 256 + 256 * 272 + 384 * 256 + 256 * 256            # kv1, alpha_res_0', kv0, fc_2
+    row_rgb = 256 * 256 + 256 * 272 + 128 * 288 + 128 * 272             # feature_fc, rgb_res_0', view_fc, rgb_res_1'
+    mac_sigma = V * row_sigma + 256 * 64 + 256 * 256                      # + fc_0 PE part, fc_3 (per sample)
+    mac_rgb = V * row_rgb + 128 * 128                                     # + fc_4
+    return 2.0 * (n_valid * mac_sigma + n_pos * mac_rgb)
+
+
 MFMA_F16_PEAK = 2500e12         # dense fp16/bf16 MFMA peak (AMD's 5 PF figure is 2:1 sparse)
 
 
-def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches):
+def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_step=None):
     """Dominant kernel = the per-point MLP.  `achieved` counts ALGORITHMIC fp32 FLOPs (the reference's
     layer shapes).  mode 1 (default): mlp_fused_kernel evaluates every fp32 MAC as three fp16 MFMA MACs
     (hi*hi + hi*lo + lo*hi, fp32 accumulate), so the pipe it is bound by is the fp16 MFMA pipe at one third
@@ -72,7 +82,10 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches):
                             "algorithmic 5.17e9",
             "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK,
             "algorithmic_flop_per_step": flops_step, "kernel_ms_per_step": stage_ms,
-            "launches_per_step": launches}
+            "launches_per_step": launches,
+            # what the matrix pipes really did (after the algebraic folds): executed FLOPs / time / peak
+            "executed_flop_per_step": executed_step,
+            "frac_executed": (executed_step / max(stage_ms * 1e-3, 1e-12) / peak) if (executed_step and mlp_mode == 1) else None}
 
 
 def load_assign(k, body):
@@ -270,7 +283,7 @@ def main():
                 "sigma_pos_samples_rank0": n_pos, "parallelism": f"ray-tile x{world}" if world > 1 else "single",
             },
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
-                                       mlp_launches / max(args.steps, 1)),
+                                       mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos)),
             "stage_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
