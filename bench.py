@@ -22,6 +22,7 @@ MLP on the fp32 MFMA pipe), measured live with HIP events on the launch stream;
 arithmetic) timed on this host on a bounded sample of the same frame.
 """
 import argparse
+import itertools
 import json
 import os
 import sys
@@ -160,6 +161,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=128)
     ap.add_argument("--mlp-mode", type=int, default=1, help="1 fused fp16-split MFMA kernel, 0 per-layer fp32 MFMA")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="render every frame with Renderer.render_fast (constants -> shading back to back on one stream) "
+                         "instead of Renderer.render_sequence (constants of frame i+1 on a second stream under the "
+                         "shading of frame i)")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="developer aid: on ONE GPU render rank 0's shard of an N-rank job (no collectives); the JSON "
+                         "line is then per-rank time, not a bench result")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,7 +203,8 @@ def main():
     batch = synth.batch_to(batch_cpu, dev)
     R = batch["ray_o"].shape[1]
     tile_major = os.environ.get("TH_RAY_ORDER", "tile") == "tile"
-    my_idx = shard_ray_indices(H, W, world, rank, tile=8, tile_major=tile_major).to(dev)
+    emu = args.emulate_world if world == 1 and args.emulate_world > 1 else 0
+    my_idx = shard_ray_indices(H, W, emu or world, rank, tile=8, tile_major=tile_major).to(dev)
     shard = dict(batch)
     for k in ("ray_o", "ray_d", "near", "far"):
         shard[k] = batch[k][:, my_idx].contiguous()
@@ -206,24 +215,45 @@ def main():
     hit_buf = torch.zeros(1, dtype=torch.int64, device=dev)
     gatherer = ImageGatherer(my_idx, R, world) if dist_on else None      # shard layout exchanged once
 
+    # The frames of the job arrive as a stream (the reference renders one dataset item after the other, run.py:96-118):
+    # Renderer.render_sequence computes the per-frame constants (encoder, paint, TransHE) of step i+1 on a second HIP
+    # stream while step i shades; every step still does one full frame of work (the look-ahead of the last timed
+    # step replaces the constants the first timed step received from the warm-up).
+    sharded = dist_on or emu
+    seq = None if args.no_pipeline else renderer.render_sequence(itertools.repeat(shard),
+                                                                  small_frame_rays=-1 if sharded else 2400)
+
+    # The reference's R' <= 2400 switch (if_clight_renderer.py:551) looks at the WHOLE frame.  Shards are rendered in the
+    # (overwhelmingly common) masked mode; the per-rank hit-ray counts th_render_rays reports anyway are summed with an
+    # 8-byte all-reduce and only if the frame total is <= 2400 the shard is rendered again in the reference's un-masked
+    # mode.  The all-reduce has its own communicator and stream and is checked AFTER the frame's work is queued, so the
+    # host never waits for the shading before it can queue the next frame.
+    ctl = dist.new_group() if dist_on else None
+    ctl_stream = torch.cuda.Stream(dev) if dist_on else None
+
     def step():
-        # Renderer.render_fast queues: ray-only stage (hull mask, compaction) -> per-frame constants (encoder, paint,
-        # TransHE) -> shading + compositing.
-        if not dist_on:
-            out = renderer.render_fast(shard)
+        # per frame: ray-only stage (hull mask, compaction) -> [per-frame constants] -> shading + compositing.
+        if seq is not None:
+            out = next(seq)
         else:
-            # The reference's R' <= 2400 switch (if_clight_renderer.py:551) looks at the WHOLE frame.  Render the
-            # shard in the (overwhelmingly common) masked mode, sum the per-rank hit-ray counts that
-            # th_render_rays reports anyway (8-byte all-reduce), and only if the frame total is <= 2400 render
-            # again in the reference's un-masked mode.
-            out = renderer.render_fast(shard, small_frame_rays=-1)
-            hit_buf.fill_(int(renderer.last_stats["hit_rays"]))
-            dist.all_reduce(hit_buf)
-            if int(hit_buf) <= 2400:
-                out = renderer.render_fast(shard, small_frame_rays=1 << 30)
+            out = renderer.render_fast(shard, small_frame_rays=-1 if sharded else 2400)
+        if dist_on:
+            with torch.cuda.stream(ctl_stream):
+                hit_buf.fill_(int(renderer.last_stats["hit_rays"]))
+                work = dist.all_reduce(hit_buf, group=ctl, async_op=True)
         local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
         if dist_on:
             img = gatherer(local)
+            with torch.cuda.stream(ctl_stream):
+                work.wait()
+                total = int(hit_buf)
+            if total <= 2400:
+                fr = renderer.last_frame if seq is not None else None
+                if fr is not None:
+                    fr.c.small_frame_rays = 1 << 30
+                out = renderer.render_fast(shard, frame=fr, small_frame_rays=1 << 30)
+                local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
+                img = gatherer(local)
         else:
             img = torch.zeros((R, 5), dtype=local.dtype, device=dev)
             img[my_idx] = local
@@ -281,12 +311,15 @@ def main():
                             f"hull mask + DPaRF + pixel gather + MLP + compositing",
                 "rays": R, "hit_rays_rank0": stats["hit_rays"], "valid_samples_rank0": n_valid,
                 "sigma_pos_samples_rank0": n_pos, "parallelism": f"ray-tile x{world}" if world > 1 else "single",
+                "frame_pipeline": "off" if seq is None else "constants(i+1) on a 2nd HIP stream under shading(i)",
             },
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
                                        mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos)),
             "stage_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if emu:
+            res["config"]["emulated_rank0_of"] = emu
+        if world == 1 and not args.no_cpu_baseline and not emu:
             res["cpu_baseline"] = cpu_baseline(batch_cpu, assign, args.samples, stride=args.cpu_stride)
     else:
         res = None
@@ -334,22 +367,34 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
             T = -R @ centre + np.array([0, 0, 3.0])
             return K, R.astype(np.float32), T.reshape(3, 1).astype(np.float32)
 
+        def frames():
+            """the video: one batch per target camera (made under render_sequence's side stream: ray generation
+            and the dealing of the masked ray list overlap the shading of the previous frame)"""
+            i = 0
+            while True:
+                rays = hip.gen_rays(*camera(i), bounds, H, W, device=dev)
+                n = rays["near"].numel()
+                mine = torch.arange(n, device=dev)
+                if world > 1:
+                    mine = mine[((mine // 64) % world) == rank]
+                sh = dict(batch)
+                for k in ("ray_o", "ray_d", "near", "far"):
+                    sh[k] = rays[k][mine][None]
+                sh["_orbit"] = (rays["mask_at_box"], mine, n)
+                yield sh
+                i += 1
+
+        seq = renderer.render_sequence(frames(), small_frame_rays=-1 if dist_on else 2400)
+
         def step(i):
-            rays = hip.gen_rays(*camera(i), bounds, H, W, device=dev)
-            n = rays["near"].numel()
-            mine = torch.arange(n, device=dev)
-            if world > 1:
-                mine = mine[((mine // 64) % world) == rank]
-            sh = dict(batch)
-            for k in ("ray_o", "ray_d", "near", "far"):
-                sh[k] = rays[k][mine][None]
-            out = renderer.render_fast(sh, small_frame_rays=-1 if dist_on else 2400)
+            out = next(seq)
+            mask_at_box, mine, n = renderer.last_batch["_orbit"]
             local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
             if dist_on:
                 from transhuman_amd.dist import gather_image
                 local = gather_image(local, mine, n, world)
             img = torch.zeros((H * W, 5), dtype=torch.float32, device=dev)
-            img[rays["mask_at_box"]] = local
+            img[mask_at_box] = local
             return img, n
         units, unit_name = H * W, "rays/sec (512x512 orbit, 64 samples/ray, rays generated on device)"
     else:

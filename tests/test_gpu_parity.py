@@ -254,6 +254,34 @@ def test_render_fast_vs_golden(hip, gpu, net, tag, H, focal):
     assert -10 * np.log10(max(mse, 1e-30)) > 80.0          # PSNR(build, reference) > 80 dB  
 
 
+def test_render_sequence_equals_per_frame_render(hip, gpu, net):
+    """Renderer.render_sequence (constants of frame i+1 on a second stream under the shading of frame i) returns,
+    for every frame of a stream of DIFFERENT frames, the image and statistics of render_fast on that frame; the
+    look-ahead never mixes frames up (each frame has its own images, pose and rays) and an exhausted stream ends it"""
+    _cfg(32)
+    r = _renderer(net)
+    frames = [synth.batch_to(synth.make_batch(64, 64, 3, seed=sd, focal=fc), gpu)
+              for sd, fc in ((0, 210.0), (1, 190.0), (2, 230.0), (0, 210.0))]
+    ref, ref_stats = [], []
+    for b in frames:
+        o = r.render_fast(b)
+        ref.append({k: v.clone() for k, v in o.items()})
+        ref_stats.append(dict(r.last_stats))
+    assert maxdiff(ref[0]["rgb_map"].cpu(), ref[1]["rgb_map"].cpu()) > 1e-2       # the frames really differ
+    for rep in range(2):                                                             # (second pass: warm side stream)
+        got = []
+        for i, o in enumerate(r.render_sequence(iter(frames))):
+            assert r.last_stats == ref_stats[i], i
+            got.append({k: v.clone() for k, v in o.items()})
+        assert len(got) == len(frames)
+        torch.cuda.synchronize()
+        for i in range(len(frames)):
+            for k in ("rgb_map", "acc_map", "depth_map"):
+                # (frame constants are recomputed: MIOpen conv summation order, like test_prepass_equals_plain_render)
+                assert maxdiff(got[i][k].cpu(), ref[i][k].cpu()) < 1e-5, (rep, i, k)
+    assert list(r.render_sequence(iter([]))) == []
+
+
 def test_render_ray_sharding_equals_full(hip, gpu, net):
     """rays are independent: rendering two interleaved shards == rendering the frame"""
     _cfg(32)

@@ -573,8 +573,10 @@ class Frame:
 _ws_cache = {}
 
 
-def _cached_ws(nbytes, device):
-    key = str(device)
+def _cached_ws(nbytes, device, slot=0):
+    """Render workspace, grown on demand.  ``slot`` selects one of several independent workspaces (the frame
+    pipeline of Renderer.render_sequence runs the hull stage of frame i+1 while frame i is still shading)."""
+    key = (str(device), slot)
     cur = _ws_cache.get(key)
     if cur is None or cur.numel() < nbytes:
         _ws_cache[key] = None
@@ -583,9 +585,10 @@ def _cached_ws(nbytes, device):
     return cur
 
 
-def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=2400, n_clusters=0):
+def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=2400, n_clusters=0, slot=0):
     """th_render_prepass: queue the ray-only front of render_rays (hull mask, compaction, ...) before the
-    per-frame constants exist.  The following render_rays on the same `points` picks it up."""
+    per-frame constants exist.  The following render_rays on the same `points` picks it up (and shades in the
+    workspace ``slot`` the prepass wrote)."""
     lib = load_library()
     v = _f32(verts_world).reshape(-1, 3)
     dev = v.device
@@ -593,7 +596,7 @@ def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=240
     f.verts_world, f.n_verts, f.V = v.data_ptr(), v.shape[0], V
     f.hull_thresh, f.small_frame_rays, f.map_channels = hull_thresh, small_frame_rays, 384
     f.n_clusters = n_clusters                  # (sizes the workspace exactly like the frame that follows)
-    ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(f), points.R, points.S), dev)
+    ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(f), points.R, points.S), dev, slot)
     points._prepass_keep = (v, ws)
     _check(lib.th_render_prepass(ctx(dev), C.byref(f), C.byref(points.c), _p(ws), ws.numel(), _stream()))
     points._prepass_pending = True          # only THIS Points object (it keeps the ray tensors alive) may consume it
@@ -610,10 +613,12 @@ def render_rays(net, frame, points, white_bkgd=False):
     dep = torch.empty(R, dtype=torch.float32, device=dev)
     if R == 0:                                   # empty ray list: nothing to launch (zero-size tensors have no address)
         return rgb, acc, dep, dict(hit_rays=0, valid_samples=0, unmasked=0)
-    ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(frame.c), R, points.S), dev)
-    if getattr(points, "_prepass_pending", False):
+    need = lib.th_render_workspace_bytes(C.byref(frame.c), R, points.S)
+    if getattr(points, "_prepass_pending", False) and points._prepass_keep[1].numel() >= need:
         points._prepass_pending = False
+        ws = points._prepass_keep[1]                        # the workspace its prepass ran in
     else:
+        ws = _cached_ws(need, dev)
         _check(lib.th_render_prepass_cancel(ctx(dev)))      # a token queued for other (possibly freed) rays
     stats = (C.c_int64 * 4)()
     _check(lib.th_render_rays(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(rgb), _p(acc), _p(dep), int(white_bkgd),
