@@ -295,12 +295,15 @@ int th_render_rays(th_ctx* ctx, const th_frame* f, const th_points* rays, float*
  * following th_render_rays (same ctx, same workspace, same ray arrays) neither repeats the stage nor stalls the
  * queue on the read-back.  `stream` may differ from the stream of th_render_rays (which waits on an event): on a
  * side stream the hull pass fills the chip while the latency-bound encoder / TransHE launches run.  The caller
- * orders the prepass after the previous use of the workspace.  Results are identical with or without it. */
+ * orders the prepass after the previous use of the workspace.  Up to 4 prepasses may be pending at once, each in
+ * its own workspace (a frame pipeline keeps the ray-only stage of the next frames in flight); th_render_rays
+ * consumes the one queued for ITS workspace.  Results are identical with or without it. */
 int th_render_prepass(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
                       size_t workspace_bytes, th_stream stream);
 /* Drops a pending prepass (a caller that abandons the frame it was queued for must not let a later
  * th_render_rays that happens to reuse the same buffers pick it up). */
-int th_render_prepass_cancel(th_ctx* ctx);
+int th_render_prepass_cancel(th_ctx* ctx);                          /* all pending prepasses */
+int th_render_prepass_drop(th_ctx* ctx, const void* workspace);     /* the one queued for this workspace */
 
 /* if_mesh_renderer.Renderer.render :46-100 up to `cube`: sigma_raw per grid
  * point (0 outside the hull).  pts [P,3] world space. */

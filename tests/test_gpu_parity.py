@@ -255,7 +255,8 @@ def test_render_fast_vs_golden(hip, gpu, net, tag, H, focal):
 
 
 def test_render_sequence_equals_per_frame_render(hip, gpu, net):
-    """Renderer.render_sequence (constants of frame i+1 on a second stream under the shading of frame i) returns,
+    """Renderer.render_sequence (hull stage + constants of the next frames on a second stream under the shading of
+    frame i, rotating workspaces, several th_render_prepass tokens pending) returns,
     for every frame of a stream of DIFFERENT frames, the image and statistics of render_fast on that frame; the
     look-ahead never mixes frames up (each frame has its own images, pose and rays) and an exhausted stream ends it"""
     _cfg(32)
@@ -268,9 +269,9 @@ def test_render_sequence_equals_per_frame_render(hip, gpu, net):
         ref.append({k: v.clone() for k, v in o.items()})
         ref_stats.append(dict(r.last_stats))
     assert maxdiff(ref[0]["rgb_map"].cpu(), ref[1]["rgb_map"].cpu()) > 1e-2       # the frames really differ
-    for rep in range(2):                                                             # (second pass: warm side stream)
+    for rep, la in enumerate((2, 1, 3)):                                             # look-ahead depths
         got = []
-        for i, o in enumerate(r.render_sequence(iter(frames))):
+        for i, o in enumerate(r.render_sequence(iter(frames), lookahead=la)):
             assert r.last_stats == ref_stats[i], i
             got.append({k: v.clone() for k, v in o.items()})
         assert len(got) == len(frames)

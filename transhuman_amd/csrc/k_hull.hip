@@ -138,12 +138,17 @@ __global__ void grid_fill_kernel(const float* __restrict__ verts, int nv, const 
 // holds ~40 of them, and a sample just outside the hull used to test all ~400 vertices of its 27 cells
 __global__ void grid_bbox_kernel(const GridInfo* __restrict__ gi, const int* __restrict__ starts,
                                  const float* __restrict__ sorted, float* __restrict__ bbox) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= gi->ncell) return;
+    // 8 lanes per cell (a surface cell holds ~40 vertices: one thread per cell was a 40-deep dependent load chain)
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, sub = threadIdx.x & 7;
+    const bool live = c < gi->ncell;
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-    for (int v = starts[c]; v < starts[c + 1]; ++v)
-        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], sorted[3 * v + a]); mx[a] = fmaxf(mx[a], sorted[3 * v + a]); }
-    for (int a = 0; a < 3; ++a) { bbox[6 * c + a] = mn[a]; bbox[6 * c + 3 + a] = mx[a]; }
+    if (live)
+        for (int v = starts[c] + sub, e = starts[c + 1]; v < e; v += 8)
+            for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], sorted[3 * v + a]); mx[a] = fmaxf(mx[a], sorted[3 * v + a]); }
+    for (int o = 1; o < 8; o <<= 1)
+        for (int a = 0; a < 3; ++a) { mn[a] = fminf(mn[a], __shfl_xor(mn[a], o)); mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o)); }
+    if (live && sub == 0)
+        for (int a = 0; a < 3; ++a) { bbox[6 * c + a] = mn[a]; bbox[6 * c + 3 + a] = mx[a]; }
 }
 
 // one thread per sample; a wave covers 64 consecutive samples (= one ray at S=64)
@@ -212,7 +217,7 @@ int th_hull_mask_launch(const ThPointSrc& ps, long long P, const float* verts, i
     hipLaunchKernelGGL(grid_count_kernel, dim3(th_cdiv(nv, 256)), dim3(256), 0, s, verts, nv, gi, counts);
     hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, gi, counts, starts, cursor);
     hipLaunchKernelGGL(grid_fill_kernel, dim3(th_cdiv(nv, 256)), dim3(256), 0, s, verts, nv, gi, cursor, sorted);
-    hipLaunchKernelGGL(grid_bbox_kernel, dim3(th_cdiv(GRID_MAX_CELLS, 256)), dim3(256), 0, s, gi, starts, sorted, bbox);
+    hipLaunchKernelGGL(grid_bbox_kernel, dim3(th_cdiv(GRID_MAX_CELLS * 8, 256)), dim3(256), 0, s, gi, starts, sorted, bbox);
     if (ray_hit) TH_HIP(hipMemsetAsync(ray_hit, 0, sizeof(int32_t) * (size_t)ps.R, s));
     hipLaunchKernelGGL(hull_mask_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, ps, P, gi, starts, sorted, bbox, thresh,
                        mask, ray_hit);

@@ -70,7 +70,8 @@ void th_ctx_destroy(th_ctx* c) {
     if (c->vit_store) (void)hipFree(c->vit_store);
     if (c->fused_store) (void)hipFree(c->fused_store);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
-    if (c->prepass_ev) (void)hipEventDestroy(c->prepass_ev);
+    for (auto& t : c->prepass)
+        if (t.ev) (void)hipEventDestroy(t.ev);
     delete[] c->vit.blocks;
     if (c->prof) {
         ThProf* p = (ThProf*)c->prof;
@@ -579,7 +580,8 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
 // (th_render_prepass): it needs only the rays, the posed vertices and the two thresholds.  `prepass` = 1: run
 // stage A only and leave the counts on their way to host_pinned[16..]; 2: stage A already ran into this workspace.
 static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long long P, bool ray_mode, ThArena& ar,
-                        float** raw_out, const uint8_t** mask_out, int64_t* stats_host, hipStream_t s, int prepass = 0) {
+                        float** raw_out, const uint8_t** mask_out, int64_t* stats_host, hipStream_t s, int prepass = 0,
+                        int slot = 0) {
     const int R = ps.R, S = ps.S, V = f->V;
     const bool compact = f->map_channels == TH_MAP_COMPACT;
     const int f_ld = compact ? 272 : 384;
@@ -607,9 +609,9 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     ThProf* pf = prof_of(c);
     int32_t* hp = c->host_pinned;
     if (prepass == 2) {
-        hp = c->host_pinned + 16;
-        TH_HIP(hipStreamWaitEvent(s, c->prepass_ev, 0));      // the prepass may have run on another stream
-        TH_HIP(hipEventSynchronize(c->prepass_ev));
+        hp = c->host_pinned + 16 + 4 * slot;
+        TH_HIP(hipStreamWaitEvent(s, c->prepass[slot].ev, 0));      // the prepass may have run on another stream
+        TH_HIP(hipEventSynchronize(c->prepass[slot].ev));
     } else {
     ProfScope* sc = new ProfScope(pf, TH_PROF_HULL, s);
     TH_HIP(hipMemsetAsync(info, 0, 16 * 4, s));
@@ -630,9 +632,9 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     // (raw is NOT cleared: its consumers read it through the mask -- 268 MB of memset + dense re-read saved per frame)
     delete sc;
     if (prepass == 1) {
-        TH_HIP(hipMemcpyAsync(c->host_pinned + 16, info, 4 * 4, hipMemcpyDeviceToHost, s));
-        if (!c->prepass_ev) TH_HIP(hipEventCreateWithFlags(&c->prepass_ev, hipEventDisableTiming));
-        TH_HIP(hipEventRecord(c->prepass_ev, s));
+        TH_HIP(hipMemcpyAsync(c->host_pinned + 16 + 4 * slot, info, 4 * 4, hipMemcpyDeviceToHost, s));
+        if (!c->prepass[slot].ev) TH_HIP(hipEventCreateWithFlags(&c->prepass[slot].ev, hipEventDisableTiming));
+        TH_HIP(hipEventRecord(c->prepass[slot].ev, s));
         return 0;
     }
     TH_HIP(hipMemcpyAsync(c->host_pinned, info, 4 * 4, hipMemcpyDeviceToHost, s));
@@ -698,10 +700,14 @@ int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* r
     float* raw = nullptr;
     const uint8_t* mask = nullptr;
     // a matching th_render_prepass (same workspace, same ray arrays) already ran the hull / compaction stage
-    const bool pre = c->prepass_valid && c->prepass_ws == ws && c->prepass_rays == (const void*)rays->ray_o &&
-                     c->prepass_R == R && c->prepass_S == S;
-    c->prepass_valid = false;
-    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, stats_host, s, pre ? 2 : 0));
+    int slot = -1;
+    for (int k = 0; k < th_ctx::kPrepassSlots; ++k) {
+        th_ctx::Prepass& t = c->prepass[k];
+        if (!t.valid || t.ws != ws) continue;
+        t.valid = false;                              // consumed, or stale for this workspace
+        if (t.rays == (const void*)rays->ray_o && t.R == R && t.S == S) slot = k;
+    }
+    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, stats_host, s, slot >= 0 ? 2 : 0, slot >= 0 ? slot : 0));
     ProfScope sc(prof_of(c), TH_PROF_COMPOSITE, s);
     return th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, mask, s);
 }
@@ -714,7 +720,15 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
                "th_render_prepass needs a complete ray description");
     hipStream_t s = (hipStream_t)stream;
     const int R = rays->R, S = rays->S;
-    c->prepass_valid = false;
+    // slot: the one already tied to this workspace, else a free one, else the oldest (round robin)
+    int slot = -1;
+    for (int k = 0; k < th_ctx::kPrepassSlots && slot < 0; ++k)
+        if (c->prepass[k].ws == ws) slot = k;
+    for (int k = 0; k < th_ctx::kPrepassSlots && slot < 0; ++k)
+        if (!c->prepass[k].valid) slot = k;
+    if (slot < 0) slot = c->prepass_rr = (c->prepass_rr + 1) % th_ctx::kPrepassSlots;
+    th_ctx::Prepass& t = c->prepass[slot];
+    t.valid = false;
     if (R <= 0) return 0;
     long long P = (long long)R * S;
     TH_REQUIRE(P < (1LL << 31), "R*S must fit in int32");
@@ -723,15 +737,22 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     ThPointSrc ps = th_src(rays);
     float* raw = nullptr;
     const uint8_t* mask = nullptr;
-    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, nullptr, s, 1));
-    c->prepass_ws = ws; c->prepass_rays = rays->ray_o; c->prepass_R = R; c->prepass_S = S;
-    c->prepass_valid = true;
+    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, nullptr, s, 1, slot));
+    t.ws = ws; t.rays = rays->ray_o; t.R = R; t.S = S;
+    t.valid = true;
     return 0;
 }
 
 int th_render_prepass_cancel(th_ctx* c) {
     TH_REQUIRE(c, "null ctx");
-    c->prepass_valid = false;
+    for (auto& t : c->prepass) t.valid = false;
+    return 0;
+}
+
+int th_render_prepass_drop(th_ctx* c, const void* ws) {
+    TH_REQUIRE(c, "null ctx");
+    for (auto& t : c->prepass)
+        if (t.ws == ws) t.valid = false;
     return 0;
 }
 

@@ -226,13 +226,20 @@ struct th_ctx {
     void* vit_store = nullptr;
     ThMlpPacked mlp;
     ThVitPacked vit;
-    int32_t* host_pinned = nullptr;   // small pinned read-back buffer ([0..15] immediate reads, [16..31] prepass)
-    // th_render_prepass token: the hull / compaction stage of the next th_render_rays already ran into `ws`
-    hipEvent_t prepass_ev = nullptr;
-    const void* prepass_ws = nullptr;
-    const void* prepass_rays = nullptr;
-    int prepass_R = 0, prepass_S = 0;
-    bool prepass_valid = false;
+    int32_t* host_pinned = nullptr;   // small pinned read-back buffer ([0..15] immediate reads, [16..31] prepass slots)
+    // th_render_prepass tokens: the hull / compaction stage of a coming th_render_rays already ran into `ws`.
+    // Several may be pending (a frame pipeline keeps the ray-only stage of the next frames in flight, each in its
+    // own workspace); th_render_rays picks the one queued for its workspace.  Counts land in host_pinned[16 + 4*slot].
+    struct Prepass {
+        hipEvent_t ev = nullptr;
+        const void* ws = nullptr;
+        const void* rays = nullptr;
+        int R = 0, S = 0;
+        bool valid = false;
+    };
+    static constexpr int kPrepassSlots = 4;
+    Prepass prepass[kPrepassSlots];
+    int prepass_rr = 0;
     int n_cu = 256;
     void* prof = nullptr;             // ThProf (th_api.hip)
 };

@@ -111,6 +111,7 @@ SYMBOLS = {
     "th_render_prepass": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
                                     C.c_void_p]),
     "th_render_prepass_cancel": (C.c_int, [C.c_void_p]),
+    "th_render_prepass_drop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_sigma_grid_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int]),
     "th_eval_sigma_grid": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
@@ -619,7 +620,7 @@ def render_rays(net, frame, points, white_bkgd=False):
         ws = points._prepass_keep[1]                        # the workspace its prepass ran in
     else:
         ws = _cached_ws(need, dev)
-        _check(lib.th_render_prepass_cancel(ctx(dev)))      # a token queued for other (possibly freed) rays
+        _check(lib.th_render_prepass_drop(ctx(dev), _p(ws)))  # a token queued there for other (possibly freed) rays
     stats = (C.c_int64 * 4)()
     _check(lib.th_render_rays(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(rgb), _p(acc), _p(dep), int(white_bkgd),
                               _p(ws), ws.numel(), stats, _stream()))

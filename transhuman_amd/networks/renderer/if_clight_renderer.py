@@ -164,73 +164,84 @@ class Renderer:
         self.last_stats = stats
         return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
 
-    def render_sequence(self, batches, ray_slice=None, small_frame_rays=2400):
+    def render_sequence(self, batches, ray_slice=None, small_frame_rays=2400, lookahead=1):
         """A stream of frames (free-viewpoint video / evaluation loops: the reference calls render_fast once per
         dataset item, run.py:96-118) as a two-stage software pipeline on two HIP streams:
 
-            current stream :             shading + compositing(i)                 -> shading + compositing(i+1) ...
-            side stream    : front(i) -> front(i+1) = hull stage + frame constants -> front(i+2) ...
+            current stream :                     shading + compositing(i)       -> shading + compositing(i+1) ...
+            side stream    : front(i), front(i+1) -> front(i+2) = hull stage + frame constants -> front(i+3) ...
 
         The ray-only hull stage and the per-frame constants (encoder, paint/group, TransHE: ~110 mostly
-        latency-bound launches) of frame i+1 run while the fused MLP of frame i fills the chip, instead of in front
-        of it, and the sample count of frame i+1 is on the host long before its shading is queued: the host never
-        waits for the device.  Two render workspaces alternate (the hull stage of i+1 writes while i shades).
-        Every frame executes exactly the work of ``render_fast`` -- same kernels, same order per frame.  Generator:
-        yields render_fast's dict per batch; ``self.last_batch`` / ``self.last_frame`` / ``self.last_stats`` describe
-        the frame just yielded.  One frame of look-ahead is taken from ``batches``; the iterator is advanced with the
-        side stream current, so device work it issues for the next frame (ray generation, SMPL skinning, uploads)
-        also runs under the shading of the current one."""
+        latency-bound launches) of the next ``lookahead`` frames run while the fused MLP of frame i fills the chip,
+        instead of in front of it, and the sample count of a frame is on the host long before its shading is
+        queued: the host never waits for the device.  lookahead + 1 render workspaces rotate (hull stages write
+        while earlier frames shade; a look-ahead beyond 1 only helps when the time per frame is very uneven).  Every frame executes exactly the work of ``render_fast`` -- same kernels, same
+        order per frame.  Generator: yields render_fast's dict per batch; ``self.last_batch`` / ``self.last_frame`` /
+        ``self.last_stats`` describe the frame just yielded.  ``lookahead`` frames are taken from ``batches`` ahead
+        of the one being shaded; the iterator is advanced with the side stream current, so device work it issues
+        for a coming frame (ray generation, SMPL skinning, uploads) also runs under the shading of the current one."""
+        import collections
         cfg = get_cfg()
         sl = slice(None) if ray_slice is None else ray_slice
         it = iter(batches)
+        lookahead = max(1, min(int(lookahead), 3))           # (th_render_prepass keeps at most 4 tokens)
+        nslots = lookahead + 1
 
-        def front(b, slot, side):
-            """side stream: hull stage of b's rays into workspace `slot`, then b's frame constants"""
+        def front(b, j, side):
+            """side stream: hull stage of b's rays into workspace 1 + j % nslots (0 is render_fast's), then b's frame
+            constants"""
             with torch.cuda.stream(side):
                 pts = hip.Points(b["ray_o"][0][sl], b["ray_d"][0][sl], b["near"][0][sl], b["far"][0][sl],
                                  n_samples=cfg.N_samples)
                 V = b["input_imgs"][0].reshape(-1, *b["input_imgs"][0].shape[2:]).shape[0]
                 if V <= 4 and pts.R > 0:
                     hip.render_prepass(pts, b["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
-                                       n_clusters=len(self.csr_offsets) - 1, slot=slot)
+                                       n_clusters=len(self.csr_offsets) - 1, slot=1 + j % nslots)
                 frame = self.prepare_frame(b)
                 frame.c.small_frame_rays = small_frame_rays
                 ready = torch.cuda.Event()
                 ready.record(side)
-            return pts, frame, ready
+            return b, pts, frame, ready
 
-        cur = next(it, None)
-        if cur is None:
+        first = next(it, None)
+        if first is None:
             return
-        dev = cur["ray_o"].device
+        dev = first["ray_o"].device
         side = self._dev.get(("side_stream", str(dev)))
         if side is None:
-            # high priority: its short kernels take the CUs the running MLP tiles release first (they would
-            # otherwise queue behind the thousands of pending MLP workgroups of the main stream)
-            side = self._dev[("side_stream", str(dev))] = torch.cuda.Stream(dev, priority=int(os.environ.get("TH_SIDE_PRIO", "-1")))
-        slot = 0
+            side = self._dev[("side_stream", str(dev))] = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        pts, frame, ready = front(cur, slot, side)
-        while cur is not None:
+        queue = collections.deque([front(first, 0, side)])
+        queued, more = 1, True
+
+        def pull():
+            nonlocal queued, more
+            if not more:
+                return
+            with torch.cuda.stream(side):
+                b = next(it, None)
+            if b is None:
+                more = False
+                return
+            queue.append(front(b, queued, side))
+            queued += 1
+
+        for _ in range(lookahead - 1):
+            pull()
+        while queue:
+            cur, pts, frame, ready = queue.popleft()
             main = torch.cuda.current_stream(dev)
             main.wait_event(ready)
-            # everything queued so far (the inputs of the next batch, the shading of the previous frame, which used
-            # the workspace the next hull stage writes) is ordered before the side stream's next piece of work;
+            # everything queued so far (inputs of coming batches, the shading of the previous frame -- the last user
+            # of the workspace the next hull stage writes) is ordered before the side stream's next piece of work;
             # this frame's shading is not
             fence = torch.cuda.Event()
             fence.record(main)
             rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd))
             side.wait_event(fence)
-            with torch.cuda.stream(side):
-                nxt = next(it, None)
-            if nxt is not None:
-                slot ^= 1
-                npts, nframe, ready = front(nxt, slot, side)
+            pull()
             self.last_stats, self.last_frame, self.last_batch = stats, frame, cur
             yield {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
-            if nxt is not None:
-                pts, frame = npts, nframe
-            cur = nxt
 
     def render(self, batch, is_train=True):
         """:486-498 -- no hull mask, every sample shaded, RGB everywhere.
