@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 from transhuman_amd import synth                                    # noqa: E402
 from transhuman_amd.config import get_cfg                           # noqa: E402
-from transhuman_amd.dist import shard_ray_indices, gather_image, ImageGatherer     # noqa: E402
+from transhuman_amd.dist import shard_ray_indices, gather_image, ImageGatherer, DeferredSum     # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12        # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 SIGMA_BIAS = -1.7
@@ -212,7 +212,6 @@ def main():
     if args.workload in ("orbit", "mesh"):
         return run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_cpu, H, W, V)
 
-    hit_buf = torch.zeros(1, dtype=torch.int64, device=dev)
     gatherer = ImageGatherer(my_idx, R, world) if dist_on else None      # shard layout exchanged once
 
     # The frames of the job arrive as a stream (the reference renders one dataset item after the other, run.py:96-118):
@@ -228,8 +227,7 @@ def main():
     # 8-byte all-reduce and only if the frame total is <= 2400 the shard is rendered again in the reference's un-masked
     # mode.  The all-reduce has its own communicator and stream and is checked AFTER the frame's work is queued, so the
     # host never waits for the shading before it can queue the next frame.
-    ctl = dist.new_group() if dist_on else None
-    ctl_stream = torch.cuda.Stream(dev) if dist_on else None
+    whole_frame_hits = DeferredSum(dev) if dist_on else None
 
     def step():
         # per frame: ray-only stage (hull mask, compaction) -> [per-frame constants] -> shading + compositing.
@@ -238,16 +236,11 @@ def main():
         else:
             out = renderer.render_fast(shard, small_frame_rays=-1 if sharded else 2400)
         if dist_on:
-            with torch.cuda.stream(ctl_stream):
-                hit_buf.fill_(int(renderer.last_stats["hit_rays"]))
-                work = dist.all_reduce(hit_buf, group=ctl, async_op=True)
+            whole_frame_hits.start(renderer.last_stats["hit_rays"])
         local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
         if dist_on:
             img = gatherer(local)
-            with torch.cuda.stream(ctl_stream):
-                work.wait()
-                total = int(hit_buf)
-            if total <= 2400:
+            if whole_frame_hits.result() <= 2400:
                 fr = renderer.last_frame if seq is not None else None
                 if fr is not None:
                     fr.c.small_frame_rays = 1 << 30

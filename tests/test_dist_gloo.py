@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from transhuman_amd.dist import ImageGatherer, gather_image, shard_ray_indices
+from transhuman_amd.dist import ImageGatherer, DeferredSum, gather_image, shard_ray_indices
 
 
 def _free_port():
@@ -42,6 +42,15 @@ def _worker(rank, world, port, H, W, q):
         for scale in (1.0, 2.0):
             ok = ok and torch.equal(ga(full[idx2] * scale), full * scale)
         ok = ok and torch.equal(torch.sort(idx2).values, idx)
+        # bench.py's step order: start the whole-frame count, gather the image on the default group, then read the
+        # count (own communicator: the two collectives never queue behind each other), for a few frames
+        ds = DeferredSum(torch.device("cpu"))
+        for fr in range(3):
+            mine = int((local[:, 3] > 0.5).sum()) + fr * (rank + 1)
+            ds.start(mine)
+            img2 = ga(full[idx2] * (fr + 1.0))
+            want = int((full[:, 3] > 0.5).sum()) + fr * world * (world + 1) // 2
+            ok = ok and ds.result() == want and torch.equal(img2, full * (fr + 1.0))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

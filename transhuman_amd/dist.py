@@ -104,3 +104,33 @@ class ImageGatherer:
         img = torch.zeros((self.n_rays, self.C), dtype=local.dtype, device=local.device)
         img.index_copy_(0, self.dst, vals.index_select(0, self.keep))
         return img
+
+
+class DeferredSum:
+    """Sum of one integer per rank (the whole-frame hit-ray count of the reference's R' <= 2400 rule,
+    if_clight_renderer.py:551) that never stalls the render stream: the 8-byte all-reduce runs on its own
+    communicator and (on a GPU) its own stream, ``start`` is called as soon as the rank knows its count and
+    ``result`` after the frame's work has been queued -- it waits for that small collective only, not for the
+    shading queued on the render stream in between."""
+
+    def __init__(self, device):
+        import torch.distributed as dist
+        self.group = dist.new_group()                      # own communicator: never queued behind the image gather
+        self.buf = torch.zeros(1, dtype=torch.int64, device=device)
+        self.stream = torch.cuda.Stream(device) if torch.device(device).type == "cuda" else None
+        self.work = None
+
+    def _ctx(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def start(self, n):
+        import torch.distributed as dist
+        with self._ctx():
+            self.buf.fill_(int(n))
+            self.work = dist.all_reduce(self.buf, group=self.group, async_op=True)
+
+    def result(self):
+        with self._ctx():
+            self.work.wait()
+            return int(self.buf)
