@@ -107,9 +107,11 @@ def build_net(device):
     return net.to(device)
 
 
-def cpu_baseline(batch, assign, n_samples, stride=64):
+def cpu_baseline(batch, assign, n_samples, stride=64, gpu_img=None):
     """Oracle on the host cores, bounded sample: every `stride`-th ray of the same frame
-    (frame constants computed once, per-ray part extrapolated linearly)."""
+    (frame constants computed once, per-ray part extrapolated linearly).  With `gpu_img` ([R,5] rgb|acc|depth of
+    the timed GPU frame) the same rays double as the in-job parity check: max |rgb,acc| difference and PSNR
+    (-10 log10 mse, if_nerf.py:34-37) of the GPU image against the oracle."""
     from oracle import th_oracle as O
     from transhuman_amd.networks.cross_transformer import Network
     # torch's intra-op pool stops scaling (and thrashes) far below the 256 hardware threads of the
@@ -133,17 +135,27 @@ def cpu_baseline(batch, assign, n_samples, stride=64):
         t0 = time.perf_counter()
         hol, pix = O.encoder_forward(sd, batch["input_imgs"][0][0])
         t1 = time.perf_counter()
-        O.render_fast(sd, sub, hol, pix, off, mem, can_c, n_samples=n_samples, vit_depth=12, small_frame_rays=-1)
+        o_out, _ = O.render_fast(sd, sub, hol, pix, off, mem, can_c, n_samples=n_samples, vit_depth=12,
+                                 small_frame_rays=-1)
         t2 = time.perf_counter()
         fc_t0 = time.perf_counter()
         O.frame_constants(sd, batch, hol, off, mem, can_c, 12)
         t_fc = time.perf_counter() - fc_t0
     t_rays = max((t2 - t1) - t_fc, 1e-9)
     est_frame = (t1 - t0) + t_fc + t_rays * (R / Rs)
-    return {"value": R / est_frame, "unit": "rays/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/th_oracle.py (torch CPU fp32, {cores} threads): every {stride}th ray of the same "
-                      f"512x512x{n_samples} frame ({Rs} rays, brute-force K=1 hull test), per-ray time scaled to "
-                      f"{R} rays + per-frame constants once; measured {t2 - t0:.1f} s"}
+    res = {"value": R / est_frame, "unit": "rays/s", "cores": cores, "kind": "port",
+           "sample": f"oracle/th_oracle.py (torch CPU fp32, {cores} threads): every {stride}th ray of the same "
+                     f"512x512x{n_samples} frame ({Rs} rays, brute-force K=1 hull test), per-ray time scaled to "
+                     f"{R} rays + per-frame constants once; measured {t2 - t0:.1f} s"}
+    if gpu_img is not None:
+        g = gpu_img[::stride].detach().cpu().double()
+        ref = torch.cat([o_out["rgb_map"][0], o_out["acc_map"][0][:, None]], dim=1).double()
+        diff = g[:, :4] - ref
+        hit = int((o_out["acc_map"][0] > 0).sum())
+        res["gpu_vs_oracle"] = {"rays": Rs, "rays_hit": hit, "max_abs_rgb_acc": float(diff.abs().max()),
+                                "psnr_rgb_db": float(-10.0 * torch.log10(torch.clamp((diff[:, :3] ** 2).mean(), min=1e-30))),
+                                "bar": "1e-4 on rgb/acc (BASELINE.json north_star)"}
+    return res
 
 
 def main():
@@ -313,7 +325,7 @@ def main():
         if emu:
             res["config"]["emulated_rank0_of"] = emu
         if world == 1 and not args.no_cpu_baseline and not emu:
-            res["cpu_baseline"] = cpu_baseline(batch_cpu, assign, args.samples, stride=args.cpu_stride)
+            res["cpu_baseline"] = cpu_baseline(batch_cpu, assign, args.samples, stride=args.cpu_stride, gpu_img=img)
     else:
         res = None
     finish(dist_on, res)
