@@ -175,6 +175,16 @@ int th_paint_group_nhwc(th_ctx* ctx, const float* map_nhwc, int V, int H, int W,
                         const int32_t* csr_members, int n_clusters, float* tokens_out, void* workspace,
                         size_t workspace_bytes, th_stream stream);
 
+/* K11 -- train-mode BatchNorm2d (+ residual) (+ ReLU), NCHW fp32: the elementwise tail of every ResNet stage of
+ * SpatialEncoder.forward (encoder.py:114-126; torchvision BasicBlock: bn -> relu, bn -> += identity -> relu) with
+ * the network in train() as run.py:29 leaves it: batch statistics (biased variance), running statistics updated with
+ * `momentum` (unbiased variance), exactly F.batch_norm(training=True).  res may be NULL; running_* may be NULL (no
+ * update); gamma/beta may be NULL (1 / 0).  y may alias x.  workspace: th_bn_workspace_bytes(N, C, H*W). */
+size_t th_bn_workspace_bytes(int N, int C, int HW);
+int th_bn_act(th_ctx* ctx, const float* x, const float* residual, int N, int C, int HW, const float* gamma,
+              const float* beta, float eps, float momentum, float* running_mean, float* running_var, int relu,
+              float* y, void* workspace, size_t workspace_bytes, th_stream stream);
+
 /* ---- K3: TransHE (ViT-tiny) ---------------------------------------------- */
 /* VisionTransformer.forward, vision_transformer.py:371-383.  x [V,N,dim]
  * tokens, pe [V,N,dim] sin-cos table (host-built, see vision_transformer.py),

@@ -254,6 +254,50 @@ def test_render_fast_vs_golden(hip, gpu, net, tag, H, focal):
     assert -10 * np.log10(max(mse, 1e-30)) > 80.0          # PSNR(build, reference) > 80 dB  
 
 
+def test_fused_bn_trunk_equals_stock_modules(hip, gpu):
+    """K11 (hip.bn_act: train-mode BatchNorm + residual + ReLU) against torch's modules on the encoder trunk: latents,
+    running statistics and counters after two forwards; plus odd shapes / no-affine / no-residual directly"""
+    import copy
+    from transhuman_amd.networks.encoder import SpatialEncoder
+    torch.manual_seed(3)
+    a = SpatialEncoder().to(gpu).train()
+    b = copy.deepcopy(a)
+    for it in range(2):
+        x = torch.rand(3, 3, 128, 96, device=gpu)
+        la = a.trunk(x, fused_bn=True)
+        lb = b.trunk(x, fused_bn=False)
+        for u, v in zip(la, lb):
+            assert u.shape == v.shape and maxdiff(u.cpu(), v.cpu()) < 2e-5, it
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if "layer3" in k or "layer4" in k:
+            continue
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sb[k]), k
+        elif "running_" in k:
+            assert maxdiff(sa[k].cpu(), sb[k].cpu()) < 1e-6, k
+    assert int(sa["model.bn1.num_batches_tracked"]) == 2
+    rs = np.random.RandomState(0)
+    for (N, C, H, W) in ((1, 5, 7, 9), (2, 3, 33, 31), (3, 64, 64, 64), (1, 2, 300, 300)):
+        x = torch.from_numpy(rs.normal(size=(N, C, H, W)).astype(np.float32) * 2 + 0.5).to(gpu)
+        r = torch.from_numpy(rs.normal(size=(N, C, H, W)).astype(np.float32)).to(gpu)
+        for affine, res, relu in ((True, None, True), (True, r, True), (False, r, False)):
+            bn1 = torch.nn.BatchNorm2d(C, affine=affine).to(gpu).train()
+            if affine:
+                with torch.no_grad():
+                    bn1.weight.uniform_(0.5, 1.5); bn1.bias.uniform_(-0.5, 0.5)
+            bn2 = copy.deepcopy(bn1)
+            got = hip.bn_act(x, bn1, residual=res, relu=relu)
+            ref = bn2(x)
+            if res is not None:
+                ref = ref + res
+            if relu:
+                ref = torch.relu(ref)
+            assert maxdiff(got.cpu(), ref.cpu()) < 5e-6, (N, C, H, W, affine, relu)
+            assert maxdiff(bn1.running_mean.cpu(), bn2.running_mean.cpu()) < 1e-6
+            assert maxdiff(bn1.running_var.cpu(), bn2.running_var.cpu()) < 1e-6
+
+
 def test_render_sequence_equals_per_frame_render(hip, gpu, net):
     """Renderer.render_sequence (hull stage + constants of the next frames on a second stream under the shading of
     frame i, rotating workspaces, several th_render_prepass tokens pending) returns,

@@ -151,3 +151,123 @@ int th_segmean_masked_launch(const float* rows, int V, int width, const uint8_t*
     TH_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// K11: train-mode BatchNorm2d (+ residual) (+ ReLU) on NCHW tensors -- the elementwise tail of every ResNet stage of
+// SpatialEncoder (encoder.py:114-126 runs torchvision's BasicBlocks with the network in train(), run.py:29: batch
+// statistics, running statistics updated).  torch issues BN, the num_batches_tracked increment, the ReLU and the
+// residual add as 3-4 launches per site; here: one statistics pass + one apply pass.
+//   y = (x - mean_c) * rsqrt(var_c + eps) * gamma_c + beta_c  [+ res]  [relu]       (var biased, like F.batch_norm)
+//   running_mean = (1-m) running_mean + m mean ; running_var = (1-m) running_var + m var * n/(n-1)
+// Statistics: fixed-order partial sums in float64 (per (n, c) plane slice) -> deterministic, and at least as accurate
+// as the fp32 reductions of the stock kernels.
+// ---------------------------------------------------------------------------
+#define BN_SPLIT_ELEMS 16384       // elements of one (n, c) plane per statistics workgroup
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int C, int HW, int splits,
+                                                       double* __restrict__ part /*[C][N*splits][2]*/, int NS) {
+    const int c = blockIdx.x, ns = blockIdx.y, n = ns / splits, sp = ns - n * splits;
+    const int per = (HW + splits - 1) / splits;
+    const int lo = sp * per, hi = min(HW, lo + per);
+    const float* p = x + ((long long)n * C + c) * HW;
+    double s = 0.0, q = 0.0;
+    if ((HW & 3) == 0 && (lo & 3) == 0) {
+        const int hi4 = lo + ((hi - lo) & ~3);
+        for (int i = lo + 4 * threadIdx.x; i < hi4; i += 4 * 256) {
+            const float4 v = *reinterpret_cast<const float4*>(p + i);
+            s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+            q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+        }
+        for (int i = hi4 + threadIdx.x; i < hi; i += 256) { s += p[i]; q += (double)p[i] * p[i]; }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) { s += p[i]; q += (double)p[i] * p[i]; }
+    }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    __shared__ double sh[8];
+    if ((threadIdx.x & 63) == 0) { sh[2 * (threadIdx.x >> 6)] = s; sh[2 * (threadIdx.x >> 6) + 1] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((long long)c * NS + ns) * 2 + 0] = (sh[0] + sh[2]) + (sh[4] + sh[6]);
+        part[((long long)c * NS + ns) * 2 + 1] = (sh[1] + sh[3]) + (sh[5] + sh[7]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ res, int C,
+                                                       int HW, int splits, const double* __restrict__ part, int NS,
+                                                       long long count, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, float momentum,
+                                                       float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                       int relu, float* __restrict__ y) {
+    const int c = blockIdx.x, ns = blockIdx.y, n = ns / splits, sp = ns - n * splits;
+    __shared__ float ss[2];
+    if (threadIdx.x == 0) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < NS; ++k) { s += part[((long long)c * NS + k) * 2]; q += part[((long long)c * NS + k) * 2 + 1]; }
+        const double mean = s / (double)count;
+        double var = q / (double)count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+        ss[0] = invstd * g;
+        ss[1] = (float)mean;
+        if (ns == 0 && run_mean != nullptr) {
+            const double unb = count > 1 ? var * ((double)count / (double)(count - 1)) : var;
+            run_mean[c] = (float)((1.0 - (double)momentum) * (double)run_mean[c] + (double)momentum * mean);
+            run_var[c] = (float)((1.0 - (double)momentum) * (double)run_var[c] + (double)momentum * unb);
+        }
+    }
+    __syncthreads();
+    const float sc = ss[0], mean = ss[1], b = beta ? beta[c] : 0.f;
+    const int per = (HW + splits - 1) / splits;
+    const int lo = sp * per, hi = min(HW, lo + per);
+    const long long base = ((long long)n * C + c) * HW;
+    const float* p = x + base;
+    const float* r = res ? res + base : nullptr;
+    float* o = y + base;
+    if ((HW & 3) == 0 && (lo & 3) == 0) {
+        const int hi4 = lo + ((hi - lo) & ~3);
+        for (int i = lo + 4 * threadIdx.x; i < hi4; i += 4 * 256) {
+            float4 v = *reinterpret_cast<const float4*>(p + i);
+            v.x = (v.x - mean) * sc + b; v.y = (v.y - mean) * sc + b; v.z = (v.z - mean) * sc + b; v.w = (v.w - mean) * sc + b;
+            if (r) {
+                const float4 a = *reinterpret_cast<const float4*>(r + i);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+            }
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(o + i) = v;
+        }
+        for (int i = hi4 + threadIdx.x; i < hi; i += 256) {
+            float v = (p[i] - mean) * sc + b;
+            if (r) v += r[i];
+            o[i] = relu ? fmaxf(v, 0.f) : v;
+        }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += 256) {
+            float v = (p[i] - mean) * sc + b;
+            if (r) v += r[i];
+            o[i] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+size_t th_bn_ws(int N, int C, int HW) {
+    const int splits = (HW + BN_SPLIT_ELEMS - 1) / BN_SPLIT_ELEMS;
+    return th_align((size_t)C * N * splits * 2 * sizeof(double));
+}
+
+int th_bn_act_launch(const float* x, const float* res, int N, int C, int HW, const float* gamma, const float* beta,
+                     float eps, float momentum, float* run_mean, float* run_var, int relu, float* y, void* ws,
+                     size_t ws_bytes, hipStream_t s) {
+    TH_REQUIRE(N > 0 && C > 0 && HW > 0, "empty tensor");
+    TH_REQUIRE(ws_bytes >= th_bn_ws(N, C, HW), "workspace too small");
+    TH_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0, "tensors must be 16-byte aligned");
+    const int splits = (HW + BN_SPLIT_ELEMS - 1) / BN_SPLIT_ELEMS;
+    const int NS = N * splits;
+    TH_REQUIRE(NS <= 65535, "too many plane slices");
+    double* part = (double*)ws;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, NS), dim3(256), 0, s, x, C, HW, splits, part, NS);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(C, NS), dim3(256), 0, s, x, res, C, HW, splits, part, NS,
+                       (long long)N * HW, gamma, beta, eps, momentum, run_mean, run_var, relu, y);
+    TH_LAUNCH_CHECK();
+    return 0;
+}

@@ -363,6 +363,17 @@ int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, i
 
 size_t th_vit_workspace_bytes(int V, int N, int dim, int heads) { return th_vit_ws(V, N, dim, heads); }
 
+size_t th_bn_workspace_bytes(int N, int C, int HW) { return th_bn_ws(N, C, HW); }
+
+int th_bn_act(th_ctx* c, const float* x, const float* residual, int N, int C, int HW, const float* gamma, const float* beta,
+              float eps, float momentum, float* running_mean, float* running_var, int relu, float* y, void* ws,
+              size_t ws_bytes, th_stream stream) {
+    TH_REQUIRE(c && x && y && ws, "null argument");
+    TH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean / running_var go together");
+    return th_bn_act_launch(x, residual, N, C, HW, gamma, beta, eps, momentum, running_mean, running_var, relu, y, ws,
+                            ws_bytes, (hipStream_t)stream);
+}
+
 int th_vit_forward(th_ctx* c, const float* x, const float* pe, int V, int N, float* out, void* ws, size_t ws_bytes,
                    th_stream stream) {
     TH_REQUIRE(c && x && pe && out && ws, "null argument");

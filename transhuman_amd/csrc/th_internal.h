@@ -320,6 +320,10 @@ int th_upsample_concat_launch(const float* img, const float* lat0, const float* 
                               const int* dims, int V, int H, int W, const float* wc, const float* bc, float* out,
                               hipStream_t s);
 // W' [N,260] = [W[:, :256] | W[:, 256:384] Wc | 0], b' = b + W[:, 256:384] bc  (fp64 accumulation)
+size_t th_bn_ws(int N, int C, int HW);
+int th_bn_act_launch(const float* x, const float* res, int N, int C, int HW, const float* gamma, const float* beta,
+                     float eps, float momentum, float* run_mean, float* run_var, int relu, float* y, void* ws,
+                     size_t ws_bytes, hipStream_t s);
 int th_fold_color_launch(const float* W /*[N,384]*/, const float* b, const float* wc /*[128,3]*/, const float* bc,
                          int N, float* Wo /*[N,260]*/, float* bo /*[N]*/, hipStream_t s);
 int th_segmean_masked_launch(const float* rows, int V, int width, const uint8_t* viz, int nv, const int32_t* off,

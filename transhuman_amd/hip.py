@@ -110,6 +110,10 @@ SYMBOLS = {
                                  C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
     "th_render_prepass": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
                                     C.c_void_p]),
+    "th_bn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "th_bn_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                            C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
+                            C.c_void_p]),
     "th_render_prepass_cancel": (C.c_int, [C.c_void_p]),
     "th_render_prepass_drop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_sigma_grid_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int]),
@@ -384,6 +388,25 @@ def paint_group_nhwc(map_nhwc, verts_world, cams, scale_xy, vizmap, red_w, red_b
                                    _p(viz), C.byref(lin), C.byref(lift) if lift is not None else None, _p(off), _p(mem),
                                    nc, _p(tokens), _p(ws), ws.numel(), _stream()))
     return tokens
+
+
+def bn_act(x, bn, residual=None, relu=True):
+    """th_bn_act: train-mode nn.BatchNorm2d `bn` on x [N,C,H,W] (+ residual) (+ ReLU) in two launches; updates
+    bn.running_mean / running_var like the module (num_batches_tracked is left to the caller)."""
+    lib = load_library()
+    assert bn.training and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    N, Cc, H, W = x.shape
+    ws = _ws(lib.th_bn_workspace_bytes(N, Cc, H * W), x.device)
+    y = torch.empty_like(x)
+    track = bn.track_running_stats and bn.running_mean is not None
+    assert bn.momentum is not None, "cumulative-average BatchNorm (momentum=None) is not handled here"
+    mom = float(bn.momentum)
+    r = None if residual is None else residual.contiguous()
+    _check(lib.th_bn_act(ctx(x.device), _p(x), None if r is None else _p(r), N, Cc, H * W,
+                         None if bn.weight is None else _p(bn.weight), None if bn.bias is None else _p(bn.bias),
+                         float(bn.eps), mom, _p(bn.running_mean) if track else None,
+                         _p(bn.running_var) if track else None, int(relu), _p(y), _p(ws), ws.numel(), _stream()))
+    return y
 
 
 def segment_mean(src, off, mem):

@@ -9,6 +9,8 @@ is restated here with torchvision's parameter names (``encoder.model.*``,
 including the never-executed layer3/layer4) to stay ``strict=True``
 checkpoint-compatible.  Runs as stock PyTorch-ROCm (MIOpen) ops.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -87,16 +89,52 @@ class SpatialEncoder(nn.Module):
         self.PE_color = _PEBuffers(10)                                                 # encoder.py:93 (unused)
         self.upsample_color = nn.Conv2d(3, 128, 1)                                     # encoder.py:95
 
-    def trunk(self, x):
+    def trunk(self, x, fused_bn=None):
         """ResNet18 stem -> the three latents (64ch @H/2, 64ch @H/4, 128ch @H/8), encoder.py:114-126.
-        Stock torch/MIOpen convolutions + train-mode BatchNorm."""
+        Convolutions are stock torch/MIOpen ops.  On a GPU with the network in train() (run.py:29) the elementwise
+        tail of every stage -- train-mode BatchNorm, ReLU, residual add -- runs as K11 (hip.bn_act: one statistics
+        pass + one apply pass instead of torch's 3-4 launches per site; ``fused_bn=False`` or TH_STOCK_BN=1 keeps the
+        stock modules); running statistics and num_batches_tracked evolve as in the stock modules."""
         m = self.model
+        if fused_bn is None:
+            fused_bn = x.is_cuda and os.environ.get("TH_STOCK_BN") != "1"
+        if fused_bn and self._bn_sites_fusable():
+            return self._trunk_fused_bn(x)
         x = m.relu(m.bn1(m.conv1(x)))
         lat = [x]
         x = m.layer1(m.maxpool(x))
         lat.append(x)
         x = m.layer2(x)
         lat.append(x)
+        return lat
+
+    def _bn_sites(self):
+        m = self.model
+        sites = [m.bn1]
+        for layer in (m.layer1, m.layer2):
+            for blk in layer:
+                sites += [blk.bn1, blk.bn2] + ([blk.downsample[1]] if blk.downsample is not None else [])
+        return sites
+
+    def _bn_sites_fusable(self):
+        return all(isinstance(b, nn.BatchNorm2d) and b.training and b.momentum is not None for b in self._bn_sites())
+
+    def _trunk_fused_bn(self, x):
+        from .. import hip
+        m = self.model
+        x = hip.bn_act(m.conv1(x), m.bn1, relu=True)
+        lat = [x]
+        x = m.maxpool(x)
+        for layer in (m.layer1, m.layer2):
+            for blk in layer:
+                idt = x if blk.downsample is None else hip.bn_act(blk.downsample[0](x), blk.downsample[1], relu=False)
+                y = hip.bn_act(blk.conv1(x), blk.bn1, relu=True)
+                x = hip.bn_act(blk.conv2(y), blk.bn2, residual=idt, relu=True)
+            lat.append(x)
+        counters = [b.num_batches_tracked for b in self._bn_sites()
+                    if b.track_running_stats and b.num_batches_tracked is not None]
+        if counters:
+            torch._foreach_add_(counters, 1)            # one launch for the ten counters
         return lat
 
     @staticmethod
