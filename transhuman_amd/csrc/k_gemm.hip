@@ -65,12 +65,19 @@ __device__ __forceinline__ float th_gelu_erf(float x) {
     return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-template <int NT, int MT>
+// LN = true (MT = 1, K <= 256, K % 4 == 0): the rows of A are layer-normalised on their way into LDS,
+// a = (a - mean_row) * rstd_row * ln_w[k] + ln_b[k] with the two-pass statistics of layernorm_kernel (k_vit.hip) --
+// the pre-LN of a transformer block costs no launch of its own (every column workgroup of a row block recomputes the
+// 16 row statistics: 3072 values, a fraction of a microsecond).
+template <int NT, int MT, bool LN = false>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restrict__ A, int lda, int M, int Kreal,
                                                             const float* __restrict__ Wp,
                                                             const float* __restrict__ bias, int N, int NB, int KB,
-                                                            float* __restrict__ C, int ldc, int flags) {
+                                                            float* __restrict__ C, int ldc, int flags,
+                                                            const float* __restrict__ ln_w = nullptr,
+                                                            const float* __restrict__ ln_b = nullptr, float ln_eps = 0.f) {
     extern __shared__ __attribute__((aligned(16))) float As[];   // [64][GEMM_LDS_STRIDE]
+    __shared__ float ln_mean[16], ln_rstd[16];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -129,11 +136,50 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
             areg[i] = v;
         }
     };
+    if (LN) {
+        // 16 threads per row: K / 16 (<= 16) values each, 16-lane shuffle reductions; two passes like layernorm_kernel
+        const int row = tid >> 4, sub = tid & 15, gm = m0 + row;
+        float v[16];
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * (sub + 16 * q);
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gm < M && k < Kreal) x = *reinterpret_cast<const float4*>(A + (long long)gm * lda + k);
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            sum += (x.x + x.y) + (x.z + x.w);
+        }
+        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum / (float)Kreal;
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * (sub + 16 * q);
+            if (k < Kreal) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float d = v[4 * q + e] - mean; ss += d * d; }
+            }
+        }
+        for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o);
+        if (sub == 0) { ln_mean[row] = mean; ln_rstd[row] = 1.0f / __fsqrt_rn(ss / (float)Kreal + ln_eps); }
+        __syncthreads();
+    }
     load_a(0);
     for (int ch = 0; ch < nchunks; ++ch) {
 #pragma unroll
         for (int i = 0; i < 2 * MT; ++i) {
             int idx = tid + 256 * i;
+            if (LN) {
+                const int row = idx >> 5, gk = ch * GEMM_KC + 4 * (idx & 31);
+                if (gk < Kreal) {
+                    const float mu = ln_mean[row], rs = ln_rstd[row];
+                    const float4 w4 = *reinterpret_cast<const float4*>(ln_w + gk), b4 = *reinterpret_cast<const float4*>(ln_b + gk);
+                    areg[i].x = (areg[i].x - mu) * rs * w4.x + b4.x;
+                    areg[i].y = (areg[i].y - mu) * rs * w4.y + b4.y;
+                    areg[i].z = (areg[i].z - mu) * rs * w4.z + b4.z;
+                    areg[i].w = (areg[i].w - mu) * rs * w4.w + b4.w;
+                }
+            }
             *reinterpret_cast<float4*>(&As[(idx >> 5) * GEMM_LDS_STRIDE + 4 * (idx & 31)]) = areg[i];
         }
         __syncthreads();
@@ -202,7 +248,24 @@ static int pick_nt(int NB) {
     return best;
 }
 
+static int gemm_launch(const float* A, int lda, int M, const ThPacked& W, int flags, float* C, int ldc,
+                       const float* ln_w, const float* ln_b, float ln_eps, hipStream_t s);
+
 int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float* C, int ldc, hipStream_t s) {
+    return gemm_launch(A, lda, M, W, flags, C, ldc, nullptr, nullptr, 0.f, s);
+}
+
+bool th_gemm_ln_ok(int M, const ThPacked& W) { return M > 0 && M <= 8192 && W.K <= 256 && (W.K & 3) == 0; }
+
+// C = act(LayerNorm(A; ln_w, ln_b, eps) W^T + b): rows normalised inside the GEMM (th_gemm_ln_ok shapes only)
+int th_gemm_ln(const float* A, int lda, int M, const ThPacked& W, const float* ln_w, const float* ln_b, float eps,
+               int flags, float* C, int ldc, hipStream_t s) {
+    TH_REQUIRE(th_gemm_ln_ok(M, W) && ln_w && ln_b, "th_gemm_ln: unsupported shape");
+    return gemm_launch(A, lda, M, W, flags, C, ldc, ln_w, ln_b, eps, s);
+}
+
+static int gemm_launch(const float* A, int lda, int M, const ThPacked& W, int flags, float* C, int ldc,
+                       const float* ln_w, const float* ln_b, float ln_eps, hipStream_t s) {
     if (M <= 0) return 0;
     TH_REQUIRE((lda & 3) == 0 && (((uintptr_t)A) & 15) == 0, "A must be 16-byte aligned with lda % 4 == 0");
     TH_REQUIRE(W.w != nullptr, "weights not packed");
@@ -218,9 +281,13 @@ int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float*
 #define LAUNCH(NT_, MT_)                                                                                            \
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<NT_, MT_>), grid, dim3(256), lds, s, A, lda, M, W.K, W.w, W.b, W.N, W.NB, \
                        W.KB, C, ldc, flags)
+#define LAUNCH_LN(NT_)                                                                                              \
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<NT_, 1, true>), grid, dim3(256), lds, s, A, lda, M, W.K, W.w, W.b, W.N, W.NB, \
+                       W.KB, C, ldc, flags, ln_w, ln_b, ln_eps)
 #define LAUNCH_NT(NT_)                 \
     do {                               \
-        if (small) LAUNCH(NT_, 1);     \
+        if (ln_w) LAUNCH_LN(NT_);      \
+        else if (small) LAUNCH(NT_, 1); \
         else LAUNCH(NT_, 4);           \
     } while (0)
     switch (nt) {
@@ -230,6 +297,7 @@ int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float*
         default: LAUNCH_NT(1); break;
     }
 #undef LAUNCH_NT
+#undef LAUNCH_LN
 #undef LAUNCH
     TH_LAUNCH_CHECK();
     return 0;

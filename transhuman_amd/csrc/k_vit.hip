@@ -10,6 +10,8 @@
 // 16-lane shuffle reductions.  The [V,3,N,N] probability tensor the reference
 // materialises (81 MB at N_c = 1500) never exists.
 // Per-frame cost 12/23/110 GFLOP at N_c = 300/500/1500 (fp32 MFMA bound).
+#include <stdlib.h>
+
 #include "th_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -243,9 +245,214 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
     }
 }
 
+
+// ---- attention, second form: operands split ONCE per layer, no LDS staging ------------------------------------
+// attn_kernel converts every K / V tile fp32 -> fp16 hi/lo inside every workgroup (the V tile transposed with
+// 2-byte LDS stores) between two block barriers: 8 q-blocks repeat the conversion of the same (view, head) and
+// the 8-tile loop is a 31 us dependent chain.  Here kv_split_kernel writes, once per layer,
+//   Kp [V][heads][2 planes][Npad][64]   K rows as fp16 hi | lo          (rows >= N zero)
+//   Vp [V][heads][2 planes][64][Npad]   V^T rows (one d, keys contiguous) as fp16 hi | lo
+// -- exactly the 16-byte B-operand fragments of the two products -- and attn2_kernel (ONE wave = 16 queries per
+// workgroup, 288 workgroups at N = 500) loads them straight from L2 into registers: no block barrier, no conversion
+// in the loop, V fragments of a tile requested before its S product, K fragments of the next tile before its P V.
+// (Splitting the keys of a query block over 4 waves with a final merge, and feeding the LDS tiling from the pre-split
+// planes, were both measured: no gain / slower -- this form is bound by its L2 traffic, the LDS form by its barriers.)
+__global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__ qkv, int N, int Npad, int dim,
+                                                       _Float16* __restrict__ Kp, _Float16* __restrict__ Vp) {
+    __shared__ float vt[64][65];
+    const int tid = threadIdx.x, head = blockIdx.y, view = blockIdx.z, heads = gridDim.y;
+    const int k0 = blockIdx.x * 64;
+    const int ld = 3 * dim;
+    const float* base = qkv + (long long)view * N * ld;
+    const long long plane = (long long)Npad * 64;
+    _Float16* kp = Kp + ((long long)view * heads + head) * 2 * plane;
+    _Float16* vp = Vp + ((long long)view * heads + head) * 2 * plane;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 4, c4 = idx & 15, key = k0 + row;
+        float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+        if (key < N) {
+            kv = *reinterpret_cast<const float4*>(base + (long long)key * ld + dim + head * 64 + 4 * c4);
+            vv = *reinterpret_cast<const float4*>(base + (long long)key * ld + 2 * dim + head * 64 + 4 * c4);
+        }
+        const float kk[4] = {kv.x, kv.y, kv.z, kv.w};
+        at_h4 kh, kl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 x, y;
+            at_split(kk[e], x, y);
+            kh[e] = x; kl[e] = y;
+        }
+        *reinterpret_cast<at_h4*>(kp + (long long)key * 64 + 4 * c4) = kh;
+        *reinterpret_cast<at_h4*>(kp + plane + (long long)key * 64 + 4 * c4) = kl;
+        vt[row][4 * c4 + 0] = vv.x; vt[row][4 * c4 + 1] = vv.y; vt[row][4 * c4 + 2] = vv.z; vt[row][4 * c4 + 3] = vv.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 256 * i, d = idx >> 4, c4 = idx & 15;     // d row, 4 consecutive keys
+        at_h4 vh, vl;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 x, y;
+            at_split(vt[4 * c4 + e][d], x, y);
+            vh[e] = x; vl[e] = y;
+        }
+        *reinterpret_cast<at_h4*>(vp + (long long)d * Npad + k0 + 4 * c4) = vh;
+        *reinterpret_cast<at_h4*>(vp + plane + (long long)d * Npad + k0 + 4 * c4) = vl;
+    }
+}
+
+__global__ __launch_bounds__(64) void attn2_kernel(const float* __restrict__ qkv, const _Float16* __restrict__ Kp,
+                                                   const _Float16* __restrict__ Vp, int N, int Npad, int dim,
+                                                   float scale, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char Pw[2 * 16 * AT_HS];        // P [q][key], hi | lo planes
+    const int lane = threadIdx.x;
+    const int head = blockIdx.y, view = blockIdx.z, heads = gridDim.y;
+    const int q0 = blockIdx.x * 16;
+    const int ld = 3 * dim;
+    const float* base = qkv + (long long)view * N * ld;
+    const long long plane = (long long)Npad * 64;
+    const _Float16* kp = Kp + ((long long)view * heads + head) * 2 * plane;
+    const _Float16* vp = Vp + ((long long)view * heads + head) * 2 * plane;
+
+    at_h8 qh[2], ql[2];
+    {
+        const int qi = q0 + (lane & 15);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = 0.f;
+            if (qi < N) {
+                const float* src = base + (long long)qi * ld + head * 64 + 32 * s2 + 8 * (lane >> 4);
+                float4 a = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
+                v8[0] = a.x; v8[1] = a.y; v8[2] = a.z; v8[3] = a.w; v8[4] = b4.x; v8[5] = b4.y; v8[6] = b4.z; v8[7] = b4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 x, y;
+                at_split(v8[e], x, y);
+                qh[s2][e] = x; ql[s2][e] = y;
+            }
+        }
+    }
+    f32x4 oacc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun[4], lrun[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mrun[r] = -3.0e38f; lrun[r] = 0.f; }
+
+    // fragments of one 64-key tile: K [nt][s2] (key = k0 + nt*16 + lane&15, d = 32 s2 + 8 (lane>>4) ..+7),
+    //                               V [j][s2]  (d = j*16 + lane&15,   keys = k0 + 32 s2 + 8 (lane>>4) ..+7)
+    at_h8 kh[4][2], kl[4][2], vh[4][2], vl[4][2];
+    auto load_k = [&](int k0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const long long o = (long long)(k0 + nt * 16 + (lane & 15)) * 64 + 32 * s2 + 8 * (lane >> 4);
+                kh[nt][s2] = *reinterpret_cast<const at_h8*>(kp + o);
+                kl[nt][s2] = *reinterpret_cast<const at_h8*>(kp + plane + o);
+            }
+    };
+    auto load_v = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const long long o = (long long)(j * 16 + (lane & 15)) * Npad + k0 + 32 * s2 + 8 * (lane >> 4);
+                vh[j][s2] = *reinterpret_cast<const at_h8*>(vp + o);
+                vl[j][s2] = *reinterpret_cast<const at_h8*>(vp + plane + o);
+            }
+    };
+    load_k(0);
+    for (int k0 = 0; k0 < N; k0 += AT_K) {
+        load_v(k0);
+        f32x4 sacc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            sacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[s2], kh[nt][s2], sacc[nt], 0, 0, 0);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s2], kl[nt][s2], sacc[nt], 0, 0, 0);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s2], kh[nt][s2], sacc[nt], 0, 0, 0);
+            }
+        }
+        if (k0 + AT_K < N) load_k(k0 + AT_K);
+        float mnew[4], corr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = -3.0e38f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                int key = k0 + nt * 16 + (lane & 15);
+                float sv = (key < N) ? sacc[nt][r] * scale : -3.0e38f;
+                sacc[nt][r] = sv;
+                m = fmaxf(m, sv);
+            }
+            for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+            mnew[r] = fmaxf(mrun[r], m);
+            corr[r] = expf(mrun[r] - mnew[r]);
+            mrun[r] = mnew[r];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the previous tile's P fragments have been read
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float ls = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                int key = k0 + nt * 16 + (lane & 15);
+                float pv = (key < N) ? expf(sacc[nt][r] - mnew[r]) : 0.f;
+                ls += pv;
+                _Float16 x, y;
+                at_split(pv, x, y);
+                const int po = (4 * (lane >> 4) + r) * AT_HS + 2 * (nt * 16 + (lane & 15));
+                *reinterpret_cast<_Float16*>(Pw + po) = x;
+                *reinterpret_cast<_Float16*>(Pw + 16 * AT_HS + po) = y;
+            }
+            for (int o = 1; o < 16; o <<= 1) ls += __shfl_xor(ls, o);
+            lrun[r] = lrun[r] * corr[r] + ls;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) oacc[j][r] *= corr[r];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): P tile written
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int pof = (lane & 15) * AT_HS + 64 * s2 + 16 * (lane >> 4);
+            const at_h8 ph = *reinterpret_cast<const at_h8*>(Pw + pof);
+            const at_h8 pl = *reinterpret_cast<const at_h8*>(Pw + 16 * AT_HS + pof);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh[j][s2], oacc[j], 0, 0, 0);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl[j][s2], oacc[j], 0, 0, 0);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh[j][s2], oacc[j], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int qi = q0 + 4 * (lane >> 4) + r;
+        if (qi < N) {
+            float inv = 1.0f / lrun[r];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                out[((long long)view * N + qi) * dim + head * 64 + j * 16 + (lane & 15)] = oacc[j][r] * inv;
+        }
+    }
+}
+
+static int vit_npad(int N) { return (N + 63) / 64 * 64; }
+
 size_t th_vit_ws(int V, int N, int dim, int heads) {
     size_t T = (size_t)V * N;
-    return 2 * th_align(T * dim * 4) + th_align(T * 4 * dim * 4);
+    // X, Y, qkv / hidden, and the split K / V^T planes of one layer (2 x [V][heads][2][Npad][64] halves)
+    return 2 * th_align(T * dim * 4) + th_align(T * 4 * dim * 4) +
+           2 * th_align((size_t)V * heads * 2 * vit_npad(N) * 64 * sizeof(_Float16));
 }
 
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
@@ -260,18 +467,43 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
     float* X = ar.take<float>((size_t)T * dim);
     float* Y = ar.take<float>((size_t)T * dim);
     float* Q = ar.take<float>((size_t)T * 4 * dim);     // qkv (3*dim) or mlp hidden (4*dim)
+    const int Npad = vit_npad(N);
+    _Float16* Kp = ar.take<_Float16>((size_t)V * heads * 2 * Npad * 64);
+    _Float16* Vp = ar.take<_Float16>((size_t)V * heads * 2 * Npad * 64);
+    TH_REQUIRE(Vp != nullptr, "workspace too small");
+    // few tokens: the register-fed form (more, shorter workgroups); many: the LDS-staged form (64 queries share every K / V
+    // tile: a quarter of the L2 traffic, which is what bounds the register-fed form from N ~ 1000 on).
+    // Measured ViT forward, N_c = 300 / 500 / 1500: 0.80 / 0.99 / 2.15 ms register-fed, 0.86 / 1.07 / 2.06 ms LDS-staged.
+    static const char* attn_env = getenv("TH_ATTN_FORM");               // "lds" | "reg": A/B switch
+    const bool attn_lds = attn_env ? attn_env[0] == 'l' : N > 768;
     TH_REQUIRE(Q != nullptr, "workspace carve failed");
     long long n = (long long)T * dim;
     hipLaunchKernelGGL(add_kernel, dim3(th_cdiv(n, 256)), dim3(256), 0, s, x, pe, n, X);
     const float scale = 0.125f;   // head_dim ** -0.5
+    // the two pre-LayerNorms of a block run inside the GEMM that consumes them (TH_VIT_SEPARATE_LN=1: own launches)
+    static const bool separate_ln = getenv("TH_VIT_SEPARATE_LN") != nullptr;
+    const bool fuse_ln = !separate_ln && th_gemm_ln_ok(T, W.blocks[0].qkv) && th_gemm_ln_ok(T, W.blocks[0].fc1);
     for (int b = 0; b < W.depth; ++b) {
         const ThVitBlockPacked& B = W.blocks[b];
-        hipLaunchKernelGGL(layernorm_kernel, dim3(th_cdiv(T, 4)), dim3(256), 0, s, X, T, dim, B.ln1_w, B.ln1_b, 1e-6f, Y);
-        TH_TRY(th_gemm(Y, dim, T, B.qkv, TH_ACT_NONE, Q, 3 * dim, s));
-        hipLaunchKernelGGL(attn_kernel, dim3(th_cdiv(N, AT_Q), heads, V), dim3(256), 0, s, Q, N, dim, scale, Y);
+        if (fuse_ln) {
+            TH_TRY(th_gemm_ln(X, dim, T, B.qkv, B.ln1_w, B.ln1_b, 1e-6f, TH_ACT_NONE, Q, 3 * dim, s));
+        } else {
+            hipLaunchKernelGGL(layernorm_kernel, dim3(th_cdiv(T, 4)), dim3(256), 0, s, X, T, dim, B.ln1_w, B.ln1_b, 1e-6f, Y);
+            TH_TRY(th_gemm(Y, dim, T, B.qkv, TH_ACT_NONE, Q, 3 * dim, s));
+        }
+        if (attn_lds) {
+            hipLaunchKernelGGL(attn_kernel, dim3(th_cdiv(N, AT_Q), heads, V), dim3(256), 0, s, Q, N, dim, scale, Y);
+        } else {
+            hipLaunchKernelGGL(kv_split_kernel, dim3(Npad / 64, heads, V), dim3(256), 0, s, Q, N, Npad, dim, Kp, Vp);
+            hipLaunchKernelGGL(attn2_kernel, dim3(th_cdiv(N, 16), heads, V), dim3(64), 0, s, Q, Kp, Vp, N, Npad, dim, scale, Y);
+        }
         TH_TRY(th_gemm(Y, dim, T, B.proj, TH_ACT_NONE | TH_GEMM_ACCUM, X, dim, s));
-        hipLaunchKernelGGL(layernorm_kernel, dim3(th_cdiv(T, 4)), dim3(256), 0, s, X, T, dim, B.ln2_w, B.ln2_b, 1e-6f, Y);
-        TH_TRY(th_gemm(Y, dim, T, B.fc1, TH_ACT_GELU, Q, 4 * dim, s));
+        if (fuse_ln) {
+            TH_TRY(th_gemm_ln(X, dim, T, B.fc1, B.ln2_w, B.ln2_b, 1e-6f, TH_ACT_GELU, Q, 4 * dim, s));
+        } else {
+            hipLaunchKernelGGL(layernorm_kernel, dim3(th_cdiv(T, 4)), dim3(256), 0, s, X, T, dim, B.ln2_w, B.ln2_b, 1e-6f, Y);
+            TH_TRY(th_gemm(Y, dim, T, B.fc1, TH_ACT_GELU, Q, 4 * dim, s));
+        }
         TH_TRY(th_gemm(Q, 4 * dim, T, B.fc2, TH_ACT_NONE | TH_GEMM_ACCUM, X, dim, s));
     }
     hipLaunchKernelGGL(layernorm_kernel, dim3(th_cdiv(T, 4)), dim3(256), 0, s, X, T, dim, W.norm_w, W.norm_b, 1e-6f, out);

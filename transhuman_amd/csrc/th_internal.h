@@ -72,6 +72,10 @@ enum { TH_ACT_NONE = 0, TH_ACT_RELU = 1, TH_ACT_GELU = 2, TH_GEMM_ACCUM = 16 };
 int th_pack_linear(const th_linear& lin, void* storage, ThPacked* out, hipStream_t s);
 // C[M,N] = act(A[M,K] W^T + b) (+ C if TH_GEMM_ACCUM)
 int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float* C, int ldc, hipStream_t s);
+// C = act(LayerNorm(A rows; ln_w, ln_b, eps) W^T + b) (+ C): the normalisation happens inside the GEMM
+bool th_gemm_ln_ok(int M, const ThPacked& W);
+int th_gemm_ln(const float* A, int lda, int M, const ThPacked& W, const float* ln_w, const float* ln_b, float eps,
+               int flags, float* C, int ldc, hipStream_t s);
 
 // ---- point source ---------------------------------------------------------------
 struct ThPointSrc {
