@@ -180,6 +180,21 @@ int th_paint_group_nhwc(th_ctx* ctx, const float* map_nhwc, int V, int H, int W,
  * the network in train() as run.py:29 leaves it: batch statistics (biased variance), running statistics updated with
  * `momentum` (unbiased variance), exactly F.batch_norm(training=True).  res may be NULL; running_* may be NULL (no
  * update); gamma/beta may be NULL (1 / 0).  y may alias x.  workspace: th_bn_workspace_bytes(N, C, H*W). */
+/* K12 -- the bias-free convolutions of the ResNet18 stem (encoder.py:114-126: 7x7/2 3->64, 3x3 64->64, 3x3/2 64->128,
+ * 3x3 128->128, 1x1/2 64->128; padding KS/2), NCHW fp32 in and out, as implicit GEMMs on v_mfma_f32_32x32x16_f16 with fp16 hi/lo split
+ * operands (fp32-class accuracy).  th_conv_pack turns a [COUT,CIN,KS,KS] weight into the per-lane fragment image
+ * (th_conv_pack_bytes bytes, device) and returns the power-of-two output scale to pass to th_conv2d; re-pack when the
+ * weight changes.  th_conv2d_supported tells whether a shape is built. */
+size_t th_conv_pack_bytes(int cout, int cin, int ks);
+int th_conv_pack(th_ctx* ctx, const float* w, int cout, int cin, int ks, void* packed, size_t packed_bytes,
+                 float* inv_scale_out, th_stream stream);
+int th_conv2d_supported(int cin, int cout, int ks, int stride);
+int th_conv2d(th_ctx* ctx, const float* x, int N, int cin, int H, int W, const void* packed, float inv_scale, int cout,
+              int ks, int stride, float* y, th_stream stream);
+
+/* nn.MaxPool2d(3, 2, 1) of the stem on [planes, H, W] fp32 -> [planes, (H-1)/2+1, (W-1)/2+1] */
+int th_maxpool3x3s2(th_ctx* ctx, const float* x, int planes, int H, int W, float* y, th_stream stream);
+
 size_t th_bn_workspace_bytes(int N, int C, int HW);
 int th_bn_act(th_ctx* ctx, const float* x, const float* residual, int N, int C, int HW, const float* gamma,
               const float* beta, float eps, float momentum, float* running_mean, float* running_var, int relu,

@@ -254,6 +254,33 @@ def test_render_fast_vs_golden(hip, gpu, net, tag, H, focal):
     assert -10 * np.log10(max(mse, 1e-30)) > 80.0          # PSNR(build, reference) > 80 dB  
 
 
+@pytest.mark.parametrize("cin,cout,ks,stride,H,W", [(64, 64, 3, 1, 128, 128), (64, 64, 3, 1, 37, 45), (64, 128, 3, 2, 128, 128),
+                                                     (64, 128, 3, 2, 33, 47), (128, 128, 3, 1, 64, 64),
+                                                     (128, 128, 3, 1, 19, 70), (64, 128, 1, 2, 128, 128),
+                                                     (64, 128, 1, 2, 31, 33), (3, 64, 7, 2, 512, 512), (3, 64, 7, 2, 61, 90)])
+def test_conv2d_vs_torch(hip, gpu, cin, cout, ks, stride, H, W):
+    """K12 (fp16-split MFMA implicit GEMM) against torch's fp64 convolution: the stem shapes, ragged sizes, borders;
+    re-packs when the weight changes"""
+    torch.manual_seed(cin + cout + ks + H)
+    conv = torch.nn.Conv2d(cin, cout, ks, stride, ks // 2, bias=False).to(gpu)
+    assert hip.conv2d_supported(conv)
+    x = (torch.randn(2, cin, H, W, device=gpu) * 1.5 + 0.3).contiguous()
+    for rep in range(2):
+        ref = torch.nn.functional.conv2d(x.double(), conv.weight.detach().double(), None, stride, ks // 2)
+        got = hip.conv2d(x, conv)
+        assert got.shape == ref.shape
+        scale = float(ref.detach().abs().max())
+        assert maxdiff(got.cpu(), ref.cpu()) < 2e-6 * max(scale, 1.0), (rep, maxdiff(got.cpu(), ref.cpu()), scale)
+        with torch.no_grad():
+            conv.weight.mul_(-0.37)                       # version bump: the packed image must be rebuilt
+
+
+def test_maxpool_vs_torch(hip, gpu):
+    for (N, C, H, W) in ((3, 64, 256, 256), (1, 5, 7, 9), (2, 3, 33, 32)):
+        x = torch.randn(N, C, H, W, device=gpu)
+        assert torch.equal(hip.maxpool3x3s2(x), torch.nn.functional.max_pool2d(x, 3, 2, 1))
+
+
 def test_fused_bn_trunk_equals_stock_modules(hip, gpu):
     """K11 (hip.bn_act: train-mode BatchNorm + residual + ReLU) against torch's modules on the encoder trunk: latents,
     running statistics and counters after two forwards; plus odd shapes / no-affine / no-residual directly"""

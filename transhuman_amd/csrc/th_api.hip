@@ -363,6 +363,28 @@ int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, i
 
 size_t th_vit_workspace_bytes(int V, int N, int dim, int heads) { return th_vit_ws(V, N, dim, heads); }
 
+size_t th_conv_pack_bytes(int cout, int cin, int ks) { return th_conv_pack_size(cout, cin, ks); }
+
+int th_conv_pack(th_ctx* c, const float* w, int cout, int cin, int ks, void* packed, size_t packed_bytes,
+                 float* inv_scale_out, th_stream stream) {
+    TH_REQUIRE(c && w && packed && inv_scale_out, "null argument");
+    return th_conv_pack_launch(w, cout, cin, ks, packed, packed_bytes, inv_scale_out, (hipStream_t)stream);
+}
+
+int th_conv2d_supported(int cin, int cout, int ks, int stride) { return th_conv2d_built(cin, cout, ks, stride) ? 1 : 0; }
+
+int th_conv2d(th_ctx* c, const float* x, int N, int cin, int H, int W, const void* packed, float inv_scale, int cout, int ks,
+              int stride, float* y, th_stream stream) {
+    TH_REQUIRE(c && x && packed && y, "null argument");
+    TH_REQUIRE(N > 0 && H > 0 && W > 0, "empty tensor");
+    return th_conv2d_launch(x, N, cin, H, W, packed, inv_scale, cout, ks, stride, y, (hipStream_t)stream);
+}
+
+int th_maxpool3x3s2(th_ctx* c, const float* x, int planes, int H, int W, float* y, th_stream stream) {
+    TH_REQUIRE(c && x && y && planes > 0 && H > 0 && W > 0, "bad argument");
+    return th_maxpool3x3s2_launch(x, planes, H, W, y, (hipStream_t)stream);
+}
+
 size_t th_bn_workspace_bytes(int N, int C, int HW) { return th_bn_ws(N, C, HW); }
 
 int th_bn_act(th_ctx* c, const float* x, const float* residual, int N, int C, int HW, const float* gamma, const float* beta,

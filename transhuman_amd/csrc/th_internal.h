@@ -324,6 +324,14 @@ int th_upsample_concat_launch(const float* img, const float* lat0, const float* 
                               const int* dims, int V, int H, int W, const float* wc, const float* bc, float* out,
                               hipStream_t s);
 // W' [N,260] = [W[:, :256] | W[:, 256:384] Wc | 0], b' = b + W[:, 256:384] bc  (fp64 accumulation)
+// K12 (k_conv.hip): convolutions of the ResNet stem on the fp16-split MFMA path
+size_t th_conv_pack_size(int COUT, int CIN, int KS);
+int th_conv_pack_launch(const float* w, int COUT, int CIN, int KS, void* out, size_t out_bytes, float* inv_scale_host,
+                        hipStream_t s);
+bool th_conv2d_built(int CIN, int COUT, int KS, int stride);
+int th_conv2d_launch(const float* x, int N, int CIN, int H, int W, const void* packed, float inv_scale, int COUT, int KS,
+                     int stride, float* y, hipStream_t s);
+int th_maxpool3x3s2_launch(const float* x, int planes, int H, int W, float* y, hipStream_t s);
 size_t th_bn_ws(int N, int C, int HW);
 int th_bn_act_launch(const float* x, const float* res, int N, int C, int HW, const float* gamma, const float* beta,
                      float eps, float momentum, float* run_mean, float* run_var, int relu, float* y, void* ws,

@@ -110,6 +110,13 @@ SYMBOLS = {
                                  C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
     "th_render_prepass": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
                                     C.c_void_p]),
+    "th_conv_pack_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "th_conv_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+                               C.POINTER(C.c_float), C.c_void_p]),
+    "th_conv2d_supported": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "th_conv2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int,
+                            C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "th_maxpool3x3s2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "th_bn_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "th_bn_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -388,6 +395,50 @@ def paint_group_nhwc(map_nhwc, verts_world, cams, scale_xy, vizmap, red_w, red_b
                                    _p(viz), C.byref(lin), C.byref(lift) if lift is not None else None, _p(off), _p(mem),
                                    nc, _p(tokens), _p(ws), ws.numel(), _stream()))
     return tokens
+
+
+_conv_cache = {}
+
+
+def conv2d_supported(conv):
+    """True for the nn.Conv2d shapes th_conv2d is built for (the bias-free convolutions of the ResNet18 stem)."""
+    ks, st, pd = conv.kernel_size, conv.stride, conv.padding
+    return (conv.bias is None and ks[0] == ks[1] and st[0] == st[1] and pd[0] == pd[1] == ks[0] // 2 and
+            conv.groups == 1 and conv.dilation == (1, 1) and
+            bool(load_library().th_conv2d_supported(conv.in_channels, conv.out_channels, ks[0], st[0])))
+
+
+def conv2d(x, conv):
+    """th_conv2d: y = conv(x) for a supported bias-free nn.Conv2d (NCHW fp32), fp16-split MFMA implicit GEMM.
+    The packed weight image is cached per module and rebuilt when the weight tensor changes."""
+    lib = load_library()
+    assert x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()
+    w = conv.weight
+    key = id(conv)
+    ent = _conv_cache.get(key)
+    if ent is None or ent[0] is not w or ent[1] != w._version or ent[2].device != x.device:
+        co, ci, ks, _ = w.shape
+        buf = torch.empty(lib.th_conv_pack_bytes(co, ci, ks), dtype=torch.uint8, device=x.device)
+        inv = C.c_float()
+        _check(lib.th_conv_pack(ctx(x.device), _p(_f32(w)), co, ci, ks, _p(buf), buf.numel(), C.byref(inv), _stream()))
+        ent = (w, w._version, buf, float(inv.value))
+        _conv_cache[key] = ent
+    N, ci, H, W = x.shape
+    co, ks, st = conv.out_channels, conv.kernel_size[0], conv.stride[0]
+    pd = ks // 2
+    Ho, Wo = (H + 2 * pd - ks) // st + 1, (W + 2 * pd - ks) // st + 1
+    y = torch.empty((N, co, Ho, Wo), dtype=torch.float32, device=x.device)
+    _check(lib.th_conv2d(ctx(x.device), _p(x), N, ci, H, W, _p(ent[2]), ent[3], co, ks, st, _p(y), _stream()))
+    return y
+
+
+def maxpool3x3s2(x):
+    """th_maxpool3x3s2: nn.MaxPool2d(3, 2, 1) on NCHW fp32."""
+    assert x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), dtype=torch.float32, device=x.device)
+    _check(load_library().th_maxpool3x3s2(ctx(x.device), _p(x), N * Cc, H, W, _p(y), _stream()))
+    return y
 
 
 def bn_act(x, bn, residual=None, relu=True):

@@ -91,10 +91,11 @@ class SpatialEncoder(nn.Module):
 
     def trunk(self, x, fused_bn=None):
         """ResNet18 stem -> the three latents (64ch @H/2, 64ch @H/4, 128ch @H/8), encoder.py:114-126.
-        Convolutions are stock torch/MIOpen ops.  On a GPU with the network in train() (run.py:29) the elementwise
-        tail of every stage -- train-mode BatchNorm, ReLU, residual add -- runs as K11 (hip.bn_act: one statistics
-        pass + one apply pass instead of torch's 3-4 launches per site; ``fused_bn=False`` or TH_STOCK_BN=1 keeps the
-        stock modules); running statistics and num_batches_tracked evolve as in the stock modules."""
+        On a GPU with the network in train() (run.py:29) the stem is hand-written HIP end to end: convolutions as K12
+        (hip.conv2d: fp16-split MFMA implicit GEMMs; TH_STOCK_CONV=1 keeps torch/MIOpen), max pooling, and the
+        elementwise tail of every stage -- train-mode BatchNorm, ReLU, residual add -- as K11 (hip.bn_act: one
+        statistics pass + one apply pass instead of torch's 3-4 launches per site).  ``fused_bn=False`` or
+        TH_STOCK_BN=1 runs the stock modules; running statistics and num_batches_tracked evolve as in them."""
         m = self.model
         if fused_bn is None:
             fused_bn = x.is_cuda and os.environ.get("TH_STOCK_BN") != "1"
@@ -122,14 +123,21 @@ class SpatialEncoder(nn.Module):
     def _trunk_fused_bn(self, x):
         from .. import hip
         m = self.model
-        x = hip.bn_act(m.conv1(x), m.bn1, relu=True)
+        stock_conv = os.environ.get("TH_STOCK_CONV") == "1"
+
+        def conv(mod, t):        # K12 for the stem's shapes, the stock module otherwise
+            if not stock_conv and hip.conv2d_supported(mod):
+                return hip.conv2d(t.contiguous(), mod)
+            return mod(t)
+
+        x = hip.bn_act(conv(m.conv1, x), m.bn1, relu=True)
         lat = [x]
-        x = m.maxpool(x)
+        x = m.maxpool(x) if stock_conv else hip.maxpool3x3s2(x)
         for layer in (m.layer1, m.layer2):
             for blk in layer:
-                idt = x if blk.downsample is None else hip.bn_act(blk.downsample[0](x), blk.downsample[1], relu=False)
-                y = hip.bn_act(blk.conv1(x), blk.bn1, relu=True)
-                x = hip.bn_act(blk.conv2(y), blk.bn2, residual=idt, relu=True)
+                idt = x if blk.downsample is None else hip.bn_act(conv(blk.downsample[0], x), blk.downsample[1], relu=False)
+                y = hip.bn_act(conv(blk.conv1, x), blk.bn1, relu=True)
+                x = hip.bn_act(conv(blk.conv2, y), blk.bn2, residual=idt, relu=True)
             lat.append(x)
         counters = [b.num_batches_tracked for b in self._bn_sites()
                     if b.track_running_stats and b.num_batches_tracked is not None]
