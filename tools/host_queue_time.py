@@ -1,6 +1,6 @@
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from transhuman_amd import synth, hip
 from transhuman_amd.config import get_cfg

@@ -11,8 +11,9 @@
 //     pre-scaled by a power of two so that their lo halves stay normal fp16 numbers, and stream from L2 into registers;
 //   * a lane's accumulators are 16 output channels of ONE pixel, lanes 0..31 are 32 consecutive x: every store
 //     instruction writes two 128-byte runs of the NCHW output.
-// Tile shapes: COUT = 64: 8 rows x 32 pixels per workgroup, the 4 waves split the rows (each: 2 row tiles x 2 column
-// tiles); COUT = 128: 2 rows x 32 pixels, the 4 waves split the output channels (each: 2 row tiles x 1 column tile).
+// Tile shapes: COUT = 64: 4 rows x 32 pixels per workgroup, waves = 2 row pairs x 2 column tiles (each: 2 row tiles x 1
+// column tile); COUT = 128: 2 rows x 32 pixels, the 4 waves split the output channels (each: 2 row tiles x 1 column tile);
+// two workgroups fit a CU (LDS 59 / 74 KB), so one stages while the other multiplies.
 #include <string.h>
 
 #include "th_internal.h"
@@ -97,7 +98,7 @@ int th_conv_pack_launch(const float* w, int COUT, int CIN, int KS, void* out, si
 // ---- the convolution ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int cv_chan(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
 
-template <int CIN, int COUT, int S, int KS, int TR, bool SPLIT_ROWS>
+template <int CIN, int COUT, int S, int KS, int TR, int WC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                         float inv_scale, float* __restrict__ y, int H, int W, int Ho,
                                                         int Wo) {
@@ -106,10 +107,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     constexpr int STRB = 2 * CIN + 16;
     constexpr int PLANE = IR * IC * STRB;
     constexpr int KB = CIN / 16, CT = COUT / 32;
-    constexpr int RTW = SPLIT_ROWS ? TR / 4 : TR;          // row tiles per wave
-    constexpr int CTW = SPLIT_ROWS ? CT : CT / 4;          // column tiles per wave
+    constexpr int WR = 4 / WC;                             // the 4 waves: WR along the rows x WC along the column tiles
+    constexpr int RTW = TR / WR;                           // row tiles per wave
+    constexpr int CTW = CT / WC;                           // column tiles per wave (waves that share a column tile load
+                                                           // the same weight fragments: L1 traffic, keep WC large)
     static_assert(CIN % 16 == 0 && COUT % 32 == 0, "channel counts");
-    static_assert(SPLIT_ROWS ? (TR % 4 == 0) : (CT % 4 == 0), "wave split");
+    static_assert(WC * WR == 4 && TR % WR == 0 && CT % WC == 0, "wave split");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* xhi = lds;
     char* xlo = lds + PLANE;
@@ -118,34 +121,49 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     const int iy0 = oy0 * S - PAD, ix0 = ox0 * S - PAD;
 
     // ---- stage the input tile: fp32 NCHW -> fp16 hi / lo planes [pixel][CIN] ----
+    // batches of SB items per thread: all 4 SB loads of a batch are in flight before the first conversion (one
+    // workgroup or two per CU: nothing else hides the global-load latency)
     {
         constexpr int ITEMS = IR * IC * (CIN / 4);
+        constexpr int SB = 6;
         const float* xn = x + (long long)n * CIN * H * W;
-        for (int it = tid; it < ITEMS; it += 256) {
-            const int px = it % IC, t2 = it / IC, r = t2 % IR, c4 = t2 / IR;
-            const int gy = iy0 + r, gx = ix0 + px;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+        const long long HW = (long long)H * W;
+#ifndef CV_SKIP_STAGE
+        for (int it0 = tid; it0 < ITEMS; it0 += 256 * SB) {
+            float v[SB][4];
+            int off[SB];
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                const int it = it0 + 256 * b;
+                const int px = it % IC, t2 = it / IC, r = t2 % IR, c4 = t2 / IR;
+                const int gy = iy0 + r, gx = ix0 + px;
+                off[b] = it < ITEMS ? (r * IC + px) * STRB + 8 * c4 : -1;
+                const bool in = it < ITEMS && gy >= 0 && gy < H && gx >= 0 && gx < W;
                 const float* p = xn + ((long long)(4 * c4) * H + gy) * W + gx;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = p[(long long)e * H * W];
+                for (int e = 0; e < 4; ++e) v[b][e] = in ? p[e * HW] : 0.f;
             }
-            cv_h4 a, b;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                _Float16 hi, lo;
-                cv_split(v[e], hi, lo);
-                a[e] = hi; b[e] = lo;
+            for (int b = 0; b < SB; ++b) {
+                cv_h4 a, bl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    _Float16 hi, lo;
+                    cv_split(v[b][e], hi, lo);
+                    a[e] = hi; bl[e] = lo;
+                }
+                if (off[b] >= 0) {
+                    *reinterpret_cast<cv_h4*>(xhi + off[b]) = a;
+                    *reinterpret_cast<cv_h4*>(xlo + off[b]) = bl;
+                }
             }
-            const int off = (r * IC + px) * STRB + 8 * c4;
-            *reinterpret_cast<cv_h4*>(xhi + off) = a;
-            *reinterpret_cast<cv_h4*>(xlo + off) = b;
         }
+#endif
     }
     __syncthreads();
 
-    const int rbase = SPLIT_ROWS ? wave * RTW : 0;
-    const int cbase = SPLIT_ROWS ? 0 : wave * CTW;
+    const int rbase = (wave / WC) * RTW;
+    const int cbase = (wave % WC) * CTW;
     cv_f32x16 acc[CTW][RTW];
 #pragma unroll
     for (int c = 0; c < CTW; ++c)
@@ -154,21 +172,26 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[c][r][e] = 0.f;
 
-    // K loop over (tap, k-block); fragments of step i+1 are requested before the MFMAs of step i
+    // K loop over (tap, k-block).  A step is only 6 MFMAs (192 cycles): the weight fragments (L2, ~1-2 k cycles away)
+    // run DW - 1 steps ahead in a register ring, the activation fragments (LDS) one step ahead.
     constexpr int STEPS = KS * KS * KB;
+    constexpr int DW = 6;
+    static_assert((DW & 1) == 0, "ring depth must be even (activation ping-pong parity)");
     const uint4* wl = wp + (long long)cbase * 2 * 64 + lane;
     const int lane_off = (lane & 31) * S * STRB + (lane >> 5) * 16;
-    uint4 wq[2][CTW][2];
+    uint4 wq[DW][CTW][2];
     cv_h8 xh[2][RTW], xl[2][RTW];
-    auto load_step = [&](int st, int buf) {
-        const int tap = st / KB, kb = st - tap * KB;
-        const int kh = tap / KS, kw = tap - kh * KS;
+    auto load_w = [&](int st, int slot) {
         const uint4* p = wl + (long long)st * (CT * 2 * 64);
 #pragma unroll
         for (int c = 0; c < CTW; ++c) {
-            wq[buf][c][0] = p[(c * 2 + 0) * 64];
-            wq[buf][c][1] = p[(c * 2 + 1) * 64];
+            wq[slot][c][0] = p[(c * 2 + 0) * 64];
+            wq[slot][c][1] = p[(c * 2 + 1) * 64];
         }
+    };
+    auto load_x = [&](int st, int buf) {
+        const int tap = st / KB, kb = st - tap * KB;
+        const int kh = tap / KS, kw = tap - kh * KS;
 #pragma unroll
         for (int r = 0; r < RTW; ++r) {
             const int off = (((rbase + r) * S + kh) * IC + kw) * STRB + lane_off + kb * 32;
@@ -176,29 +199,42 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
             xl[buf][r] = *reinterpret_cast<const cv_h8*>(xlo + off);
         }
     };
-    load_step(0, 0);
-#pragma unroll 2
-    for (int st = 0; st < STEPS; ++st) {
-        const int cur = st & 1;
-        if (st + 1 < STEPS) load_step(st + 1, cur ^ 1);
 #pragma unroll
-        for (int c = 0; c < CTW; ++c)
+    for (int j = 0; j < DW - 1; ++j)
+        if (j < STEPS) load_w(j, j);
+    load_x(0, 0);
+#ifdef CV_SKIP_GEMM
+    if (inv_scale == 12345.f)
+#endif
+#pragma unroll 1
+    for (int st0 = 0; st0 < STEPS; st0 += DW) {
 #pragma unroll
-            for (int r = 0; r < RTW; ++r)
-                acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wq[cur][c][1]), xh[cur][r],
-                                                                   acc[c][r], 0, 0, 0);
+        for (int j = 0; j < DW; ++j) {
+            const int st = st0 + j;
+            if (st < STEPS) {
+                if (st + DW - 1 < STEPS) load_w(st + DW - 1, (j + DW - 1) % DW);
+                if (st + 1 < STEPS) load_x(st + 1, (j + 1) & 1);
+                const int cur = j & 1;
 #pragma unroll
-        for (int c = 0; c < CTW; ++c)
+                for (int c = 0; c < CTW; ++c)
 #pragma unroll
-            for (int r = 0; r < RTW; ++r)
-                acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wq[cur][c][0]), xl[cur][r],
-                                                                   acc[c][r], 0, 0, 0);
+                    for (int r = 0; r < RTW; ++r)
+                        acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wq[j][c][1]),
+                                                                           xh[cur][r], acc[c][r], 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < CTW; ++c)
+                for (int c = 0; c < CTW; ++c)
 #pragma unroll
-            for (int r = 0; r < RTW; ++r)
-                acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wq[cur][c][0]), xh[cur][r],
-                                                                   acc[c][r], 0, 0, 0);
+                    for (int r = 0; r < RTW; ++r)
+                        acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wq[j][c][0]),
+                                                                           xl[cur][r], acc[c][r], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < CTW; ++c)
+#pragma unroll
+                    for (int r = 0; r < RTW; ++r)
+                        acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wq[j][c][0]),
+                                                                           xh[cur][r], acc[c][r], 0, 0, 0);
+            }
+        }
     }
 
     // ---- epilogue: NCHW fp32 ----
@@ -221,13 +257,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     }
 }
 
-template <int CIN, int COUT, int S, int KS, int TR, bool SPLIT_ROWS>
+template <int CIN, int COUT, int S, int KS, int TR, int WC>
 static int conv_launch_t(const float* x, const uint4* wp, float inv_scale, float* y, int N, int H, int W, int Ho, int Wo,
                          hipStream_t s) {
     constexpr int IR = (TR - 1) * S + KS, IC = 31 * S + KS, STRB = 2 * CIN + 16;
     constexpr size_t lds = (size_t)2 * IR * IC * STRB;
     static_assert(lds <= 160 * 1024, "input tile does not fit in LDS");
-    auto kern = conv_mfma_kernel<CIN, COUT, S, KS, TR, SPLIT_ROWS>;
+    auto kern = conv_mfma_kernel<CIN, COUT, S, KS, TR, WC>;
     static bool attr_done = false;
     if (!attr_done) {
         TH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -240,11 +276,11 @@ static int conv_launch_t(const float* x, const uint4* wp, float inv_scale, float
 }
 
 // ---- conv1: 7x7 / 2, 3 -> 64 (K = 147: too few input channels for the per-tap form) ----------------------------------
-// The workgroup (4 output rows x 32 pixels) stages its raw fp32 input patch (13 x 69 x 3) in LDS, expands it there into
+// The workgroup (2 output rows x 32 pixels) stages its raw fp32 input patch (9 x 69 x 3) in LDS, expands it there into
 // the im2col operand [pixel][k = (c*7 + kh)*7 + kw, padded to 160] as fp16 hi / lo planes, and runs ONE 10-k-block GEMM
 // (the weight [64][3][7][7] is already [64][147] row-major: packed by conv_pack_kernel as a 1-tap layer with CIN = 147).
-// Wave w owns output row w of the tile (1 row tile x 2 column tiles).
-#define C1_TR 4
+// Wave w owns output row (w & 1) and column tile (w >> 1) of the tile; three workgroups fit a CU.
+#define C1_TR 2
 #define C1_K 147
 #define C1_KB 10
 #define C1_STRB (2 * 16 * C1_KB + 16)
@@ -264,10 +300,19 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict
     const int n = blockIdx.z, oy0 = blockIdx.y * C1_TR, ox0 = blockIdx.x * 32;
     const int iy0 = oy0 * 2 - 3, ix0 = ox0 * 2 - 3;
     const float* xn = x + (long long)n * 3 * H * W;
-    for (int it = tid; it < 3 * C1_IR * C1_IC; it += 256) {
-        const int px = it % C1_IC, t2 = it / C1_IC, r = t2 % C1_IR, c = t2 / C1_IR;
-        const int gy = iy0 + r, gx = ix0 + px;
-        raw[it] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xn[((long long)c * H + gy) * W + gx] : 0.f;
+    {
+        constexpr int RAW = 3 * C1_IR * C1_IC, RB = (RAW + 255) / 256;
+        float rv[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {                                    // all loads in flight, then the LDS stores
+            const int it = tid + 256 * b;
+            const int px = it % C1_IC, t2 = it / C1_IC, r = t2 % C1_IR, c = t2 / C1_IR;
+            const int gy = iy0 + r, gx = ix0 + px;
+            rv[b] = (it < RAW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? xn[((long long)c * H + gy) * W + gx] : 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+            if (tid + 256 * b < RAW) raw[tid + 256 * b] = rv[b];
     }
     if (tid < 16 * C1_KB) {
         const int c = tid / 49, rem = tid - c * 49, kh = rem / 7, kw = rem - kh * 7;
@@ -290,33 +335,31 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict
         *reinterpret_cast<cv_h4*>(xlo + p * C1_STRB + 8 * g) = b;
     }
     __syncthreads();
-    cv_f32x16 acc[2];
+    cv_f32x16 acc;
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int rt = wave & 1, ct = wave >> 1;
     const uint4* wl = wp + lane;
-    const int xoff = (wave * 32 + (lane & 31)) * C1_STRB + (lane >> 5) * 16;
+    const int xoff = (rt * 32 + (lane & 31)) * C1_STRB + (lane >> 5) * 16;
+    uint4 wh[C1_KB], wlo[C1_KB];
+#pragma unroll
+    for (int kb = 0; kb < C1_KB; ++kb) {
+        wh[kb] = wl[((kb * 2 + ct) * 2 + 0) * 64];
+        wlo[kb] = wl[((kb * 2 + ct) * 2 + 1) * 64];
+    }
 #pragma unroll
     for (int kb = 0; kb < C1_KB; ++kb) {
         const cv_h8 xh = *reinterpret_cast<const cv_h8*>(xhi + xoff + kb * 32);
         const cv_h8 xl = *reinterpret_cast<const cv_h8*>(xlo + xoff + kb * 32);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const uint4 wh = wl[((kb * 2 + c) * 2 + 0) * 64], wlo = wl[((kb * 2 + c) * 2 + 1) * 64];
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wlo), xh, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wh), xl, acc[c], 0, 0, 0);
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wh), xh, acc[c], 0, 0, 0);
-        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wlo[kb]), xh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wh[kb]), xl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const cv_h8*>(&wh[kb]), xh, acc, 0, 0, 0);
     }
-    const int ox = ox0 + (lane & 31), oy = oy0 + wave;
+    const int ox = ox0 + (lane & 31), oy = oy0 + rt;
     if (ox < Wo && oy < Ho) {
         float* yn = y + (long long)n * 64 * Ho * Wo;
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                yn[((long long)(c * 32 + cv_chan(e, lane)) * Ho + oy) * Wo + ox] = acc[c][e] * inv_scale;
+        for (int e = 0; e < 16; ++e) yn[((long long)(ct * 32 + cv_chan(e, lane)) * Ho + oy) * Wo + ox] = acc[e] * inv_scale;
     }
 }
 
@@ -374,13 +417,16 @@ int th_conv2d_launch(const float* x, int N, int CIN, int H, int W, const void* p
     const uint4* wp = (const uint4*)packed;
     if (CIN == 3 && COUT == 64 && KS == 7 && stride == 2) return conv1_launch(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
     if (CIN == 64 && COUT == 64 && KS == 3 && stride == 1)
-        return conv_launch_t<64, 64, 1, 3, 8, true>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
+        #ifndef CV_TR64
+#define CV_TR64 4
+#endif
+        return conv_launch_t<64, 64, 1, 3, CV_TR64, 2>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
     if (CIN == 64 && COUT == 128 && KS == 3 && stride == 2)
-        return conv_launch_t<64, 128, 2, 3, 2, false>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
+        return conv_launch_t<64, 128, 2, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
     if (CIN == 128 && COUT == 128 && KS == 3 && stride == 1)
-        return conv_launch_t<128, 128, 1, 3, 2, false>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
+        return conv_launch_t<128, 128, 1, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
     if (CIN == 64 && COUT == 128 && KS == 1 && stride == 2)
-        return conv_launch_t<64, 128, 2, 1, 2, false>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
+        return conv_launch_t<64, 128, 2, 1, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
     TH_REQUIRE(false, "th_conv2d: shape not built (ResNet18 stem shapes only)");
     return 1;
 }
