@@ -6,7 +6,7 @@ Drop-in for /root/reference/lib/networks/renderer/if_clight_renderer.py
 ``{'rgb_map' [1,R,3], 'acc_map' [1,R], 'depth_map' [1,R]}``.
 
 What runs where
-  * encoder (ResNet18 stem)            stock PyTorch-ROCm ops
+  * encoder (ResNet18 stem)            th_conv2d / th_bn_act / th_maxpool3x3s2  (K12, K11)
   * paint + cluster pooling            th_paint_group        (K2)
   * TransHE                            th_vit_forward        (K3)
   * DPaRF tables (centres, rotations)  th_segment_mean_*     (K2)
@@ -88,7 +88,7 @@ class Renderer:
     def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True):
         """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
 
-        fused_encoder_tail=True (default): the ResNet stem runs as stock torch ops, its tail
+        fused_encoder_tail=True (default): the ResNet stem runs through SpatialEncoder.trunk (K12 / K11), its tail
         (3 upsamples + colour lift + concat, encoder.py:133-146) is ONE HIP kernel that writes the
         384-channel map channels-last, and holder_feat_map is never materialised -- the 384->192
         reduction_layer is applied to the 3 x 6890 sampled vertex rows instead (it commutes with the
