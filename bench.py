@@ -357,8 +357,8 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
     verts = batch_cpu["tar_smpl_vertice"][0].numpy()
     if args.workload == "orbit":
         # C3: 60-view orbit around the body (run.py --type visualize): per step a new target camera -> rays on
-        # device (th_gen_rays, the reference's get_rays + get_near_far) -> the masked ray list is dealt to the
-        # ranks in contiguous 64-ray runs -> render -> one all_gather.
+        # device (th_gen_rays, the reference's get_rays + get_near_far) -> pixel tiles dealt to the ranks -> render ->
+        # one all_gather.
         bounds = np.stack([verts.min(0), verts.max(0)]).astype(np.float32)
         bounds[0, 2] -= 0.05; bounds[1, 2] += 0.05                                   # can_smpl.py:228-230
         centre = 0.5 * (bounds[0] + bounds[1]).astype(np.float64)
@@ -372,35 +372,33 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
             T = -R @ centre + np.array([0, 0, 3.0])
             return K, R.astype(np.float32), T.reshape(3, 1).astype(np.float32)
 
+        # every pixel is a ray (rays that miss the body box get near = far = 0 from K9: no sample can pass the hull test,
+        # they come out as background exactly like the pixels the reference never renders): no per-frame compaction of
+        # the ray list, hence no host round trip and no index arithmetic per frame; pixel tiles are dealt to the ranks
+        # like in the headline workload, layout exchanged once
+        my_px = shard_ray_indices(H, W, world, rank, tile=8, tile_major=True).to(dev) if world > 1 else None
+        gatherer = ImageGatherer(my_px, H * W, world) if dist_on and world > 1 else None
+
         def frames():
             """the video: one batch per target camera (made under render_sequence's side stream: ray generation
-            and the dealing of the masked ray list overlap the shading of the previous frame)"""
+            overlaps the shading of the previous frame)"""
             i = 0
             while True:
-                rays = hip.gen_rays(*camera(i), bounds, H, W, device=dev)
-                n = rays["near"].numel()
-                mine = torch.arange(n, device=dev)
-                if world > 1:
-                    mine = mine[((mine // 64) % world) == rank]
+                rays = hip.gen_rays(*camera(i), bounds, H, W, device=dev, compact=False)
                 sh = dict(batch)
                 for k in ("ray_o", "ray_d", "near", "far"):
-                    sh[k] = rays[k][mine][None]
-                sh["_orbit"] = (rays["mask_at_box"], mine, n)
+                    sh[k] = (rays[k] if my_px is None else rays[k][my_px])[None]
                 yield sh
                 i += 1
 
-        seq = renderer.render_sequence(frames(), small_frame_rays=-1 if dist_on else 2400)
+        seq = renderer.render_sequence(frames(), small_frame_rays=-1 if world > 1 else 2400)
 
         def step(i):
             out = next(seq)
-            mask_at_box, mine, n = renderer.last_batch["_orbit"]
-            local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
-            if dist_on:
-                from transhuman_amd.dist import gather_image
-                local = gather_image(local, mine, n, world)
-            img = torch.zeros((H * W, 5), dtype=torch.float32, device=dev)
-            img[mask_at_box] = local
-            return img, n
+            img = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
+            if gatherer is not None:
+                img = gatherer(img)
+            return img, H * W
         units, unit_name = H * W, "rays/sec (512x512 orbit, 64 samples/ray, rays generated on device)"
     else:
         # C5: mesh extraction grid (if_mesh_renderer.py:46-100): sigma on grid^3 voxel centres over the body box,

@@ -522,6 +522,22 @@ def test_generated_rays_render(hip, gpu, net):
     out = r.render_fast(bb)
     assert out["rgb_map"].shape == (1, rays["near"].numel(), 3) and torch.isfinite(out["rgb_map"]).all()
     assert r.last_stats["hit_rays"] > 0
+    # dense form (every pixel a ray; rays that miss the box carry near = far = 0 and render as background): the image of
+    # the masked list scattered into the frame, with the same frame constants
+    frame = r.prepare_frame(bb)
+    frame.c.small_frame_rays = -1
+    sparse = r.render_fast(bb, frame=frame)
+    dense_rays = hip.gen_rays(cam["K"].astype(np.float32), cam["R"].astype(np.float32), cam["T"].astype(np.float32), bounds,
+                              48, 48, device=gpu, compact=False)
+    bd = dict(b)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        bd[k] = dense_rays[k][None]
+    dense = r.render_fast(bd, frame=frame)
+    m = dense_rays["mask_at_box"]
+    assert torch.equal(m, rays["mask_at_box"]) and 0 < int(m.sum()) < m.numel()
+    for k in ("rgb_map", "acc_map", "depth_map"):
+        assert torch.equal(dense[k][0][m], sparse[k][0])
+        assert float(dense[k][0][~m].abs().max()) == 0.0
 
 
 def _render_vs_oracle(hip, gpu, net, V, nc, assign, H=32, S=32, focal=None):
