@@ -12,6 +12,8 @@
 // >= 0.1*1.05 only prunes vertices that cannot pass; the outcome is bit-identical
 // to brute force while doing ~27 cells x a few vertices instead of 6890.
 // Bound: HBM/L2 streaming of 32 B/ray in + 1 B/sample out (bytes, not FLOPs).
+#include <stdlib.h>
+
 #include "th_internal.h"
 
 struct GridInfo {
@@ -151,6 +153,111 @@ __global__ void grid_bbox_kernel(const GridInfo* __restrict__ gi, const int* __r
         for (int a = 0; a < 3; ++a) { bbox[6 * c + a] = mn[a]; bbox[6 * c + 3 + a] = mx[a]; }
 }
 
+// The whole grid build as ONE single-workgroup launch (6890 vertices: 7 per thread): AABB -> GridInfo, zeroed counters,
+// per-cell counts, exclusive scan, bucket fill, per-cell bounding boxes -- the five launches above cost ~30 us alone
+// but ~80 us EACH when they have to squeeze in between the MLP tiles of a concurrent frame (frame pipeline, sharded
+// frames).  Also clears the per-ray hit flags and the 16-int info block of the caller (two memset launches less).
+// Same arithmetic per phase as the separate kernels; the order of the vertices inside a cell is as arbitrary as before
+// (atomics) and does not matter to the predicate.
+__global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restrict__ verts, int nv, float h0,
+                                                          GridInfo* __restrict__ gi, int* __restrict__ counts,
+                                                          int* __restrict__ starts, int* __restrict__ cursor,
+                                                          float* __restrict__ sorted, float* __restrict__ bbox,
+                                                          int32_t* __restrict__ ray_hit, int R,
+                                                          int32_t* __restrict__ info_zero) {
+    __shared__ float smin[3][16], smax[3][16];
+    __shared__ GridInfo g;
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (info_zero != nullptr && tid < 16) info_zero[tid] = 0;
+    if (ray_hit != nullptr)
+        for (int i = tid; i < R; i += 1024) ray_hit[i] = 0;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = tid; i < nv; i += 1024)
+        for (int a = 0; a < 3; ++a) {
+            float v = verts[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    for (int a = 0; a < 3; ++a) {
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o));
+        }
+        if ((tid & 63) == 0) {
+            smin[a][tid >> 6] = mn[a];
+            smax[a][tid >> 6] = mx[a];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float ext = 0.f;
+        for (int a = 0; a < 3; ++a) {
+            float lo = smin[a][0], hi = smax[a][0];
+            for (int w = 1; w < 16; ++w) { lo = fminf(lo, smin[a][w]); hi = fmaxf(hi, smax[a][w]); }
+            g.gmin[a] = lo;
+            smax[a][0] = hi;
+            ext = fmaxf(ext, hi - lo);
+        }
+        float h = fmaxf(h0, ext / (float)(GRID_MAX_DIM - 2));
+        g.inv_h = 1.0f / h;
+        int nc = 1;
+        for (int a = 0; a < 3; ++a) {
+            int d = cell_coord(smax[a][0], g.gmin[a], g.inv_h) + 1;
+            d = d < 1 ? 1 : (d > GRID_MAX_DIM ? GRID_MAX_DIM : d);
+            g.dim[a] = d;
+            nc *= d;
+        }
+        g.ncell = nc;
+        *gi = g;
+        carry = 0;
+    }
+    __syncthreads();
+    const int n = g.ncell;
+    for (int i = tid; i < n + 1; i += 1024) counts[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nv; i += 1024) atomicAdd(&counts[vert_cell(g, verts[3 * i], verts[3 * i + 1], verts[3 * i + 2])], 1);
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {            // exclusive scan, 1024 cells per round
+        int i = base + tid;
+        int v = (i < n) ? counts[i] : 0;
+        int x = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(x, o);
+            if ((tid & 63) >= o) x += t;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < (tid >> 6); ++w) woff += wsum[w];
+        int excl = carry + woff + x - v;
+        if (i < n) { starts[i] = excl; cursor[i] = excl; }
+        __syncthreads();
+        if (tid == 1023) carry = excl + v;
+        __syncthreads();
+    }
+    if (tid == 0) starts[n] = carry;
+    __syncthreads();
+    for (int i = tid; i < nv; i += 1024) {
+        float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+        int pos = atomicAdd(&cursor[vert_cell(g, x, y, z)], 1);
+        sorted[3 * pos] = x; sorted[3 * pos + 1] = y; sorted[3 * pos + 2] = z;
+    }
+    __syncthreads();
+    for (int c = tid >> 3; c < n; c += 128) {                // 8 lanes per cell
+        const int sub = tid & 7;
+        float bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        for (int v = starts[c] + sub, e = starts[c + 1]; v < e; v += 8)
+            for (int a = 0; a < 3; ++a) { bmn[a] = fminf(bmn[a], sorted[3 * v + a]); bmx[a] = fmaxf(bmx[a], sorted[3 * v + a]); }
+        for (int o = 1; o < 8; o <<= 1)
+            for (int a = 0; a < 3; ++a) { bmn[a] = fminf(bmn[a], __shfl_xor(bmn[a], o)); bmx[a] = fmaxf(bmx[a], __shfl_xor(bmx[a], o)); }
+        if (sub == 0)
+            for (int a = 0; a < 3; ++a) { bbox[6 * c + a] = bmn[a]; bbox[6 * c + 3 + a] = bmx[a]; }
+    }
+}
+
+
 // one thread per sample; a wave covers 64 consecutive samples (= one ray at S=64)
 __global__ __launch_bounds__(256) void hull_mask_kernel(ThPointSrc ps, long long P, const GridInfo* __restrict__ gi,
                                                         const int* __restrict__ starts,
@@ -200,7 +307,7 @@ size_t th_hull_ws(int n_verts) {
 }
 
 int th_hull_mask_launch(const ThPointSrc& ps, long long P, const float* verts, int nv, float thresh, uint8_t* mask,
-                        int32_t* ray_hit, void* ws, size_t ws_bytes, hipStream_t s) {
+                        int32_t* ray_hit, void* ws, size_t ws_bytes, hipStream_t s, int32_t* info_zero) {
     TH_REQUIRE(ws_bytes >= th_hull_ws(nv), "workspace too small");
     ThArena ar(ws, ws_bytes);
     GridInfo* gi = ar.take<GridInfo>(1);
@@ -213,12 +320,19 @@ int th_hull_mask_launch(const ThPointSrc& ps, long long P, const float* verts, i
     // cell size: thresh plus 5 % so fp rounding of the cell index can never
     // separate a vertex within `thresh` from the 3x3x3 neighbourhood
     float h0 = thresh * 1.05f;
-    hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1024), 0, s, verts, nv, h0, gi, counts);
-    hipLaunchKernelGGL(grid_count_kernel, dim3(th_cdiv(nv, 256)), dim3(256), 0, s, verts, nv, gi, counts);
-    hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, gi, counts, starts, cursor);
-    hipLaunchKernelGGL(grid_fill_kernel, dim3(th_cdiv(nv, 256)), dim3(256), 0, s, verts, nv, gi, cursor, sorted);
-    hipLaunchKernelGGL(grid_bbox_kernel, dim3(th_cdiv(GRID_MAX_CELLS * 8, 256)), dim3(256), 0, s, gi, starts, sorted, bbox);
-    if (ray_hit) TH_HIP(hipMemsetAsync(ray_hit, 0, sizeof(int32_t) * (size_t)ps.R, s));
+    static const bool split_build = getenv("TH_HULL_SPLIT_BUILD") != nullptr;     // A/B switch: the five-launch build
+    if (split_build) {
+        hipLaunchKernelGGL(grid_setup_kernel, dim3(1), dim3(1024), 0, s, verts, nv, h0, gi, counts);
+        hipLaunchKernelGGL(grid_count_kernel, dim3(th_cdiv(nv, 256)), dim3(256), 0, s, verts, nv, gi, counts);
+        hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, gi, counts, starts, cursor);
+        hipLaunchKernelGGL(grid_fill_kernel, dim3(th_cdiv(nv, 256)), dim3(256), 0, s, verts, nv, gi, cursor, sorted);
+        hipLaunchKernelGGL(grid_bbox_kernel, dim3(th_cdiv(GRID_MAX_CELLS * 8, 256)), dim3(256), 0, s, gi, starts, sorted, bbox);
+        if (ray_hit) TH_HIP(hipMemsetAsync(ray_hit, 0, sizeof(int32_t) * (size_t)ps.R, s));
+        if (info_zero) TH_HIP(hipMemsetAsync(info_zero, 0, 16 * sizeof(int32_t), s));
+    } else {
+        hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, s, verts, nv, h0, gi, counts, starts, cursor, sorted, bbox,
+                           ray_hit, ray_hit ? ps.R : 0, info_zero);
+    }
     hipLaunchKernelGGL(hull_mask_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, ps, P, gi, starts, sorted, bbox, thresh,
                        mask, ray_hit);
     TH_LAUNCH_CHECK();
@@ -264,12 +378,26 @@ int th_small_frame_rule(uint8_t* mask, const int32_t* ray_hit, int R, int S, int
 // ---------------------------------------------------------------------------
 #define CMP_ITEMS 4096   // per block (256 threads x 16)
 
+// Optional small-frame rule (if_clight_renderer.py:551) evaluated on the fly: when rule.ray_hit != nullptr and the
+// number of hit rays info[0] is <= thr, the effective mask of sample i is "ray i / S was hit" (every sample of a hit
+// ray is shaded); cmp_write_kernel then also stores that mask and records the mode in info[1].  Same result as the
+// separate small_frame_apply_kernel pass in front of a plain compaction, one launch and one 16 MB sweep less.
+struct CmpRule {
+    const int32_t* ray_hit;
+    int32_t* info;
+    int S, thr;
+};
+__device__ __forceinline__ bool cmp_rule_on(const CmpRule& r) { return r.ray_hit != nullptr && r.info[0] <= r.thr; }
+
 __global__ __launch_bounds__(256) void cmp_count_kernel(const uint8_t* __restrict__ mask, long long P,
-                                                        int* __restrict__ bcount) {
+                                                        int* __restrict__ bcount, CmpRule rule) {
     __shared__ int ws[4];
     long long base = (long long)blockIdx.x * CMP_ITEMS + threadIdx.x * 16;
     int c = 0;
-    if (base + 16 <= P) {
+    if (cmp_rule_on(rule)) {
+        for (int k = 0; k < 16; ++k)
+            if (base + k < P) c += rule.ray_hit[(int)((base + k) / rule.S)] != 0;
+    } else if (base + 16 <= P) {
         uint4 v = *reinterpret_cast<const uint4*>(mask + base);
         c = __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
             __popc(v.w & 0x01010101u);
@@ -306,12 +434,21 @@ __global__ __launch_bounds__(1024) void cmp_scan_kernel(int* __restrict__ bcount
     }
     if (threadIdx.x == 0) *total = carry;
 }
-__global__ __launch_bounds__(256) void cmp_write_kernel(const uint8_t* __restrict__ mask, long long P,
-                                                        const int* __restrict__ boff, int32_t* __restrict__ idx) {
+__global__ __launch_bounds__(256) void cmp_write_kernel(uint8_t* __restrict__ mask, long long P,
+                                                        const int* __restrict__ boff, int32_t* __restrict__ idx,
+                                                        CmpRule rule) {
     __shared__ int ws[4];
     long long base = (long long)blockIdx.x * CMP_ITEMS + threadIdx.x * 16;
     uint8_t m[16];
     int c = 0;
+    if (cmp_rule_on(rule)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) rule.info[1] = 1;
+        for (int k = 0; k < 16; ++k) {
+            m[k] = (base + k < P && rule.ray_hit[(int)((base + k) / rule.S)] != 0) ? 1 : 0;
+            if (base + k < P) mask[base + k] = m[k];
+            c += m[k] != 0;
+        }
+    } else
     for (int k = 0; k < 16; ++k) {
         m[k] = (base + k < P) ? mask[base + k] : 0;
         c += m[k] != 0;
@@ -332,15 +469,28 @@ __global__ __launch_bounds__(256) void cmp_write_kernel(const uint8_t* __restric
 
 size_t th_compact_ws(long long P) { return th_align((size_t)(th_cdiv(P, CMP_ITEMS) + 1) * sizeof(int)); }
 
-int th_compact_mask(const uint8_t* mask, long long P, int32_t* idx_out, int32_t* dev_count, void* ws,
-                    size_t ws_bytes, hipStream_t s) {
+static int compact_launch(uint8_t* mask, long long P, int32_t* idx_out, int32_t* dev_count, void* ws, size_t ws_bytes,
+                          const CmpRule& rule, hipStream_t s) {
     TH_REQUIRE(P < (1LL << 31), "too many points for int32 indices");
     int nb = th_cdiv(P, CMP_ITEMS);
     TH_REQUIRE(ws_bytes >= th_compact_ws(P), "workspace too small");
     int* bcount = (int*)ws;
-    hipLaunchKernelGGL(cmp_count_kernel, dim3(nb), dim3(256), 0, s, mask, P, bcount);
+    hipLaunchKernelGGL(cmp_count_kernel, dim3(nb), dim3(256), 0, s, mask, P, bcount, rule);
     hipLaunchKernelGGL(cmp_scan_kernel, dim3(1), dim3(1024), 0, s, bcount, nb, dev_count);
-    hipLaunchKernelGGL(cmp_write_kernel, dim3(nb), dim3(256), 0, s, mask, P, bcount, idx_out);
+    hipLaunchKernelGGL(cmp_write_kernel, dim3(nb), dim3(256), 0, s, mask, P, bcount, idx_out, rule);
     TH_LAUNCH_CHECK();
     return 0;
+}
+
+int th_compact_mask(const uint8_t* mask, long long P, int32_t* idx_out, int32_t* dev_count, void* ws,
+                    size_t ws_bytes, hipStream_t s) {
+    return compact_launch(const_cast<uint8_t*>(mask), P, idx_out, dev_count, ws, ws_bytes, CmpRule{nullptr, nullptr, 1, 0}, s);
+}
+
+// hit-ray count -> info[0]; then the compaction with the small-frame rule applied on the fly (info[1] = mode)
+int th_compact_mask_rule(uint8_t* mask, long long P, const int32_t* ray_hit, int R, int S, int thr, int32_t* dev_info,
+                         int32_t* idx_out, int32_t* dev_count, void* ws, size_t ws_bytes, hipStream_t s) {
+    // dev_info[0..1] must be zero on entry
+    hipLaunchKernelGGL(count_hits_kernel, dim3(R >= 65536 ? 256 : th_cdiv(R, 256)), dim3(256), 0, s, ray_hit, R, dev_info);
+    return compact_launch(mask, P, idx_out, dev_count, ws, ws_bytes, CmpRule{ray_hit, dev_info, S, thr}, s);
 }

@@ -647,21 +647,25 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         TH_HIP(hipEventSynchronize(c->prepass[slot].ev));
     } else {
     ProfScope* sc = new ProfScope(pf, TH_PROF_HULL, s);
-    TH_HIP(hipMemsetAsync(info, 0, 16 * 4, s));
     const bool no_hull = f->hull_thresh < 0.f;   // Renderer.render (:486-498): every sample shaded, RGB everywhere
     if (no_hull) {
+        TH_HIP(hipMemsetAsync(info, 0, 16 * 4, s));
         TH_HIP(hipMemsetAsync(mask, 1, (size_t)P, s));
         if (ray_mode) TH_HIP(hipMemsetAsync(ray_hit, 1, (size_t)R * 4, s));   // any non-zero marks a hit
     } else {
+        // (the grid build clears `info` and the per-ray hit flags: no memset launches)
         TH_TRY(th_hull_mask_launch(ps, P, f->verts_world, f->n_verts, f->hull_thresh, mask,
-                                   ray_mode ? ray_hit : nullptr, hws, hws_b, s));
+                                   ray_mode ? ray_hit : nullptr, hws, hws_b, s, info));
     }
     if (ray_mode) {
-        // no_hull: threshold R makes the rule fire -> un-masked mode (rgb for all samples)
-        TH_TRY(th_small_frame_rule(mask, ray_hit, R, S, no_hull ? R : f->small_frame_rays, info, s));
+        // hit-ray count, the R' <= 2400 rule (:551) and the compaction in one chain (no_hull: threshold R makes the
+        // rule fire -> un-masked mode, rgb for all samples)
         TH_TRY(th_view_embed_launch(ps.ray_d, R, 4, vd_all, s));
+        TH_TRY(th_compact_mask_rule(mask, P, ray_hit, R, S, no_hull ? R : f->small_frame_rays, info, idx, info + 2, cws,
+                                    cws_b, s));
+    } else {
+        TH_TRY(th_compact_mask(mask, P, idx, info + 2, cws, cws_b, s));
     }
-    TH_TRY(th_compact_mask(mask, P, idx, info + 2, cws, cws_b, s));
     // (raw is NOT cleared: its consumers read it through the mask -- 268 MB of memset + dense re-read saved per frame)
     delete sc;
     if (prepass == 1) {

@@ -251,8 +251,14 @@ struct th_ctx {
 // ---- launchers (one group per .hip file) -------------------------------------------
 // k_hull.hip
 size_t th_hull_ws(int n_verts);
+// (info_zero: optional 16-int block cleared by the grid build -- saves the caller a memset launch)
 int th_hull_mask_launch(const ThPointSrc& ps, long long P, const float* verts, int nv, float thresh,
-                        uint8_t* mask, int32_t* ray_hit, void* ws, size_t ws_bytes, hipStream_t s);
+                        uint8_t* mask, int32_t* ray_hit, void* ws, size_t ws_bytes, hipStream_t s,
+                        int32_t* info_zero = nullptr);
+// count of hit rays -> dev_info[0], then compaction with the reference's R' <= thr rule applied on the fly
+// (dev_info[1] = 1 and mask rewritten when it fires); dev_info[0..1] zero on entry
+int th_compact_mask_rule(uint8_t* mask, long long P, const int32_t* ray_hit, int R, int S, int thr, int32_t* dev_info,
+                         int32_t* idx_out, int32_t* dev_count, void* ws, size_t ws_bytes, hipStream_t s);
 // compaction helpers (k_hull.hip)
 size_t th_compact_ws(long long P);
 // counts[0]=n_valid written to dev_count; idx_out ascending
