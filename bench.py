@@ -177,6 +177,8 @@ def main():
                     help="render every frame with Renderer.render_fast (constants -> shading back to back on one stream) "
                          "instead of Renderer.render_sequence (constants of frame i+1 on a second stream under the "
                          "shading of frame i)")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="with --emulate-world: which rank's shard")
+    ap.add_argument("--tile", type=int, default=8, help="edge of the pixel tiles dealt round-robin to the ranks")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="developer aid: on ONE GPU render rank 0's shard of an N-rank job (no collectives); the JSON "
                          "line is then per-rank time, not a bench result")
@@ -216,7 +218,8 @@ def main():
     R = batch["ray_o"].shape[1]
     tile_major = os.environ.get("TH_RAY_ORDER", "tile") == "tile"
     emu = args.emulate_world if world == 1 and args.emulate_world > 1 else 0
-    my_idx = shard_ray_indices(H, W, emu or world, rank, tile=8, tile_major=tile_major).to(dev)
+    my_idx = shard_ray_indices(H, W, emu or world, args.emulate_rank if emu else rank, tile=args.tile,
+                               tile_major=tile_major).to(dev)
     shard = dict(batch)
     for k in ("ray_o", "ray_d", "near", "far"):
         shard[k] = batch[k][:, my_idx].contiguous()
@@ -412,7 +415,12 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
         nvox = g * g * g
         mine = torch.arange(nvox, device=dev)
         if world > 1:
-            mine = mine[((mine // 4096) % world) == rank]
+            # run r of 4096 voxels; the runs of one x-slice (g*g/4096 of them) are shifted from slice to slice so that
+            # a rank does not own the same y-band of every slice (see dist.shard_ray_indices)
+            from transhuman_amd.dist import _tile_skew
+            run = mine // 4096
+            per_slice = max(1, (g * g) // 4096)
+            mine = mine[((run % per_slice + _tile_skew(world) * (run // per_slice)) % world) == rank]
 
         def step(i):
             out = mr.render(mb, pts_slice=mine)
