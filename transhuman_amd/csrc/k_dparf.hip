@@ -20,6 +20,8 @@
 // fp32 [sample][view][256] (64 lanes x float4: every lane busy), and pe_out = the blended 63-wide positional
 // encoding, ONE split-f16 row (64 hi + 64 lo halves) per sample -- it is the same for every view.
 // Bound: L2 gather of 7*V*768 B per sample; HBM write 3 KB per sample.
+#include <stdlib.h>
+
 #include "th_internal.h"
 
 #define DP_K 7
@@ -199,7 +201,7 @@ int th_dparf_grid_build(const float* centres, int nc, void* ws, size_t ws_bytes,
     return 0;
 }
 
-template <bool FOLDED>
+template <bool FOLDED, int VT = 0>
 __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restrict__ pts_smpl, ThPointSrc ps,
                                                            const float* __restrict__ Rh, const float* __restrict__ Th,
                                                            const int32_t* __restrict__ sel, int P,
@@ -329,6 +331,32 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                 pe = (k == 0) ? w[k] * val : fmaf(w[k], val, pe);
             }
         }
+        if constexpr (FOLDED && VT > 0) {
+            // all VT * 7 row loads of the sample in flight before the first blend (one exposed round trip per sample
+            // instead of one per view)
+            float4 r[VT > 0 ? VT : 1][DP_K];
+#pragma unroll
+            for (int v = 0; v < VT; ++v)
+#pragma unroll
+                for (int k = 0; k < DP_K; ++k)
+                    r[v][k] = *reinterpret_cast<const float4*>(tokens + ((long long)v * nc + id[k]) * 256 + 4 * lane);
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                float4 acc = make_float4(w[0] * r[v][0].x, w[0] * r[v][0].y, w[0] * r[v][0].z, w[0] * r[v][0].w);
+#pragma unroll
+                for (int k = 1; k < DP_K; ++k) {
+                    acc.x = fmaf(w[k], r[v][k].x, acc.x); acc.y = fmaf(w[k], r[v][k].y, acc.y);
+                    acc.z = fmaf(w[k], r[v][k].z, acc.z); acc.w = fmaf(w[k], r[v][k].w, acc.w);
+                }
+                *reinterpret_cast<float4*>(out + ((long long)gp * VT + v) * 256 + 4 * lane) = acc;
+            }
+            _Float16* ph = reinterpret_cast<_Float16*>(pe_out) + (long long)gp * 128;
+            _Float16 x, y;
+            dp_split((lane < 63) ? pe : 0.f, x, y);
+            ph[lane] = x;
+            ph[64 + lane] = y;
+            continue;
+        }
         if (FOLDED) {
             for (int v = 0; v < V; ++v) {
                 const float* tv = tokens + (long long)v * nc * 256;
@@ -395,7 +423,16 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
         cnt = ar.take<int>(DPG_MAXCELLS);
         cand = ar.take<int>((size_t)DPG_MAXCELLS * nc);
     }
-    if (fmt == TH_ROWS_FOLDED)
+    static const bool per_view = getenv("TH_DPARF_PER_VIEW") != nullptr;       // A/B switch
+    if (fmt == TH_ROWS_FOLDED && V == 3 && !per_view) {
+        static bool attr3 = false;
+        if (!attr3) {
+            TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((dparf_kernel<true, 3>), dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
+                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out, gi, cnt, cand);
+    } else if (fmt == TH_ROWS_FOLDED)
         hipLaunchKernelGGL(dparf_kernel<true>, dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
                            Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out, gi, cnt, cand);
     else
