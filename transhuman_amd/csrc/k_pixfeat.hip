@@ -63,6 +63,9 @@ __device__ __forceinline__ float4 pg_blend(float4 a, float4 bb, float4 cc, float
 //           64 lanes = the 256 latent channels); columns >= 256 (compact map: r g b 0 + zero tail of the row)
 //           are produced for the 4 rows of a batch at once by lanes 0..15.
 #define PG_G 16
+#ifndef PG_B
+#define PG_B 4      // rows per batch: 4 PG_B corner loads in flight per wave
+#endif
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict__ map, int V, int C, int H, int W,
                                                         const float* __restrict__ pts_world, ThPointSrc ps,
@@ -98,11 +101,11 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
         b = th_bilinear_setup(uu, vv, scale[0], scale[1], H, W);
     }
     // ---- phase 2 ----
-    for (int r0 = 0; r0 < nrow; r0 += 4) {
-        float4 q[4][4];
-        float w[4][4];
+    for (int r0 = 0; r0 < nrow; r0 += PG_B) {
+        float4 q[PG_B][4];
+        float w[PG_B][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PG_B; ++j) {
             const int i = min(r0 + j, nrow - 1);                           // ragged tail: duplicate loads, no store
             const int i00 = __builtin_amdgcn_readlane(b.i00, i), i01 = __builtin_amdgcn_readlane(b.i01, i);
             const int i10 = __builtin_amdgcn_readlane(b.i10, i), i11 = __builtin_amdgcn_readlane(b.i11, i);
@@ -119,12 +122,12 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
         }
         // columns >= 256 of the 4 rows: lane = 4*t + j handles float4 column 64 + t of row r0 + j
         if (C4 <= 65 && L4 <= 68) {
-            const int j = lane & 3, t = lane >> 2, i = min(r0 + j, nrow - 1);
+            const int j = lane & (PG_B - 1), t = lane / PG_B, i = min(r0 + j, nrow - 1);
             const int c4 = 64 + t;
             // this lane's row parameters live in lane i (phase 1): fetch them across lanes
             const int i00 = __shfl(b.i00, i), i01 = __shfl(b.i01, i), i10 = __shfl(b.i10, i), i11 = __shfl(b.i11, i);
             const float w00 = __shfl(b.w00, i), w01 = __shfl(b.w01, i), w10 = __shfl(b.w10, i), w11 = __shfl(b.w11, i);
-            if (lane < 16 && c4 < L4 && r0 + j < nrow) {
+            if (lane < 4 * PG_B && c4 < L4 && r0 + j < nrow) {
                 float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (c4 < C4)
                     r = pg_blend(reinterpret_cast<const float4*>(m + (long long)i00 * C)[c4],
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PG_B; ++j) {
             if (r0 + j >= nrow) break;
             float* orow = out + ((long long)(p0 + r0 + j) * V + v) * ldo;
             if (lane < C4)
