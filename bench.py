@@ -324,6 +324,8 @@ def main():
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
                                        mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos)),
             "stage_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
+            "stage_note": "HIP-event spans per stage; with the frame pipeline hull / vit run on the side stream under the "
+                          "other stages (their spans are stretched by the overlap and do not add to the frame time)",
         }
         if emu:
             res["config"]["emulated_rank0_of"] = emu
