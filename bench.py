@@ -52,9 +52,10 @@ def algorithmic_mlp_flops(V, n_valid, n_pos):
 
 def executed_mlp_flops(V, n_valid, n_pos):
     """Dense MACs the fused kernel actually issues (per operand product triple counted once): the fc_0 token
-    part and fc_1 are folded away, the f-consuming layers have K = 272 (260 real), view_fc K = 288."""
+    part and fc_1 are folded away, the f-consuming layers have K = 272 (260 real), and view_fc is folded over
+    feature_fc / rgb_res_0 (128-wide products on inter, f and the 32-wide view-direction rows)."""
     row_sigma = 384 * 256 + 256 * 272 + 384 * 256 + 256 * 256            # kv1, alpha_res_0', kv0, fc_2
-    row_rgb = 256 * 256 + 256 * 272 + 128 * 288 + 128 * 272             # feature_fc, rgb_res_0', view_fc, rgb_res_1'
+    row_rgb = 128 * 256 + 128 * 32 + 256 * 272                          # (Wa F), Wd, stacked [Wa R0' ; rgb_res_1']
     mac_sigma = V * row_sigma + 256 * 64 + 256 * 256                      # + fc_0 PE part, fc_3 (per sample)
     mac_rgb = V * row_rgb + 128 * 128                                     # + fc_4
     return 2.0 * (n_valid * mac_sigma + n_pos * mac_rgb)

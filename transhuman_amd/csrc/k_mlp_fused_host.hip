@@ -70,10 +70,10 @@ __global__ void absmax_kernel(const float* __restrict__ w, long long n, unsigned
 size_t th_fused_pack_bytes() {
     // every layer, both planes, K padded to 16 (+ biases / column tables / scratch in a 64 KiB tail)
     size_t halves = 0;
-    const int dims[][2] = {{256, 256}, {384, 256}, {256, 384}, {384, 256}, {256, 256}, {256, 256}, {256, 256},
-                           {256, 256}, {256, 384}, {128, 288}, {128, 384}, {128, 128},
-                           {256, 272}, {256, 272}, {128, 272}};   // colour-folded ar0 / rr0 / rr1
-    for (auto& d : dims) halves += (size_t)d[0] * d[1] * 2;
+    const int dims[][2] = {{256, 64},  {256, 384}, {256, 272}, {384, 256}, {384, 256}, {256, 256}, {256, 256},
+                           {128, 256}, {128, 32},  {256, 384}, {256, 272}, {128, 128}};
+    // fc_0pe, ar0, ar0c, kv1, kv0, fc_2, fc_3, vfA, vfD, rst, rstc, fc_4
+    for (auto& d : dims) halves += (size_t)d[0] * d[1] * 2 + 4096;
     return th_align(halves * 2) + 16 * 256 + 64 * 1024;
 }
 
@@ -144,62 +144,138 @@ __global__ void fold_bias_kernel(const float* __restrict__ F, const float* __res
     out[o] = (float)acc;
 }
 
+// ---- algebraic fold of feature_fc / rgb_res_0 into view_fc ----------------------------------------------
+// _RGB_forward (cross_transformer.py:330-343): features = feature_fc(inter) + rgb_res_0(f); net =
+// relu(view_fc(cat(features, viewdir))).  There is no nonlinearity between the two linear maps, so with
+// view_fc.W = [Wa (128 x 256) | Wd (128 x 27)]:
+//   view_fc(.) = (Wa F) inter + (Wa R0) f + Wd viewdir + [b_vf + Wa (b_F + b_R0)]
+// 128-wide products replace the two 256-wide layers (206 848 -> 106 496 MACs per row of the RGB branch, one
+// barrier-delimited phase and one [96][256] hi/lo epilogue less).  The products are formed once at weight
+// upload with fp64 accumulation; rgb_res_1(f) (added after the relu, :346) rides along as the second
+// column-tile family of the same pass over f.
+// out[m][n] = sum_k A[m*lda + k] * B[k*ldb + n]
+__global__ void fold_mm_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int K, int N,
+                               float* __restrict__ out, int ldo) {
+    const int m = blockIdx.x;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        double acc = 0.0;
+        for (int k = 0; k < K; ++k) acc += (double)A[(long long)m * lda + k] * (double)B[(long long)k * ldb + n];
+        out[(long long)m * ldo + n] = (float)acc;
+    }
+}
+// out[m] = b0[m] + sum_k A[m*lda + k] * (b1[k] + b2[k])   (null biases count as zero)
+__global__ void fold_mv_kernel(const float* __restrict__ A, int lda, int K, const float* __restrict__ b0,
+                               const float* __restrict__ b1, const float* __restrict__ b2, float* __restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc = b0 ? (double)b0[m] : 0.0;
+    for (int k = 0; k < K; ++k)
+        acc += (double)A[(long long)m * lda + k] * ((b1 ? (double)b1[k] : 0.0) + (b2 ? (double)b2[k] : 0.0));
+    out[m] = (float)acc;
+}
+// dst[r][:] = src[r][:] * scale (a power of two: exact)
+__global__ void scale_rows_kernel(const float* __restrict__ src, int lds_, int rows, int cols, float scale,
+                                  float* __restrict__ dst, int ldd) {
+    long long n = (long long)rows * cols;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        int r = (int)(i / cols), c = (int)(i % cols);
+        dst[(long long)r * ldd + c] = src[(long long)r * lds_ + c] * scale;
+    }
+}
+
 // Builds the fused image from the fp32 layers.  `store` = th_fused_pack_bytes() of device memory.
 int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store, FusedParams* out, hipStream_t s) {
     char* tail = (char*)store + th_fused_pack_bytes() - 64 * 1024;
     PackCursor cur{(char*)store, (float*)tail, (int*)(tail + 40 * 1024)};
     unsigned int* amax = (unsigned int*)(tail + 60 * 1024);
-    int c256[8], c128[4], ckv[12];
+    int c256[8], c128[4], ckv[12], cst[8];
     for (int wv = 0; wv < 4; ++wv) {
         c256[wv * 2] = wv * 64; c256[wv * 2 + 1] = wv * 64 + 32;
         c128[wv] = wv * 32;
         // stacked [key(128); value(256)]: tile 0 = key cols wave*32, tiles 1,2 = value cols 128 + wave*64 (+32)
         ckv[wv * 3] = wv * 32; ckv[wv * 3 + 1] = 128 + wv * 64; ckv[wv * 3 + 2] = 128 + wv * 64 + 32;
+        // stacked [Wa R0 (128); rgb_res_1 (128)]: tile 0 = view_fc cols wave*32, tile 1 = rgb_res_1 cols wave*32
+        cst[wv * 2] = wv * 32; cst[wv * 2 + 1] = 128 + wv * 32;
     }
     int sl2, sl2b;
 #define PACK_SIMPLE(LAYER, L, N_, K_, CT_, COLS)                                       \
     TH_TRY(layer_scale_log2((L).w, (long long)(N_) * (K_), amax, &sl2, s));            \
     TH_TRY(pack_layer((L).w, (L).b, N_, K_, CT_, COLS, sl2, cur, &out->LAYER, s))
+    // scratch for the folds (fp32): wpe [256,63] | XF [128,256] | XR [128,384] | XRc [128,260] | st [256,384] | bias [256]
+    float* scratch = nullptr;
+    const size_t n_scratch = 256 * 63 + 128 * 256 + 128 * 384 + 128 * 260 + 256 * 384 + 256 + (384 * 256 + 384);
+    TH_HIP(hipMalloc((void**)&scratch, n_scratch * 4));
+    struct Free { float* p; ~Free() { (void)hipFree(p); } } free_scratch{scratch};
+    float* wpe = scratch;
+    float* XF = wpe + 256 * 63;
+    float* XR = XF + 128 * 256;
+    float* XRc = XR + 128 * 384;
+    float* st = XRc + 128 * 260;
+    float* stb = st + 256 * 384;
+    float* tw = stb + 256;
     {   // fc_0: only the 63 positional-encoding columns [192, 255) stay in the kernel (token columns -> T', th_api.hip)
-        float* wpe = nullptr;
-        TH_HIP(hipMalloc((void**)&wpe, 256 * 63 * 4));
         TH_HIP(hipMemcpy2DAsync(wpe, 63 * 4, w->fc_0.w + 192, 255 * 4, 63 * 4, 256, hipMemcpyDeviceToDevice, s));
         TH_TRY(layer_scale_log2(wpe, 256LL * 63, amax, &sl2, s));
         TH_TRY(pack_layer(wpe, w->fc_0.b, 256, 63, 2, c256, sl2, cur, &out->fc_0pe, s));
-        TH_HIP(hipStreamSynchronize(s));
-        TH_HIP(hipFree(wpe));
     }
     PACK_SIMPLE(ar0, w->alpha_res_0, 256, 384, 2, c256);
-    PACK_SIMPLE(fc_1, w->fc_1, 256, 256, 2, c256);
     PACK_SIMPLE(fc_2, w->fc_2, 256, 256, 2, c256);
     PACK_SIMPLE(fc_3, w->fc_3, 256, 256, 2, c256);
-    PACK_SIMPLE(vfc, w->view_fc, 128, 283, 1, c128);
-    PACK_SIMPLE(rr1, w->rgb_res_1, 128, 384, 1, c128);
     PACK_SIMPLE(fc_4, w->fc_4, 128, 128, 1, c128);
 #undef PACK_SIMPLE
-    // feature_fc and rgb_res_0 (either form) accumulate into ONE register tile -> they must share a scale
-    TH_TRY(layer_scale_log2(w->feature_fc.w, 256LL * 256, amax, &sl2, s));
-    TH_TRY(layer_scale_log2(w->rgb_res_0.w, 256LL * 384, amax, &sl2b, s));
-    if (sl2b < sl2) sl2 = sl2b;
-    if (folded) {
-        TH_TRY(layer_scale_log2(folded[1].w, 256LL * 260, amax, &sl2b, s));
-        if (sl2b < sl2) sl2 = sl2b;
-    }
-    TH_TRY(pack_layer(w->feature_fc.w, w->feature_fc.b, 256, 256, 2, c256, sl2, cur, &out->feat, s));
-    TH_TRY(pack_layer(w->rgb_res_0.w, w->rgb_res_0.b, 256, 384, 2, c256, sl2, cur, &out->rr0, s));
     out->compact_ready = false;
     if (folded) {
-        // colour-folded layers: K = 260 -> 17 k-blocks, consumed as 8 + 9 (see the kernel's f layout)
-        TH_TRY(pack_layer(folded[1].w, folded[1].b, 256, 260, 2, c256, sl2, cur, &out->rr0c, s));
         TH_TRY(layer_scale_log2(folded[0].w, 256LL * 260, amax, &sl2, s));
         TH_TRY(pack_layer(folded[0].w, folded[0].b, 256, 260, 2, c256, sl2, cur, &out->ar0c, s));
-        TH_TRY(layer_scale_log2(folded[2].w, 128LL * 260, amax, &sl2, s));
-        TH_TRY(pack_layer(folded[2].w, folded[2].b, 128, 260, 1, c128, sl2, cur, &out->rr1c, s));
-        out->compact_ready = true;
+    }
+    // ---- RGB branch: view_fc folded over feature_fc / rgb_res_0 (see above) ----
+    {
+        const float* Wvf = w->view_fc.w;                  // [128, 283] = [Wa | Wd]
+        hipLaunchKernelGGL(fold_mm_kernel, dim3(128), dim3(256), 0, s, Wvf, 283, w->feature_fc.w, 256, 256, 256, XF, 256);
+        hipLaunchKernelGGL(fold_mm_kernel, dim3(128), dim3(256), 0, s, Wvf, 283, w->rgb_res_0.w, 384, 256, 384, XR, 384);
+        if (folded)
+            hipLaunchKernelGGL(fold_mm_kernel, dim3(128), dim3(256), 0, s, Wvf, 283, folded[1].w, 260, 256, 260, XRc, 260);
+        TH_LAUNCH_CHECK();
+        // the three K ranges of the folded view_fc accumulate into ONE register tile -> one scale
+        TH_TRY(layer_scale_log2(XF, 128LL * 256, amax, &sl2, s));
+        TH_TRY(layer_scale_log2(XR, 128LL * 384, amax, &sl2b, s));
+        if (sl2b < sl2) sl2 = sl2b;
+        if (folded) {
+            TH_TRY(layer_scale_log2(XRc, 128LL * 260, amax, &sl2b, s));
+            if (sl2b < sl2) sl2 = sl2b;
+        }
+        {   // Wd: strided view of view_fc -> contiguous [128, 27] in `st`
+            TH_HIP(hipMemcpy2DAsync(st, 27 * 4, Wvf + 256, 283 * 4, 27 * 4, 128, hipMemcpyDeviceToDevice, s));
+            TH_TRY(layer_scale_log2(st, 128LL * 27, amax, &sl2b, s));
+            if (sl2b < sl2) sl2 = sl2b;
+            TH_TRY(pack_layer(st, nullptr, 128, 27, 1, c128, sl2, cur, &out->vfD, s));
+        }
+        const int s_vf = sl2;
+        TH_TRY(pack_layer(XF, nullptr, 128, 256, 1, c128, s_vf, cur, &out->vfA, s));
+        for (int variant = 0; variant < (folded ? 2 : 1); ++variant) {
+            const int K = variant ? 260 : 384;
+            const float* xr = variant ? XRc : XR;
+            const th_linear& r0 = variant ? folded[1] : w->rgb_res_0;
+            const th_linear& r1 = variant ? folded[2] : w->rgb_res_1;
+            int s_r1;
+            TH_TRY(layer_scale_log2(r1.w, 128LL * K, amax, &s_r1, s));
+            hipLaunchKernelGGL(scale_rows_kernel, dim3(128), dim3(256), 0, s, xr, K, 128, K, ldexpf(1.f, s_vf), st, K);
+            hipLaunchKernelGGL(scale_rows_kernel, dim3(128), dim3(256), 0, s, r1.w, K, 128, K, ldexpf(1.f, s_r1),
+                               st + 128 * K, K);
+            // bias rows: [b_vf + Wa (b_F + b_R0) | b_R1]
+            hipLaunchKernelGGL(fold_mv_kernel, dim3(1), dim3(128), 0, s, Wvf, 283, 256, w->view_fc.b, w->feature_fc.b,
+                               r0.b, stb);
+            if (r1.b) TH_HIP(hipMemcpyAsync(stb + 128, r1.b, 128 * 4, hipMemcpyDeviceToDevice, s));
+            else TH_HIP(hipMemsetAsync(stb + 128, 0, 128 * 4, s));
+            TH_LAUNCH_CHECK();
+            FusedLayer* dst = variant ? &out->rstc : &out->rst;
+            TH_TRY(pack_layer(st, stb, 256, K, 2, cst, 0, cur, dst, s));
+            dst->inv_scale = ldexpf(1.f, -s_vf);
+            dst->inv_scale2 = ldexpf(1.f, -s_r1);
+        }
+        out->vfA.inv_scale = out->vfD.inv_scale = ldexpf(1.f, -s_vf);
+        out->compact_ready = folded != nullptr;
     }
     // stacked key/value layers need a contiguous [384,256] weight + [384] bias
-    float* tw = nullptr;
-    TH_HIP(hipMalloc((void**)&tw, (size_t)(384 * 256 + 384) * 4));
     float* tb = tw + 384 * 256;
     for (int which = 0; which < 2; ++which) {
         const th_linear& k = which == 0 ? w->key1 : w->key0;
@@ -213,12 +289,12 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
         TH_TRY(layer_scale_log2(tw, 384LL * 256, amax, &sl2, s));
         TH_TRY(pack_layer(tw, tb, 384, 256, 3, ckv, sl2, cur, which == 0 ? &out->kv1 : &out->kv0, s));
     }
-    // folded bias of fc_1 (the packed fc_1 weights above are no longer read by the kernel)
+    // folded bias of fc_1 (fc_1 itself lives inside the value projections)
     hipLaunchKernelGGL(fold_bias_kernel, dim3(1), dim3(256), 0, s, w->fc_1.w, w->fc_1.b, w->val1.b, w->val0.b, cur.bias);
+    out->fc_1 = FusedLayer{};
     out->fc_1.bias = cur.bias;
     cur.bias += 256;
     TH_HIP(hipStreamSynchronize(s));
-    TH_HIP(hipFree(tw));
     TH_REQUIRE(cur.w <= tail, "fused pack overflow");
     TH_REQUIRE((char*)cur.bias <= tail + 40 * 1024 && (char*)cur.cols <= tail + 60 * 1024, "fused pack tail overflow");
     return 0;
@@ -233,7 +309,7 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
                "pixel-feature rows must be 384 wide, or 272 wide with upsample_color weights uploaded");
     const bool cf = f_ld == 272;
     FusedParams p = base;
-    if (cf) { p.ar0 = base.ar0c; p.rr0 = base.rr0c; p.rr1 = base.rr1c; }
+    if (cf) { p.ar0 = base.ar0c; p.rst = base.rstc; }
     p.alpha_w = heads.alpha_w; p.alpha_b = heads.alpha_b; p.rgb_w = heads.rgb_w; p.rgb_b = heads.rgb_b;
     p.stok = stok; p.pe = (const _Float16*)pe; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
     static bool attr = false;
@@ -250,8 +326,8 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     // so the weight working set is 256 KB -> shows how much of a phase is L2-capacity/latency
     static int alias_w = getenv("TH_FUSED_ALIAS_W") ? 1 : 0;
     if (alias_w) {
-        FusedLayer* ls[] = {&p.kv1, &p.ar0, &p.kv0, &p.fc_2, &p.fc_3, &p.feat, &p.rr0, &p.vfc, &p.rr1, &p.fc_4};
-        for (auto* l : ls) l->w = p.fc_1.w;
+        FusedLayer* ls[] = {&p.kv1, &p.ar0, &p.kv0, &p.fc_2, &p.fc_3, &p.vfA, &p.rst, &p.fc_4};
+        for (auto* l : ls) l->w = p.kv1.w;
     }
     // developer aid: TH_FUSED_DBG=1 -> average cycles between barriers over every 16th tile (first big launch only)
     static int dbg_state = getenv("TH_FUSED_DBG") ? 1 : 0;

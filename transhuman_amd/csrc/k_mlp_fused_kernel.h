@@ -571,6 +571,21 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     FM_SYNC();
 
     // ================= sigma head: relu(fc_3 m) . alpha_w + b =================
+    // view directions of the tile (27 of 32 columns used; operand of the folded view_fc): requested here so the
+    // loads fly under the fc_3 GEMM, parked in MBUF once every wave is done reading the fc_3 operand
+    float vdv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int i = tid + 256 * q, row = i >> 5, c = i & 31;
+        float x = 0.f;
+        if (P.rgb_all != 2 && c < 27 && row < npts) {
+            const long long vr = P.vd_sel ? (long long)(P.vd_sel[pbase + row] / P.vd_div) : (long long)(pbase + row);
+            x = P.vd[vr * 27 + c];
+        }
+        vdv[q] = x;
+    }
+    char* vd_hi = mbuf + MBUF_VD_OFF;
+    char* vd_lo = vd_hi + 32 * STRVD;
     {
         f32x16 a1[2][1];
         gemm_phase_z<1, 2, STR256, 32 * STR256, 6>(mbuf, mbuf + 32 * STR256, wslice(P.fc_3, wave, 2, 0), P.fc_3.KB, lane, a1);
@@ -587,6 +602,14 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         if (tid < 32)
             sig[tid] = part[tid * 4] + part[(32 + tid) * 4] + part[(64 + tid) * 4] + part[(96 + tid) * 4] + P.alpha_b[0];
         if (tid == 0) *flag = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int i = tid + 256 * q, row = i >> 5, c = i & 31;
+            _Float16 a, b;
+            split_h(vdv[q], a, b);
+            *reinterpret_cast<_Float16*>(vd_hi + row * STRVD + 2 * c) = a;
+            *reinterpret_cast<_Float16*>(vd_lo + row * STRVD + 2 * c) = b;
+        }
         FM_SYNC();
         // rgb_all: 0 progressive (sigma > 0 only, :296-305), 1 every sample (MLP_forward_ori), 2 none (sigma grid)
         if (tid < npts && P.rgb_all != 2 && (P.rgb_all == 1 || sig[tid] > 0.f)) *flag = 1;
@@ -596,78 +619,38 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     float rgb_out[3] = {0.f, 0.f, 0.f};
     if (need_rgb) {
         // ================= RGB branch (cross_transformer.py:330-353) =================
-        // feat = feature_fc(inter) + rgb_res_0(f)   (one accumulator: both layers share a scale)
-        f32x16 r1[1][V];
-        gemm_phase_z<V, 2, STR256>(abuf, a256_lo, wslice(P.feat, wave, 2, 0), P.feat.KB, lane, acc2);
-        FM_SYNC();
-        // view directions of the tile (27 of 32 columns used), fetched now, split into MBUF after the f passes
-        float vdv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int i = tid + 256 * q, row = i >> 5, c = i & 31;
-            float x = 0.f;
-            if (c < 27 && row < npts) {
-                const long long vr = P.vd_sel ? (long long)(P.vd_sel[pbase + row] / P.vd_div) : (long long)(pbase + row);
-                x = P.vd[vr * 27 + c];
-            }
-            vdv[q] = x;
-        }
+        // view_fc is folded over feature_fc / rgb_res_0 (k_mlp_fused_host.hip):
+        //   t = relu((Wa F) inter + Wd viewdir + (Wa R0) f + b') ; u = t + rgb_res_1(f) ; mean over views ; fc_4 ; rgb_fc
+        // acc2[0] collects the three K ranges of the folded view_fc (this wave's 32 of its 128 outputs), acc2[1] is
+        // rgb_res_1: the pass over f multiplies the stacked [Wa R0 ; R1] image as two column tiles.
+        f32x16 (&vf)[1][V] = *reinterpret_cast<f32x16 (*)[1][V]>(&acc2[0]);
+        gemm_phase_z<V, 1, STR256, 32 * STR256, 6>(abuf, a256_lo, wslice(P.vfA, wave, 1, 0), 16, lane, vf);
+        gemm_phase<V, 1, STRVD, 0>(vd_hi, vd_lo, wslice(P.vfD, wave, 1, 0), 2, lane, vf);
+        FM_SYNC();                                  // every wave is done reading inter: ABUF may take f again
         stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
+#pragma unroll
+        for (int r = 0; r < V; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[1][r][e] = 0.f;
         FM_SYNC();
-        gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.rr0, wave, 2, 0), FL::NA, lane, acc2);
-        gemm_phase_z<V, 1, FL::SA, 32 * FL::SA, 6>(abuf, fa_lo, wslice(P.rr1, wave, 1, 0), FL::NA, lane, r1);
-        FM_SYNC();
+        gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.rst, wave, 2, 0), FL::NA, lane, acc2);
         if constexpr (FL::NB > 0) {
+            FM_SYNC();
             stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
             FM_SYNC();
-            gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.rr0, wave, 2, FL::NA), FL::NB, lane, acc2);
-            gemm_phase<V, 1, FL::SB, 32 * FL::SB, 6>(abuf, fb_lo, wslice(P.rr1, wave, 1, FL::NA), FL::NB, lane, r1);
-            FM_SYNC();
+            gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.rst, wave, 2, FL::NA), FL::NB, lane, acc2);
         }
-        // feat (+ both biases) -> ABUF [ROWS][256]; the 27 view-direction inputs of view_fc -> MBUF [32][32]
-        char* vd_hi = mbuf + MBUF_VD_OFF;
-        char* vd_lo = vd_hi + 32 * STRVD;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            finish_tile<V>(acc2[c], P.feat.bias, wave * 64 + c * 32, P.feat.inv_scale, false, lane);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float4 b = *reinterpret_cast<const float4*>(P.rr0.bias + wave * 64 + c * 32 + 8 * g + 4 * (lane >> 5));
-#pragma unroll
-                for (int r = 0; r < V; ++r) {
-                    acc2[c][r][4 * g] += b.x; acc2[c][r][4 * g + 1] += b.y;
-                    acc2[c][r][4 * g + 2] += b.z; acc2[c][r][4 * g + 3] += b.w;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < V; ++r)
-                store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int i = tid + 256 * q, row = i >> 5, c = i & 31;
-            float x = vdv[q];
-            _Float16 a, b;
-            split_h(x, a, b);
-            *reinterpret_cast<_Float16*>(vd_hi + row * STRVD + 2 * c) = a;
-            *reinterpret_cast<_Float16*>(vd_lo + row * STRVD + 2 * c) = b;
-        }
-        FM_SYNC();
-        // view_fc over [feat(256) | viewdir(27 -> 32)]: 16 k-blocks from ABUF + 2 from the shared viewdir rows
-        f32x16 vf[1][V];
-        gemm_phase_z<V, 1, STR256, 32 * STR256, 6>(abuf, a256_lo, wslice(P.vfc, wave, 1, 0), 16, lane, vf);
-        gemm_phase<V, 1, STRVD, 0>(vd_hi, vd_lo, wslice(P.vfc, wave, 1, 16), 2, lane, vf);
-        finish_tile<V>(vf[0], P.vfc.bias, wave * 32, P.vfc.inv_scale, true, lane);
-        finish_tile<V>(r1[0], P.rr1.bias, wave * 32, P.rr1.inv_scale, false, lane);
+        finish_tile<V>(acc2[0], P.rst.bias, wave * 32, P.rst.inv_scale, true, lane);
+        finish_tile<V>(acc2[1], P.rst.bias, 128 + wave * 32, P.rst.inv_scale2, false, lane);
         char* f4_hi = mbuf + MBUF_FC4_OFF;
         char* f4_lo = f4_hi + 32 * STR128;
         {
             f32x16 m;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float a = vf[0][0][e] + r1[0][0][e];
+                float a = acc2[0][0][e] + acc2[1][0][e];
 #pragma unroll
-                for (int r = 1; r < V; ++r) a = a + (vf[0][r][e] + r1[0][r][e]);
+                for (int r = 1; r < V; ++r) a = a + (acc2[0][r][e] + acc2[1][r][e]);
                 m[e] = a / (float)V;
             }
             store_tile_h<STR128>(m, myrow, wave * 32, f4_hi, f4_lo, lane);

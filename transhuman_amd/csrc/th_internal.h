@@ -189,11 +189,16 @@ struct FusedLayer {
     const float* bias;   // [N]
     float inv_scale;     // 2^-scale_log2
     int CT, KB;
+    float inv_scale2;    // stacked layers: scale of the second column-tile family (rows N/2 ..)
 };
 struct FusedParams {
     FusedLayer fc_0pe;             // fc_0[:, 192:255] (the positional-encoding columns) + the fc_0 bias
-    FusedLayer kv1, ar0, kv0, fc_1, fc_2, fc_3, feat, rr0, vfc, rr1, fc_4;
-    FusedLayer ar0c, rr0c, rr1c;   // colour-folded (K = 272) forms; the launcher copies them over ar0/rr0/rr1
+    FusedLayer kv1, ar0, kv0, fc_1, fc_2, fc_3, fc_4;
+    // RGB branch after the view_fc fold (k_mlp_fused_host.hip): vfA = view_fc[:, :256] feature_fc (K 256, on inter),
+    // vfD = view_fc[:, 256:283] (K 32, on the view-direction rows), rst = [view_fc[:, :256] rgb_res_0 ; rgb_res_1]
+    // stacked along out_f (K 384, on f): column tile 0 accumulates onto vfA / vfD, tile 1 is rgb_res_1
+    FusedLayer vfA, vfD, rst;
+    FusedLayer ar0c, rstc;         // colour-folded (K = 272) forms; the launcher copies them over ar0 / rst
     bool compact_ready;
     const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
     // token branch, written by K4 in TH_ROWS_FOLDED form: the neighbour blend of T' = tokens W_tok^T (fp32) and

@@ -240,27 +240,37 @@ def set_vit_weights(vit):
                                   _stream()))
 
 
-_weight_versions = {}
-_param_lists = {}
+_ctx_owner = {}        # (device index, kind) -> (weakref to the module whose weights the ctx holds, version tuple)
+_param_lists = {}      # id(module) -> [weakref(module), parameter list, calls since the last walk]
 
 
 def _sync_weights(mod, kind):
-    """Re-upload when any parameter changed (load_state_dict, .cuda(), optimiser step).
+    """Re-upload when the device context does not hold THIS module's current weights: a th_ctx has one MLP and
+    one ViT weight image per device, so ownership is tracked per (device, kind) -- rendering with net A, then
+    net B, then A again re-uploads A (a cache keyed by id(module) alone would find A's old version tuple and
+    shade A with B's weights; the same for a new module that lands on a freed module's id()).  Any parameter
+    change (load_state_dict, .cuda(), optimiser step) bumps the version tuple.
     The check runs every frame, so it is kept cheap: the module tree is walked once (and again every 256 calls,
     in case a Parameter object was replaced), per call only the in-place version counters of the cached
     parameter list and the addresses of its first / last tensor are read (25 us instead of 0.9 ms for the
     310-tensor Network: the walk used to leave the GPU idle in front of the per-sample stage)."""
-    key = (id(mod), kind)
-    ent = _param_lists.get(key)
-    if ent is None or ent[1] >= 256:
-        ent = [list(mod.parameters()), 0]
-        _param_lists[key] = ent
-    ent[1] += 1
-    pl = ent[0]
+    import weakref
+    ent = _param_lists.get(id(mod))
+    if ent is None or ent[0]() is not mod or ent[2] >= 256:
+        ent = [weakref.ref(mod), list(mod.parameters()), 0]
+        _param_lists[id(mod)] = ent
+        if len(_param_lists) > 64:                       # drop entries of modules that are gone
+            for k in [k for k, v in _param_lists.items() if v[0]() is None]:
+                del _param_lists[k]
+    ent[2] += 1
+    pl = ent[1]
     ver = (tuple(p._version for p in pl), pl[0].data_ptr(), pl[-1].data_ptr(), len(pl))
-    if _weight_versions.get(key) != ver:
+    dev = pl[0].device
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), kind)
+    own = _ctx_owner.get(key)
+    if own is None or own[0]() is not mod or own[1] != ver:
         (set_mlp_weights if kind == "mlp" else set_vit_weights)(mod)
-        _weight_versions[key] = ver
+        _ctx_owner[key] = (weakref.ref(mod), ver)
 
 
 # ---------------------------------------------------------------------------
