@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 2
+#define TH_ABI_VERSION 3
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -91,6 +91,25 @@ int th_set_mlp_weights(th_ctx* ctx, const th_mlp_weights* w, th_stream stream);
  * v_mfma_f32_32x32x16_f16 with fp16 hi/lo operand splitting (3 products, fp32 accumulate: fp32-class
  * accuracy); 0 = one fp32-MFMA GEMM launch per layer (exact fp32 products; also the path for V = 4). */
 int th_set_mlp_mode(th_ctx* ctx, int mode);
+
+/* Range guard of the fp16 hi/lo split arithmetic (fused MLP kernel, its producer K5, the ResNet-stem convolutions).
+ * The reference computes this path in fp32 (cross_transformer.py:291-353 has no autocast); the fused kernel is
+ * fp32-class only while every split value satisfies |x| < 65504 (fp16 range) and the tensor it belongs to is not
+ * uniformly tiny (below 2^-14 the halves are subnormal: absolute resolution 2^-25).  The kernels keep launch-wide
+ * maxima of |x| per split tensor in a device table; th_range_snapshot queues a copy of the table (and clears it)
+ * behind the work issued so far on `stream` and returns a slot id (>= 0; 4 slots rotate), th_range_read waits for that
+ * copy and returns the TH_RANGE_SLOTS words: slots 0..5 = fp16 bit pattern of max |hi half| of
+ * {f rows (K5), s, p, n, inter, fc_4 operand}; slot 6 = fp32 bit pattern of max |input| of the stem convolutions;
+ * inf / NaN show up as values >= 0x7C00 (fp16 slots) / 0x7F800000 (fp32 slot).  th_render_rays,
+ * th_eval_sigma_grid and th_network_forward take a snapshot at their end (th_range_last_slot).  A caller that finds
+ * a slot >= TH_RANGE_FP16_LIMIT, or a non-zero slot below TH_RANGE_FP16_FLOOR, re-renders with th_set_mlp_mode(ctx, 0)
+ * (per-layer fp32 MFMA): transhuman_amd/hip.py does exactly that. */
+#define TH_RANGE_SLOTS 8
+#define TH_RANGE_FP16_LIMIT 0x7B53u     /* 6.0e4 */
+#define TH_RANGE_FP16_FLOOR 0x2400u     /* 2^-6  */
+int th_range_snapshot(th_ctx* ctx, th_stream stream);
+int th_range_read(th_ctx* ctx, int slot, uint32_t* out /* [TH_RANGE_SLOTS] */);
+int th_range_last_slot(th_ctx* ctx);
 /* Samples shaded per pass of the per-sample stage (process-wide; default 524288, the reference's
  * batchify_rays chunk is 32768, if_clight_renderer.py:575).  Results do not depend on it; workspace
  * sizes do, so call it before the *_workspace_bytes() queries. */
@@ -307,7 +326,7 @@ typedef struct {
 /* Renderer.render_fast :429-484 incl. _render/batchify_rays/raw2outputs for a
  * range of rays (the unit that is sharded across GPUs).  Outputs are dense
  * over the R rays (zeros for rays that miss the hull).
- * stats_host (optional, int64[4]): hit rays, valid samples, sigma>0 samples, mode. */
+ * stats_host (optional, int64[4]): hit rays, valid samples, range-guard snapshot slot (th_range_read), mode. */
 size_t th_render_workspace_bytes(const th_frame* f, int R, int S);
 int th_render_rays(th_ctx* ctx, const th_frame* f, const th_points* rays, float* rgb, float* acc,
                    float* depth, int white_bkgd, void* workspace, size_t workspace_bytes,

@@ -26,6 +26,12 @@ __device__ __forceinline__ void cv_split(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
     lo = (_Float16)(x - (float)hi);
 }
+// range guard of the split input (th_range_read, slot TH_RANGE_CONV): running maximum of |x| as fp32 bit patterns
+// (inf / NaN order above every finite value); merged into the launch-wide table with an atomic only when it grows
+__device__ __forceinline__ void cv_range_acc(unsigned& rm, float x) { rm = max(rm, __float_as_uint(x) & 0x7fffffffu); }
+__device__ __forceinline__ void cv_range_commit(unsigned* __restrict__ table, unsigned rm) {
+    if (table != nullptr && rm > table[TH_RANGE_CONV]) atomicMax(table + TH_RANGE_CONV, rm);
+}
 
 // ---- weight packing ---------------------------------------------------------------------------------------------
 __global__ void conv_absmax_kernel(const float* __restrict__ w, long long n, unsigned int* __restrict__ out) {
@@ -101,7 +107,7 @@ __device__ __forceinline__ int cv_chan(int e, int lane) { return (e & 3) + 8 * (
 template <int CIN, int COUT, int S, int KS, int TR, int WC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                         float inv_scale, float* __restrict__ y, int H, int W, int Ho,
-                                                        int Wo) {
+                                                        int Wo, unsigned* __restrict__ range) {
     constexpr int PAD = KS / 2;
     constexpr int IR = (TR - 1) * S + KS, IC = 31 * S + KS;
     constexpr int STRB = 2 * CIN + 16;
@@ -128,6 +134,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
         constexpr int SB = 6;
         const float* xn = x + (long long)n * CIN * H * W;
         const long long HW = (long long)H * W;
+        unsigned rmax = 0u;
 #ifndef CV_SKIP_STAGE
         for (int it0 = tid; it0 < ITEMS; it0 += 256 * SB) {
             float v[SB][4];
@@ -150,6 +157,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
                 for (int e = 0; e < 4; ++e) {
                     _Float16 hi, lo;
                     cv_split(v[b][e], hi, lo);
+                    cv_range_acc(rmax, v[b][e]);
                     a[e] = hi; bl[e] = lo;
                 }
                 if (off[b] >= 0) {
@@ -159,6 +167,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
             }
         }
 #endif
+        cv_range_commit(range, rmax);
     }
     __syncthreads();
 
@@ -259,6 +268,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
 
 template <int CIN, int COUT, int S, int KS, int TR, int WC>
 static int conv_launch_t(const float* x, const uint4* wp, float inv_scale, float* y, int N, int H, int W, int Ho, int Wo,
+                         unsigned* range,
                          hipStream_t s) {
     constexpr int IR = (TR - 1) * S + KS, IC = 31 * S + KS, STRB = 2 * CIN + 16;
     constexpr size_t lds = (size_t)2 * IR * IC * STRB;
@@ -270,7 +280,7 @@ static int conv_launch_t(const float* x, const uint4* wp, float inv_scale, float
         attr_done = true;
     }
     dim3 grid(th_cdiv(Wo, 32), th_cdiv(Ho, TR), N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo, range);
     TH_LAUNCH_CHECK();
     return 0;
 }
@@ -289,7 +299,7 @@ static int conv_launch_t(const float* x, const uint4* wp, float inv_scale, float
 
 __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                          float inv_scale, float* __restrict__ y, int H, int W, int Ho,
-                                                         int Wo) {
+                                                         int Wo, unsigned* __restrict__ range) {
     constexpr int PLANE = C1_TR * 32 * C1_STRB;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* xhi = lds;
@@ -310,9 +320,11 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict
             const int gy = iy0 + r, gx = ix0 + px;
             rv[b] = (it < RAW && gy >= 0 && gy < H && gx >= 0 && gx < W) ? xn[((long long)c * H + gy) * W + gx] : 0.f;
         }
+        unsigned rmax = 0u;
 #pragma unroll
         for (int b = 0; b < RB; ++b)
-            if (tid + 256 * b < RAW) raw[tid + 256 * b] = rv[b];
+            if (tid + 256 * b < RAW) { raw[tid + 256 * b] = rv[b]; cv_range_acc(rmax, rv[b]); }
+        cv_range_commit(range, rmax);
     }
     if (tid < 16 * C1_KB) {
         const int c = tid / 49, rem = tid - c * 49, kh = rem / 7, kw = rem - kh * 7;
@@ -364,6 +376,7 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict
 }
 
 static int conv1_launch(const float* x, const uint4* wp, float inv_scale, float* y, int N, int H, int W, int Ho, int Wo,
+                        unsigned* range,
                         hipStream_t s) {
     constexpr size_t lds = (size_t)2 * C1_TR * 32 * C1_STRB + 3 * C1_IR * C1_IC * 4 + 16 * C1_KB * 4;
     static bool attr_done = false;
@@ -372,7 +385,7 @@ static int conv1_launch(const float* x, const uint4* wp, float inv_scale, float*
         attr_done = true;
     }
     dim3 grid(th_cdiv(Wo, 32), th_cdiv(Ho, C1_TR), N);
-    hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo);
+    hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo, range);
     TH_LAUNCH_CHECK();
     return 0;
 }
@@ -411,22 +424,22 @@ int th_maxpool3x3s2_launch(const float* x, int planes, int H, int W, float* y, h
 
 // the shapes of the ResNet18 stem (bias-free, padding KS/2)
 int th_conv2d_launch(const float* x, int N, int CIN, int H, int W, const void* packed, float inv_scale, int COUT, int KS,
-                     int stride, float* y, hipStream_t s) {
+                     int stride, float* y, hipStream_t s, unsigned int* range) {
     const int PAD = KS / 2;
     const int Ho = (H + 2 * PAD - KS) / stride + 1, Wo = (W + 2 * PAD - KS) / stride + 1;
     const uint4* wp = (const uint4*)packed;
-    if (CIN == 3 && COUT == 64 && KS == 7 && stride == 2) return conv1_launch(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
+    if (CIN == 3 && COUT == 64 && KS == 7 && stride == 2) return conv1_launch(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
     if (CIN == 64 && COUT == 64 && KS == 3 && stride == 1)
         #ifndef CV_TR64
 #define CV_TR64 4
 #endif
-        return conv_launch_t<64, 64, 1, 3, CV_TR64, 2>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
+        return conv_launch_t<64, 64, 1, 3, CV_TR64, 2>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
     if (CIN == 64 && COUT == 128 && KS == 3 && stride == 2)
-        return conv_launch_t<64, 128, 2, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
+        return conv_launch_t<64, 128, 2, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
     if (CIN == 128 && COUT == 128 && KS == 3 && stride == 1)
-        return conv_launch_t<128, 128, 1, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
+        return conv_launch_t<128, 128, 1, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
     if (CIN == 64 && COUT == 128 && KS == 1 && stride == 2)
-        return conv_launch_t<64, 128, 2, 1, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, s);
+        return conv_launch_t<64, 128, 2, 1, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
     TH_REQUIRE(false, "th_conv2d: shape not built (ResNet18 stem shapes only)");
     return 1;
 }

@@ -302,7 +302,7 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
 
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all, float* raw_c,
-                         hipStream_t s) {
+                         unsigned int* range, hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(V >= 1 && V <= 3, "fused MLP supports 1..3 reference views");
     TH_REQUIRE(f_ld == 384 || (f_ld == 272 && base.compact_ready),
@@ -311,7 +311,7 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     FusedParams p = base;
     if (cf) { p.ar0 = base.ar0c; p.rst = base.rstc; }
     p.alpha_w = heads.alpha_w; p.alpha_b = heads.alpha_b; p.rgb_w = heads.rgb_w; p.rgb_b = heads.rgb_b;
-    p.stok = stok; p.pe = (const _Float16*)pe; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all;
+    p.stok = stok; p.pe = (const _Float16*)pe; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all; p.range = range;
     static bool attr = false;
     if (!attr) {
 #define FM_ATTR(V_, F_)                                                                                       \

@@ -50,9 +50,34 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
         }                                                                                                \
     } while (0)
 
+// cycle stamp without a barrier (same accounting as FM_SYNC: wave 0 of every 16th tile)
+#define FM_STAMP()                                                                                       \
+    do {                                                                                                 \
+        if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {                                    \
+            long long now_ = clock64();                                                                  \
+            atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + dbg_i++), (unsigned long long)(now_ - dbg_t)); \
+            dbg_t = now_;                                                                                \
+        }                                                                                                \
+    } while (0)
+
 __device__ __forceinline__ void split_h(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
     lo = (_Float16)(x - (float)hi);
+}
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two values -> packed hi pair + packed lo pair: one v_cvt_pk_f16_f32 and two mixed-precision FMAs
+// (lo = fp16(x - hi), the f16 -> f32 widening of hi, the subtraction and the narrowing in ONE instruction each;
+// x - hi is exact in fp32, so this is bit-identical to split_h at 1.5 instead of 3.25 VALU instructions per value)
+__device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
+    h2v h;
+    h[0] = (_Float16)x0;
+    h[1] = (_Float16)x1;
+    hi = *reinterpret_cast<unsigned*>(&h);
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+    lo = l;
 }
 
 // ---- global -> LDS staging by LDS-DMA ------------------------------------------------------------------
@@ -68,26 +93,33 @@ typedef __attribute__((address_space(3))) void* fm_lptr;
 template <int V, int KROW, int KC, int STR>
 __device__ __forceinline__ void stage_glds(const _Float16* __restrict__ src, int coff, int pbase, int npts,
                                            char* __restrict__ hi, char* __restrict__ lo, int wave, int lane) {
-    constexpr int PLANE = 32 * V * STR;
-    constexpr int NCH = (PLANE + 1023) / 1024;
-    static_assert(2 * KC + 16 == STR || 2 * KC + 16 < STR, "row stride too small");
+    // 16-byte slots: SL per LDS row (the last one is the pad), DS of them carry data; a plane image is NS slots,
+    // filled 64 slots (1 KiB) per load.  A lane's slot index advances by 256 per round of the four waves: its
+    // (row, slot) pair is stepped incrementally (one division per call instead of one per load -- the address
+    // arithmetic, not the memory system, used to bound this loop: 45 VALU instructions per load under a vector
+    // loop counter, 8-9 k cycles per filling).
+    constexpr int SL = STR / 16, DS = (2 * KC) / 16, NS = 32 * V * SL;
+    constexpr int NCH = (NS + 63) / 64;
+    constexpr int DR = 256 / SL, DSL = 256 % SL;
+    static_assert(STR % 16 == 0 && (2 * KC) % 16 == 0 && DS < SL, "row stride must hold the data slots plus a pad slot");
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int q0 = wv * 64 + lane;
+    int row = q0 / SL, slot = q0 - row * SL;
+    const char* gbase = reinterpret_cast<const char*>(src) + 2 * coff;
 #pragma unroll 1
-    for (int ch = wave; ch < 2 * NCH; ch += 4) {
-        const int plane = ch >= NCH ? 1 : 0;
-        const int c = ch - plane * NCH;
-        const int o = c * 1024 + lane * 16;
-        if (o < PLANE) {
-            const int row = o / STR;
-            int col = o - row * STR;                 // bytes into the LDS row
-            if (col >= 2 * KC) col = 0;
+    for (int c = wv; c < NCH; c += 4) {
+        if (c * 64 + lane < NS) {
             int p = row & 31;
             const int vw = row >> 5;
-            if (p >= npts) p = npts - 1;
-            const char* g = reinterpret_cast<const char*>(src) + ((long long)(pbase + p) * V + vw) * (4 * KROW) +
-                            plane * (2 * KROW) + 2 * coff + col;
-            char* dst = (plane ? lo : hi) + c * 1024;
-            __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)dst, 16, 0, 0);   // (sc0 / nt / sc1 policy bits: no measurable effect)
+            p = p < npts ? p : npts - 1;
+            const int col = slot < DS ? slot * 16 : 0;
+            const char* g = gbase + (long long)((pbase + p) * V + vw) * (4 * KROW) + col;
+            __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)(hi + c * 1024), 16, 0, 0);   // (sc0 / nt / sc1 policy bits: no measurable effect)
+            __builtin_amdgcn_global_load_lds((fm_gptr)(g + 2 * KROW), (fm_lptr)(lo + c * 1024), 16, 0, 0);
         }
+        row += DR;
+        slot += DSL;
+        if (slot >= SL) { slot -= SL; row += 1; }
     }
 }
 
@@ -262,6 +294,74 @@ __device__ __forceinline__ void gemm_phase_z(const char* __restrict__ ahi, const
     gemm_phase_impl<RT, CT, STR, ROWSTEP, D, XPP, true>(ahi, alo, wp, KB, lane, acc);
 }
 
+// Two independent products in ONE software-pipelined loop over 16 k-blocks (K = 256):
+//   a3 (2 column tiles x 1 row tile)  += W3 * M^T      fc_3 on the 32 view-mean rows (MBUF)
+//   va (1 column tile  x V row tiles) += WA * X^T      folded view_fc (Wa F) on the 32*V rows of inter (ABUF)
+// fc_3 alone re-uses every weight fragment on ONE row tile: its 256 KB of weights per tile ask for 85 B/clk/CU
+// of L2 bandwidth and the phase took 11 k cycles for 3 k cycles of MFMA issue.  Interleaved with the (MFMA-heavy,
+// 3 row tiles per fragment) view_fc product the pair streams 6 KB of weights per 15 MFMAs per wave (50 B/clk/CU).
+template <int V>
+__device__ __forceinline__ void gemm_dual_fc3_vfa(const char* __restrict__ mhi, const char* __restrict__ mlo,
+                                                  const char* __restrict__ xhi, const char* __restrict__ xlo,
+                                                  const uint4* __restrict__ w3, const uint4* __restrict__ wa, int lane,
+                                                  f32x16 (&a3)[2][1], f32x16 (&va)[1][V]) {
+    constexpr int KB = 16, D = 4;
+    const uint4* w3l = w3 + lane;
+    const uint4* wal = wa + lane;
+    const int aoff = (lane & 31) * STR256 + (lane >> 5) * 16;
+    uint4 r3[D][2][2], ra[D][1][2];
+    h8 mh[2][1], ml[2][1], xh[2][V], xl[2][V];
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) {
+        load_wfrag<2>(w3l, j, r3[j]);
+        load_wfrag<1>(wal, j, ra[j]);
+    }
+    load_xfrag<1, STR256, 0>(mhi, mlo, aoff, 0, mh[0], ml[0]);
+    load_xfrag<V, STR256, 32 * STR256>(xhi, xlo, aoff, 0, xh[0], xl[0]);
+    FM_SB();
+    zero_acc<2, 1>(a3);
+    zero_acc<1, V>(va);
+    FM_SB();
+#pragma unroll 1
+    for (int kb = 0; kb < KB; kb += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int kw = (kb + j + D - 1 < KB) ? kb + j + D - 1 : KB - 1;
+            const int kx = (kb + j + 1 < KB) ? kb + j + 1 : KB - 1;
+            load_wfrag<2>(w3l, kw, r3[(j + D - 1) % D]);
+            load_wfrag<1>(wal, kw, ra[(j + D - 1) % D]);
+            load_xfrag<1, STR256, 0>(mhi, mlo, aoff, kx, mh[(j + 1) & 1], ml[(j + 1) & 1]);
+            load_xfrag<V, STR256, 32 * STR256>(xhi, xlo, aoff, kx, xh[(j + 1) & 1], xl[(j + 1) & 1]);
+            // term-major over the 2 + V accumulators (an accumulator recurs every 2 + V MFMAs: the 2-accumulator fc_3
+            // block alone would issue dependent MFMAs back to back)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int wp = t == 0 ? 1 : 0;                    // weight plane: lo, hi, hi
+                const bool xlo = t == 1;                           // activation plane: hi, lo, hi
+                a3[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&r3[j][0][wp]),
+                                                                  xlo ? ml[j & 1][0] : mh[j & 1][0], a3[0][0], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < V; ++r) {
+                    va[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&ra[j][0][wp]),
+                                                                      xlo ? xl[j & 1][r] : xh[j & 1][r], va[0][r], 0, 0, 0);
+                    if (r == 0)
+                        a3[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&r3[j][1][wp]),
+                                                                          xlo ? ml[j & 1][0] : mh[j & 1][0], a3[1][0], 0, 0, 0);
+                }
+            }
+            constexpr int NMEM = 6 + 2 + 2 * V, NMF = 6 + 3 * V;
+            constexpr int NPAIR = NMEM < NMF ? NMEM : NMF;
+#pragma unroll
+            for (int q = 0; q < NPAIR; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);     // one VMEM read or DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NPAIR, 0);
+            FM_SB();
+        }
+    }
+}
+
 // channel of accumulator register e (within a 32-wide column tile) for this lane
 __device__ __forceinline__ int acc_chan(int e, int lane) { return (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); }
 
@@ -283,22 +383,68 @@ __device__ __forceinline__ void finish_tile(f32x16 (&acc)[RT], const float* __re
     }
 }
 
+// The bias values a lane needs for one 32-wide column tile: 4 groups of 4 consecutive channels.  They are
+// requested as one batch BEFORE the barrier / arithmetic in front of the epilogue (the per-group loads inside
+// finish_tile used to be waited for one by one: 8-12 exposed L2 round trips per epilogue).
+struct BiasT { float4 g[4]; };
+__device__ __forceinline__ BiasT load_bias(const float* __restrict__ bias, int col0, int lane) {
+    BiasT b;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b.g[g] = *reinterpret_cast<const float4*>(bias + col0 + 8 * g + 4 * (lane >> 5));
+    return b;
+}
+// y = acc*inv_scale + bias with a preloaded bias (inv_scale is a power of two: the fused form rounds like mul + add)
+template <int RT>
+__device__ __forceinline__ void finish_tile_b(f32x16 (&acc)[RT], const BiasT& b, float inv_scale, bool relu) {
+    const f32x2 sc = {inv_scale, inv_scale}, zero = {0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x2 b01 = {b.g[g].x, b.g[g].y}, b23 = {b.g[g].z, b.g[g].w};
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            f32x2 y01 = {acc[r][4 * g], acc[r][4 * g + 1]}, y23 = {acc[r][4 * g + 2], acc[r][4 * g + 3]};
+            y01 = __builtin_elementwise_fma(y01, sc, b01);
+            y23 = __builtin_elementwise_fma(y23, sc, b23);
+            if (relu) { y01 = __builtin_elementwise_max(y01, zero); y23 = __builtin_elementwise_max(y23, zero); }
+            acc[r][4 * g] = y01[0]; acc[r][4 * g + 1] = y01[1];
+            acc[r][4 * g + 2] = y23[0]; acc[r][4 * g + 3] = y23[1];
+        }
+    }
+}
+
 // write one 32x32 output tile (this lane: row, 4 groups of 4 consecutive channels) as hi/lo halves
+// Range guard of the fp16 hi/lo split (x = hi + lo needs |x| < 65504; below 2^-14 the halves are subnormal and the
+// absolute resolution stops at 2^-25).  Every value that is split passes through store_tile_h: the |hi| halves
+// (as 15-bit integers: inf and NaN order above every finite value) are folded into a per-lane running maximum
+// with one v_and + one v_pk_max_u16 per PAIR of values, and after each activation the lane maximum is merged into
+// the launch-wide table P.range[slot] -- with an atomic only when it exceeds the value read at kernel start, i.e.
+// almost never after the first tiles.  The host reads the table per frame (th_range_read) and re-renders on the
+// fp32 MFMA path when a slot reached 6e4 (overflow / NaN) or stayed below 2^-6 (resolution).
+typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void range_acc(unsigned& rm, unsigned hi2) {
+    unsigned a = hi2 & 0x7fff7fffu;
+    us2v m = __builtin_elementwise_max(*reinterpret_cast<us2v*>(&rm), *reinterpret_cast<us2v*>(&a));
+    rm = *reinterpret_cast<unsigned*>(&m);
+}
+__device__ __forceinline__ void range_commit(unsigned* __restrict__ table, int slot, unsigned seen, unsigned& rm) {
+    const unsigned m = max(rm & 0xffffu, rm >> 16);
+    if (table != nullptr && m > seen) atomicMax(table + slot, m);
+    rm = 0u;
+}
+
 template <int STR>
 __device__ __forceinline__ void store_tile_h(const f32x16& t, int row, int col0, char* __restrict__ hi,
-                                             char* __restrict__ lo, int lane) {
+                                             char* __restrict__ lo, int lane, unsigned& rm) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         int c = col0 + 8 * g + 4 * (lane >> 5);
-        h4 a, b;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            _Float16 x, y;
-            split_h(t[4 * g + q], x, y);
-            a[q] = x; b[q] = y;
-        }
-        *reinterpret_cast<h4*>(hi + row * STR + 2 * c) = a;
-        *reinterpret_cast<h4*>(lo + row * STR + 2 * c) = b;
+        uint2 a, b;
+        split_pair(t[4 * g], t[4 * g + 1], a.x, b.x);
+        split_pair(t[4 * g + 2], t[4 * g + 3], a.y, b.y);
+        range_acc(rm, a.x);
+        range_acc(rm, a.y);
+        *reinterpret_cast<uint2*>(hi + row * STR + 2 * c) = a;
+        *reinterpret_cast<uint2*>(lo + row * STR + 2 * c) = b;
     }
     FM_SB();   // VALU temporaries must be arch VGPRs (<= 256): do not let the next tile's conversions hoist above
 }
@@ -342,6 +488,12 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         dbg_t = clock64();
     }
 
+    // range guard: launch-wide maxima as they stood when this tile started (uniform -> scalar loads)
+    unsigned rmax = 0u;
+    const unsigned seen_s = P.range ? P.range[TH_RANGE_S] : 0u, seen_p = P.range ? P.range[TH_RANGE_P] : 0u,
+                   seen_n = P.range ? P.range[TH_RANGE_N] : 0u, seen_i = P.range ? P.range[TH_RANGE_INTER] : 0u,
+                   seen_4 = P.range ? P.range[TH_RANGE_F4] : 0u;
+
     char* a256_lo = abuf + ROWS * STR256;
     char* fa_lo = abuf + ROWS * FL::SA;      // lo planes of the two f fillings
     char* fb_lo = abuf + ROWS * FL::SB;
@@ -352,12 +504,30 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     // th_api.hip).  K4 therefore hands over `stok` = that blend (fp32, [P][V][256]) and the blended 63-wide
     // positional encoding `pe` (one split-f16 row per SAMPLE: it is the same for every view); what is left of
     // fc_0 here is W_pe pe: 4 k-blocks on 32 rows instead of 16 k-blocks on 32*V rows.
-    // Issue order matters (vmcnt returns in order): pe rows and the 4 weight blocks first, then the 96 KB of
-    // stok straight into the accumulator layout -- the small GEMM runs while stok is still arriving.
+    // The 96 KB of stok of a tile are one contiguous block of global memory ([sample][view][256] fp32): every
+    // (sample, view) row is copied by ONE LDS-DMA load (1 KiB, fully coalesced) into ABUF rows of STOK_STR bytes
+    // (an odd number of 16-byte slots) and read back in the accumulator layout with conflict-free ds_read_b128.
+    // (Fetching that layout straight from global memory took 96 loads per lane of 32 B segments from 32 different
+    // rows each: the texture path, not the memory latency, bounded the phase at 9 k cycles.)
+    // The view-direction rows of the tile (used by the RGB branch, 27 of 32 columns) are requested here too: two
+    // dependent HBM round trips that used to sit in front of the fc_3 weight stream.
+    float vdv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int i = tid + 256 * q, row = i >> 5, c = i & 31;
+        float x = 0.f;
+        if (P.rgb_all != 2 && c < 27 && row < npts) {
+            const long long vr = P.vd_sel ? (long long)(P.vd_sel[pbase + row] / P.vd_div) : (long long)(pbase + row);
+            x = P.vd[vr * 27 + c];
+        }
+        vdv[q] = x;
+    }
     f32x16 acc2[2][V];
     {
-        char* pe_hi = abuf;
-        char* pe_lo = abuf + 32 * STR64;
+        constexpr int STOK_STR = 1040;
+        static_assert(32 * V * STOK_STR <= ABUF_BYTES, "stok rows must fit the operand buffer");
+        char* pe_hi = mbuf;
+        char* pe_lo = mbuf + 32 * STR64;
         // pe: 32 rows x (64 hi | 64 lo halves) = 8 KiB: one 16-byte piece per thread and plane
         const int prow = tid >> 3, pc = tid & 7;
         const int psrc = min(prow, npts - 1);
@@ -367,16 +537,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         const uint4* wl = wslice(P.fc_0pe, wave, 2, 0) + lane;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) load_wfrag<2>(wl, kb, wq[kb]);
-        float4 st[2][V][4];
-        const int srow = min(myrow, npts - 1);
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < V; ++r)
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    st[c][r][g] = *reinterpret_cast<const float4*>(P.stok + ((long long)(pbase + srow) * V + r) * 256 +
-                                                                   wave * 64 + c * 32 + 8 * g + 4 * (lane >> 5));
+        const BiasT b0[2] = {load_bias(P.fc_0pe.bias, wave * 64, lane), load_bias(P.fc_0pe.bias, wave * 64 + 32, lane)};
+        {
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            const char* sg = reinterpret_cast<const char*>(P.stok) + lane * 16;
+#pragma unroll 4
+            for (int i = wv; i < 32 * V; i += 4) {                  // LDS row i = view * 32 + sample (wave-uniform)
+                const int sp = min(i & 31, npts - 1), vw = i >> 5;
+                const char* g = sg + ((long long)(pbase + sp) * V + vw) * 1024;
+                __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)(abuf + i * STOK_STR), 16, 0, 0);
+            }
+        }
         FM_SB();
         *reinterpret_cast<uint4*>(pe_hi + prow * STR64 + 16 * pc) = pe_h;
         *reinterpret_cast<uint4*>(pe_lo + prow * STR64 + 16 * pc) = pe_l;
@@ -390,10 +561,19 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             load_xfrag<1, STR64, 0>(pe_hi, pe_lo, aoff, kb, xh, xl);
             mfma_kblock<1, 2>(wq[kb], xh, xl, a1);
         }
-        FM_SYNC();                                   // every wave has read the pe rows: ABUF may take s
+        float4 st[2][V][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < V; ++r)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    st[c][r][g] = *reinterpret_cast<const float4*>(abuf + (r * 32 + myrow) * STOK_STR +
+                                                                   4 * (wave * 64 + c * 32 + 8 * g + 4 * (lane >> 5)));
+        FM_SYNC();                                   // every wave has its stok values in registers: ABUF may take s
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            finish_tile<1>(a1[c], P.fc_0pe.bias, wave * 64 + c * 32, P.fc_0pe.inv_scale, false, lane);
+            finish_tile_b<1>(a1[c], b0[c], P.fc_0pe.inv_scale, false);
 #pragma unroll
             for (int r = 0; r < V; ++r) {
 #pragma unroll
@@ -403,9 +583,10 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
                     acc2[c][r][4 * g + 2] = fmaxf(a1[c][0][4 * g + 2] + st[c][r][g].z, 0.f);
                     acc2[c][r][4 * g + 3] = fmaxf(a1[c][0][4 * g + 3] + st[c][r][g].w, 0.f);
                 }
-                store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+                store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
             }
         }
+        range_commit(P.range, TH_RANGE_S, seen_s, rmax);
     }
     FM_SYNC();
     // kv layers: column tile 0 = key tile `wave` (cols wave*32..), tiles 1,2 = value cols 128 + wave*64 ..
@@ -414,9 +595,17 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     {
         f32x16 acc3[3][V];
         gemm_phase_z<V, 3, STR256>(abuf, a256_lo, wslice(P.kv1, wave, 3, 0), P.kv1.KB, lane, acc3);
-        finish_tile<V>(acc3[0], P.kv1.bias, wave * 32, P.kv1.inv_scale, false, lane);
-        finish_tile<V>(acc3[1], P.kv1.bias, 128 + wave * 64, P.kv1.inv_scale, false, lane);
-        finish_tile<V>(acc3[2], P.kv1.bias, 128 + wave * 64 + 32, P.kv1.inv_scale, false, lane);
+#ifdef FM_STAMPS
+        FM_STAMP();
+#endif
+        {
+            const BiasT bk = load_bias(P.kv1.bias, wave * 32, lane), bv0 = load_bias(P.kv1.bias, 128 + wave * 64, lane),
+                        bv1 = load_bias(P.kv1.bias, 128 + wave * 64 + 32, lane);
+            FM_SB();
+            finish_tile_b<V>(acc3[0], bk, P.kv1.inv_scale, false);
+            finish_tile_b<V>(acc3[1], bv0, P.kv1.inv_scale, false);
+            finish_tile_b<V>(acc3[2], bv1, P.kv1.inv_scale, false);
+        }
 #pragma unroll
         for (int r = 0; r < V; ++r) {
             store_tile_f(acc3[0][r], r * 32 + myrow, wave * 32, ksb, lane);
@@ -428,8 +617,15 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
     stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
+#ifdef FM_STAMPS
+    FM_STAMP();
+#endif
     FM_SYNC();
     gemm_phase_z<V, 2, FL::SA>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2);
+#ifdef FM_STAMPS
+    FM_STAMP();
+#endif
+    const BiasT bp[2] = {load_bias(P.ar0.bias, wave * 64, lane), load_bias(P.ar0.bias, wave * 64 + 32, lane)};
     FM_SYNC();
     if constexpr (FL::NB > 0) {
         stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
@@ -439,19 +635,25 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        finish_tile<V>(acc2[c], P.ar0.bias, wave * 64 + c * 32, P.ar0.inv_scale, true, lane);
+        finish_tile_b<V>(acc2[c], bp[c], P.ar0.inv_scale, true);
 #pragma unroll
         for (int r = 0; r < V; ++r)
-            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
     }
+    range_commit(P.range, TH_RANGE_P, seen_p, rmax);
     FM_SYNC();
     f32x16 vp[2][V];
     {
         f32x16 acc3[3][V];
         gemm_phase_z<V, 3, STR256>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane, acc3);
-        finish_tile<V>(acc3[0], P.kv0.bias, wave * 32, P.kv0.inv_scale, false, lane);
-        finish_tile<V>(acc3[1], P.kv0.bias, 128 + wave * 64, P.kv0.inv_scale, false, lane);
-        finish_tile<V>(acc3[2], P.kv0.bias, 128 + wave * 64 + 32, P.kv0.inv_scale, false, lane);
+        {
+            const BiasT bk = load_bias(P.kv0.bias, wave * 32, lane), bv0 = load_bias(P.kv0.bias, 128 + wave * 64, lane),
+                        bv1 = load_bias(P.kv0.bias, 128 + wave * 64 + 32, lane);
+            FM_SB();
+            finish_tile_b<V>(acc3[0], bk, P.kv0.inv_scale, false);
+            finish_tile_b<V>(acc3[1], bv0, P.kv0.inv_scale, false);
+            finish_tile_b<V>(acc3[2], bv1, P.kv0.inv_scale, false);
+        }
         FM_SYNC();                                                  // every wave is done reading p from ABUF
         float* kpb = reinterpret_cast<float*>(abuf);                // [ROWS][KSTR]
 #pragma unroll
@@ -466,6 +668,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
     // ================= cross-view attention (cross_transformer.py:128-149) =================
     {
         const float* kpb = reinterpret_cast<const float*>(abuf);
+        const BiasT bn[2] = {load_bias(P.fc_1.bias, wave * 64, lane), load_bias(P.fc_1.bias, wave * 64 + 32, lane)};
         // A[j][i] = kp_j . ks_i / sqrt(128).  Thread (p = tid >> 3, c8 = tid & 7) owns float4 columns c8, c8 + 8,
         // c8 + 16, c8 + 24 of sample p (8 lanes read 128 contiguous bytes of a key row): it loads the V pixel-branch
         // and the V token-branch keys once, forms all V*V partial products, and the 8 partials of a sample are
@@ -532,29 +735,39 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
                 f32x16 n;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float4 b4 = *reinterpret_cast<const float4*>(P.fc_1.bias + wave * 64 + c * 32 + 8 * g + 4 * (lane >> 5));
-                    float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                    const float4 b4 = bn[c].g[g];
+                    const f32x2 bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        int e = 4 * g + q;
-                        float t = vp[c][0][e] * A[0][i];
+                    for (int h = 0; h < 2; ++h) {         // packed fp32 FMAs: two channels per instruction
+                        const int e = 4 * g + 2 * h;
+                        f32x2 t = {vs[c][i][e], vs[c][i][e + 1]};
+                        t = t + bb[h];
 #pragma unroll
-                        for (int j = 1; j < V; ++j) t = t + vp[c][j][e] * A[j][i];
-                        n[e] = fmaxf((vs[c][i][e] + t) + bb[q], 0.f);
+                        for (int j = 0; j < V; ++j) {
+                            const f32x2 v2 = {vp[c][j][e], vp[c][j][e + 1]}, a2 = {A[j][i], A[j][i]};
+                            t = __builtin_elementwise_fma(v2, a2, t);
+                        }
+                        n[e] = fmaxf(t[0], 0.f);
+                        n[e + 1] = fmaxf(t[1], 0.f);
                     }
                 }
-                store_tile_h<STR256>(n, i * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+                store_tile_h<STR256>(n, i * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
             }
+        range_commit(P.range, TH_RANGE_N, seen_n, rmax);
         FM_SYNC();
     }
 
     // ================= fc_2 (fc_1 is folded into the value projections) =================
     gemm_phase_z<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_2, wave, 2, 0), P.fc_2.KB, lane, acc2);
+#ifdef FM_STAMPS
+    FM_STAMP();
+#endif
+    const BiasT bi[2] = {load_bias(P.fc_2.bias, wave * 64, lane), load_bias(P.fc_2.bias, wave * 64 + 32, lane)};
     FM_SYNC();
     // inter = relu(.) -> ABUF (operand of feature_fc); its view mean -> MBUF (operand of fc_3)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-        finish_tile<V>(acc2[c], P.fc_2.bias, wave * 64 + c * 32, P.fc_2.inv_scale, true, lane);
+        finish_tile_b<V>(acc2[c], bi[c], P.fc_2.inv_scale, true);
         f32x16 m;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -563,42 +776,60 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             for (int r = 1; r < V; ++r) a = a + acc2[c][r][e];
             m[e] = a / (float)V;
         }
-        store_tile_h<STR256>(m, myrow, wave * 64 + c * 32, mbuf, mbuf + 32 * STR256, lane);
+        store_tile_h<STR256>(m, myrow, wave * 64 + c * 32, mbuf, mbuf + 32 * STR256, lane, rmax);
 #pragma unroll
         for (int r = 0; r < V; ++r)
-            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane);
+            store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
     }
+    range_commit(P.range, TH_RANGE_INTER, seen_i, rmax);
     FM_SYNC();
 
     // ================= sigma head: relu(fc_3 m) . alpha_w + b =================
-    // view directions of the tile (27 of 32 columns used; operand of the folded view_fc): requested here so the
-    // loads fly under the fc_3 GEMM, parked in MBUF once every wave is done reading the fc_3 operand
-    float vdv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        int i = tid + 256 * q, row = i >> 5, c = i & 31;
-        float x = 0.f;
-        if (P.rgb_all != 2 && c < 27 && row < npts) {
-            const long long vr = P.vd_sel ? (long long)(P.vd_sel[pbase + row] / P.vd_div) : (long long)(pbase + row);
-            x = P.vd[vr * 27 + c];
-        }
-        vdv[q] = x;
-    }
+    // (the view-direction values vdv were requested at the top of the tile; they are parked in MBUF once every wave is
+    // done reading the fc_3 operand)
     char* vd_hi = mbuf + MBUF_VD_OFF;
     char* vd_lo = vd_hi + 32 * STRVD;
+    // acc2[0] collects the three K ranges of the folded view_fc (this wave's 32 of its 128 outputs), acc2[1] is
+    // rgb_res_1: the pass over f multiplies the stacked [Wa R0 ; R1] image as two column tiles.
+    f32x16 (&vf)[1][V] = *reinterpret_cast<f32x16 (*)[1][V]>(&acc2[0]);
     {
         f32x16 a1[2][1];
-        gemm_phase_z<1, 2, STR256, 32 * STR256, 6>(mbuf, mbuf + 32 * STR256, wslice(P.fc_3, wave, 2, 0), P.fc_3.KB, lane, a1);
+        // head rows / biases of this lane's channels, requested ahead of the GEMM
+        float4 aw[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                aw[c][g] = *reinterpret_cast<const float4*>(P.alpha_w + wave * 64 + c * 32 + 8 * g + 4 * (lane >> 5));
+        const BiasT b3[2] = {load_bias(P.fc_3.bias, wave * 64, lane), load_bias(P.fc_3.bias, wave * 64 + 32, lane)};
+        // the view_fc product on inter does not depend on sigma: it shares the loop with fc_3 (see gemm_dual_fc3_vfa)
+        // unless no sample can need colour (sigma-only consumers)
+#ifdef FM_STAMPS
+        FM_STAMP();
+#endif
+        if (P.rgb_all != 2)
+            gemm_dual_fc3_vfa<V>(mbuf, mbuf + 32 * STR256, abuf, a256_lo, wslice(P.fc_3, wave, 2, 0), wslice(P.vfA, wave, 1, 0),
+                                 lane, a1, vf);
+        else
+            gemm_phase_z<1, 2, STR256, 32 * STR256, 6>(mbuf, mbuf + 32 * STR256, wslice(P.fc_3, wave, 2, 0), P.fc_3.KB, lane, a1);
+#ifdef FM_STAMPS
+        FM_STAMP();
+#endif
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            finish_tile<1>(a1[c], P.fc_3.bias, wave * 64 + c * 32, P.fc_3.inv_scale, true, lane);
+            finish_tile_b<1>(a1[c], b3[c], P.fc_3.inv_scale, true);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s = fmaf(a1[c][0][e], P.alpha_w[wave * 64 + c * 32 + acc_chan(e, lane)], s);
+            for (int g = 0; g < 4; ++g) {
+                s = fmaf(a1[c][0][4 * g + 0], aw[c][g].x, s);
+                s = fmaf(a1[c][0][4 * g + 1], aw[c][g].y, s);
+                s = fmaf(a1[c][0][4 * g + 2], aw[c][g].z, s);
+                s = fmaf(a1[c][0][4 * g + 3], aw[c][g].w, s);
+            }
         }
         s += __shfl_xor(s, 32);
         if (lane < 32) part[(wave * 32 + lane) * 4] = s;
-        FM_SYNC();
+        FM_SYNC();                                  // every wave is done reading the means (MBUF) and inter (ABUF)
         if (tid < 32)
             sig[tid] = part[tid * 4] + part[(32 + tid) * 4] + part[(64 + tid) * 4] + part[(96 + tid) * 4] + P.alpha_b[0];
         if (tid == 0) *flag = 0;
@@ -621,27 +852,45 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         // ================= RGB branch (cross_transformer.py:330-353) =================
         // view_fc is folded over feature_fc / rgb_res_0 (k_mlp_fused_host.hip):
         //   t = relu((Wa F) inter + Wd viewdir + (Wa R0) f + b') ; u = t + rgb_res_1(f) ; mean over views ; fc_4 ; rgb_fc
-        // acc2[0] collects the three K ranges of the folded view_fc (this wave's 32 of its 128 outputs), acc2[1] is
-        // rgb_res_1: the pass over f multiplies the stacked [Wa R0 ; R1] image as two column tiles.
-        f32x16 (&vf)[1][V] = *reinterpret_cast<f32x16 (*)[1][V]>(&acc2[0]);
-        gemm_phase_z<V, 1, STR256, 32 * STR256, 6>(abuf, a256_lo, wslice(P.vfA, wave, 1, 0), 16, lane, vf);
-        gemm_phase<V, 1, STRVD, 0>(vd_hi, vd_lo, wslice(P.vfD, wave, 1, 0), 2, lane, vf);
-        FM_SYNC();                                  // every wave is done reading inter: ABUF may take f again
+        // ABUF has been free since the barrier behind the fc_3 / view_fc loop: f is requested first, the two
+        // view-direction k-blocks (operand in MBUF) multiply while it arrives.
         stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
+        gemm_phase<V, 1, STRVD, 0>(vd_hi, vd_lo, wslice(P.vfD, wave, 1, 0), 2, lane, vf);
 #pragma unroll
         for (int r = 0; r < V; ++r)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc2[1][r][e] = 0.f;
         FM_SYNC();
         gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.rst, wave, 2, 0), FL::NA, lane, acc2);
+#ifdef FM_STAMPS
+        FM_STAMP();
+#endif
         if constexpr (FL::NB > 0) {
             FM_SYNC();
             stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
             FM_SYNC();
             gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.rst, wave, 2, FL::NA), FL::NB, lane, acc2);
         }
-        finish_tile<V>(acc2[0], P.rst.bias, wave * 32, P.rst.inv_scale, true, lane);
-        finish_tile<V>(acc2[1], P.rst.bias, 128 + wave * 32, P.rst.inv_scale2, false, lane);
+        // fc_4 weights (this wave's 8 k-blocks) and the rgb_fc rows of its channels: requested before the epilogue
+        uint4 w4[8][1][2];
+        {
+            const uint4* wl4 = wslice(P.fc_4, wave, 1, 0) + lane;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) load_wfrag<1>(wl4, kb, w4[kb]);
+        }
+        float4 rw[3][4];
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                rw[o][g] = *reinterpret_cast<const float4*>(P.rgb_w + o * 128 + wave * 32 + 8 * g + 4 * (lane >> 5));
+        const BiasT b4 = load_bias(P.fc_4.bias, wave * 32, lane);
+        {
+            const BiasT bt = load_bias(P.rst.bias, wave * 32, lane), br = load_bias(P.rst.bias, 128 + wave * 32, lane);
+            FM_SB();
+            finish_tile_b<V>(acc2[0], bt, P.rst.inv_scale, true);
+            finish_tile_b<V>(acc2[1], br, P.rst.inv_scale2, false);
+        }
         char* f4_hi = mbuf + MBUF_FC4_OFF;
         char* f4_lo = f4_hi + 32 * STR128;
         {
@@ -653,19 +902,32 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
                 for (int r = 1; r < V; ++r) a = a + (acc2[0][r][e] + acc2[1][r][e]);
                 m[e] = a / (float)V;
             }
-            store_tile_h<STR128>(m, myrow, wave * 32, f4_hi, f4_lo, lane);
+            store_tile_h<STR128>(m, myrow, wave * 32, f4_hi, f4_lo, lane, rmax);
+            range_commit(P.range, TH_RANGE_F4, seen_4, rmax);
         }
         FM_SYNC();
         f32x16 a4[1][1];
-        gemm_phase_z<1, 1, STR128, 32 * STR128, 8>(f4_hi, f4_lo, wslice(P.fc_4, wave, 1, 0), P.fc_4.KB, lane, a4);
-        finish_tile<1>(a4[0], P.fc_4.bias, wave * 32, P.fc_4.inv_scale, true, lane);
+        zero_acc<1, 1>(a4);
+        {
+            const int aoff4 = (lane & 31) * STR128 + (lane >> 5) * 16;
+#pragma unroll
+            for (int kb = 0; kb < 8; ++kb) {
+                h8 xh4[1], xl4[1];
+                load_xfrag<1, STR128, 0>(f4_hi, f4_lo, aoff4, kb, xh4, xl4);
+                mfma_kblock<1, 1>(w4[kb], xh4, xl4, a4);
+            }
+        }
+        finish_tile_b<1>(a4[0], b4, P.fc_4.inv_scale, true);
         float s3[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            int ch = wave * 32 + acc_chan(e, lane);
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int o = 0; o < 3; ++o) s3[o] = fmaf(a4[0][0][e], P.rgb_w[o * 128 + ch], s3[o]);
-        }
+            for (int o = 0; o < 3; ++o) {
+                s3[o] = fmaf(a4[0][0][4 * g + 0], rw[o][g].x, s3[o]);
+                s3[o] = fmaf(a4[0][0][4 * g + 1], rw[o][g].y, s3[o]);
+                s3[o] = fmaf(a4[0][0][4 * g + 2], rw[o][g].z, s3[o]);
+                s3[o] = fmaf(a4[0][0][4 * g + 3], rw[o][g].w, s3[o]);
+            }
 #pragma unroll
         for (int o = 0; o < 3; ++o) s3[o] += __shfl_xor(s3[o], 32);
         if (lane < 32) {

@@ -20,8 +20,21 @@ __device__ __forceinline__ void pg_split(float x, _Float16& hi, _Float16& lo) {
 }
 
 // SPLIT: rows are written as ldo fp16 hi halves followed by ldo fp16 lo halves (TH_ROWS_SPLIT) instead of ldo floats
+// range guard of the split rows (see store_tile_h in k_mlp_fused_kernel.h): running maximum of the |hi| halves as
+// 15-bit integers (inf / NaN order above every finite value), one v_and + v_pk_max_u16 per pair of values
+typedef unsigned short pg_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pg_range_acc(unsigned& rm, unsigned hi2) {
+    unsigned a = hi2 & 0x7fff7fffu;
+    pg_us2 m = __builtin_elementwise_max(*reinterpret_cast<pg_us2*>(&rm), *reinterpret_cast<pg_us2*>(&a));
+    rm = *reinterpret_cast<unsigned*>(&m);
+}
+__device__ __forceinline__ void pg_range_commit(unsigned* __restrict__ table, unsigned rm) {
+    const unsigned m = max(rm & 0xffffu, rm >> 16);
+    if (table != nullptr && m > table[TH_RANGE_F]) atomicMax(table + TH_RANGE_F, m);
+}
+
 template <bool SPLIT>
-__device__ __forceinline__ void pg_store4(float* __restrict__ orow, int ldo, int c4, float4 r) {
+__device__ __forceinline__ void pg_store4(float* __restrict__ orow, int ldo, int c4, float4 r, unsigned& rm) {
     if (!SPLIT) reinterpret_cast<float4*>(orow)[c4] = r;
     else {
         _Float16* oh = reinterpret_cast<_Float16*>(orow);
@@ -31,6 +44,8 @@ __device__ __forceinline__ void pg_store4(float* __restrict__ orow, int ldo, int
         pg_split(r.y, x, y); hv[1] = x; lv[1] = y;
         pg_split(r.z, x, y); hv[2] = x; lv[2] = y;
         pg_split(r.w, x, y); hv[3] = x; lv[3] = y;
+        pg_range_acc(rm, reinterpret_cast<const unsigned*>(&hv)[0]);
+        pg_range_acc(rm, reinterpret_cast<const unsigned*>(&hv)[1]);
 #ifndef PG_EXP_NOSTORE      // timing experiments only
         *reinterpret_cast<pg_h4*>(oh + 4 * c4) = hv;
 #ifndef PG_EXP_NOLO
@@ -72,8 +87,9 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
                                                         const int32_t* __restrict__ sel, int P,
                                                         const float* __restrict__ cams,
                                                         const float* __restrict__ scale, float* __restrict__ out,
-                                                        int ldo) {
+                                                        int ldo, unsigned* __restrict__ range) {
     const int lane = threadIdx.x & 63;
+    unsigned rm = 0u;
     // XCD-aware remap (speed only): workgroup b runs on XCD b % 8, each XCD has its own L2: give every XCD a
     // CONTIGUOUS range of groups: logical block = (b % 8) * ceil(nb / 8) + b / 8 (bijective incl. ragged tails
     // via the bounds check below).
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
                                  reinterpret_cast<const float4*>(m + (long long)i01 * C)[c4],
                                  reinterpret_cast<const float4*>(m + (long long)i10 * C)[c4],
                                  reinterpret_cast<const float4*>(m + (long long)i11 * C)[c4], w00, w01, w10, w11);
-                pg_store4<SPLIT>(out + ((long long)(p0 + r0 + j) * V + v) * ldo, ldo, c4, r);
+                pg_store4<SPLIT>(out + ((long long)(p0 + r0 + j) * V + v) * ldo, ldo, c4, r, rm);
             }
         }
 #pragma unroll
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
             if (r0 + j >= nrow) break;
             float* orow = out + ((long long)(p0 + r0 + j) * V + v) * ldo;
             if (lane < C4)
-                pg_store4<SPLIT>(orow, ldo, lane, pg_blend(q[j][0], q[j][1], q[j][2], q[j][3], w[j][0], w[j][1], w[j][2], w[j][3]));
+                pg_store4<SPLIT>(orow, ldo, lane, pg_blend(q[j][0], q[j][1], q[j][2], q[j][3], w[j][0], w[j][1], w[j][2], w[j][3]), rm);
             if (!(C4 <= 65 && L4 <= 68)) {
                 // wide maps (full 384-channel map): remaining columns row by row
                 const int i = r0 + j;
@@ -156,16 +172,17 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
                                      reinterpret_cast<const float4*>(m + (long long)i10 * C)[c4],
                                      reinterpret_cast<const float4*>(m + (long long)i11 * C)[c4], w[j][0], w[j][1], w[j][2],
                                      w[j][3]);
-                    pg_store4<SPLIT>(orow, ldo, c4, r);
+                    pg_store4<SPLIT>(orow, ldo, c4, r, rm);
                 }
             }
         }
     }
+    if (SPLIT) pg_range_commit(range, rm);
 }
 
 int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world, const ThPointSrc* ps,
                         const int32_t* sel, int P, const float* cams, const float* scale, float* out, int ldo,
-                        int fmt, hipStream_t s) {
+                        int fmt, hipStream_t s, unsigned int* range) {
     if (P <= 0) return 0;
     TH_REQUIRE((C & 3) == 0 && (ldo & 3) == 0 && ldo >= C, "channel count / row stride must be multiples of 4, ldo >= C");
     ThPointSrc src = ps ? *ps : ThPointSrc{};
@@ -173,10 +190,10 @@ int th_pixgather_launch(const float* map, int V, int C, int H, int W, const floa
     const int nblk = 8 * th_cdiv(th_cdiv(groups, 4), 8);     // multiple of 8 so the XCD remap is onto
     if (fmt == TH_ROWS_SPLIT)
         hipLaunchKernelGGL(pixgather_kernel<true>, dim3(nblk), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel, P,
-                           cams, scale, out, ldo);
+                           cams, scale, out, ldo, range);
     else
         hipLaunchKernelGGL(pixgather_kernel<false>, dim3(nblk), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel, P,
-                           cams, scale, out, ldo);
+                           cams, scale, out, ldo, nullptr);
     TH_LAUNCH_CHECK();
     return 0;
 }
@@ -187,8 +204,10 @@ int th_pixgather_launch(const float* map, int V, int C, int H, int W, const floa
 template <bool SPLIT>
 __global__ __launch_bounds__(256) void gather_chan_major_kernel(const float* __restrict__ pf, int V, int C,
                                                                 long long Pall, const int32_t* __restrict__ sel,
-                                                                int P, float* __restrict__ out) {
+                                                                int P, float* __restrict__ out,
+                                                                unsigned* __restrict__ range) {
     __shared__ float tile[32][33];
+    unsigned rm = 0u;
     int v = blockIdx.z;
     int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -209,19 +228,21 @@ __global__ __launch_bounds__(256) void gather_chan_major_kernel(const float* __r
                 pg_split(tile[tx][r], x, y);
                 oh[c] = x;
                 oh[C + c] = y;
+                pg_range_acc(rm, (unsigned)__builtin_bit_cast(unsigned short, x));
             }
         }
     }
+    if (SPLIT) pg_range_commit(range, rm);
 }
 int th_gather_chan_major_launch(const float* pf, int V, int C, long long Pall, const int32_t* sel, int P, float* out,
-                                int fmt, hipStream_t s) {
+                                int fmt, hipStream_t s, unsigned int* range) {
     if (P <= 0) return 0;
     if (fmt == TH_ROWS_SPLIT)
         hipLaunchKernelGGL(gather_chan_major_kernel<true>, dim3(th_cdiv(P, 32), th_cdiv(C, 32), V), dim3(256), 0, s, pf, V,
-                           C, Pall, sel, P, out);
+                           C, Pall, sel, P, out, range);
     else
         hipLaunchKernelGGL(gather_chan_major_kernel<false>, dim3(th_cdiv(P, 32), th_cdiv(C, 32), V), dim3(256), 0, s, pf, V,
-                           C, Pall, sel, P, out);
+                           C, Pall, sel, P, out, nullptr);
     TH_LAUNCH_CHECK();
     return 0;
 }

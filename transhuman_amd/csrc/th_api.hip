@@ -60,6 +60,11 @@ int th_ctx_create(int device, th_ctx** out) {
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
     TH_HIP(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(int32_t), hipHostMallocDefault));
+    TH_HIP(hipMalloc((void**)&c->range_dev, TH_RANGE_SLOTS * sizeof(unsigned int)));
+    TH_HIP(hipMemset(c->range_dev, 0, TH_RANGE_SLOTS * sizeof(unsigned int)));
+    TH_HIP(hipHostMalloc((void**)&c->range_host, th_ctx::kRangeSnaps * TH_RANGE_SLOTS * sizeof(unsigned int),
+                         hipHostMallocDefault));
+    memset(c->range_host, 0, th_ctx::kRangeSnaps * TH_RANGE_SLOTS * sizeof(unsigned int));
     *out = c;
     return 0;
 }
@@ -70,6 +75,10 @@ void th_ctx_destroy(th_ctx* c) {
     if (c->vit_store) (void)hipFree(c->vit_store);
     if (c->fused_store) (void)hipFree(c->fused_store);
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
+    if (c->range_dev) (void)hipFree(c->range_dev);
+    if (c->range_host) (void)hipHostFree(c->range_host);
+    for (auto& e : c->range_ev)
+        if (e) (void)hipEventDestroy(e);
     for (auto& t : c->prepass)
         if (t.ev) (void)hipEventDestroy(t.ev);
     delete[] c->vit.blocks;
@@ -216,6 +225,30 @@ int th_set_mlp_weights(th_ctx* c, const th_mlp_weights* w, th_stream stream) {
     c->fused_ready = true;
     return 0;
 }
+
+int th_range_snapshot(th_ctx* c, th_stream stream) {
+    TH_REQUIRE(c, "null ctx");
+    hipStream_t s = (hipStream_t)stream;
+    const int slot = c->range_rr;
+    c->range_rr = (c->range_rr + 1) % th_ctx::kRangeSnaps;
+    if (!c->range_ev[slot]) TH_HIP(hipEventCreateWithFlags(&c->range_ev[slot], hipEventDisableTiming));
+    TH_HIP(hipMemcpyAsync(c->range_host + slot * TH_RANGE_SLOTS, c->range_dev, TH_RANGE_SLOTS * sizeof(unsigned int),
+                          hipMemcpyDeviceToHost, s));
+    TH_HIP(hipMemsetAsync(c->range_dev, 0, TH_RANGE_SLOTS * sizeof(unsigned int), s));
+    TH_HIP(hipEventRecord(c->range_ev[slot], s));
+    c->range_last = slot;
+    return slot;
+}
+
+int th_range_read(th_ctx* c, int slot, uint32_t* out) {
+    TH_REQUIRE(c && out, "null argument");
+    TH_REQUIRE(slot >= 0 && slot < th_ctx::kRangeSnaps && c->range_ev[slot], "no such range snapshot");
+    TH_HIP(hipEventSynchronize(c->range_ev[slot]));
+    memcpy(out, c->range_host + slot * TH_RANGE_SLOTS, TH_RANGE_SLOTS * sizeof(unsigned int));
+    return 0;
+}
+
+int th_range_last_slot(th_ctx* c) { return c ? c->range_last : -1; }
 
 int th_set_mlp_mode(th_ctx* c, int mode) {
     TH_REQUIRE(c && (mode == 0 || mode == 1), "mode must be 0 (layer-by-layer fp32 MFMA) or 1 (fused fp16-split MFMA)");
@@ -377,7 +410,7 @@ int th_conv2d(th_ctx* c, const float* x, int N, int cin, int H, int W, const voi
               int stride, float* y, th_stream stream) {
     TH_REQUIRE(c && x && packed && y, "null argument");
     TH_REQUIRE(N > 0 && H > 0 && W > 0, "empty tensor");
-    return th_conv2d_launch(x, N, cin, H, W, packed, inv_scale, cout, ks, stride, y, (hipStream_t)stream);
+    return th_conv2d_launch(x, N, cin, H, W, packed, inv_scale, cout, ks, stride, y, (hipStream_t)stream, c->range_dev);
 }
 
 int th_maxpool3x3s2(th_ctx* c, const float* x, int planes, int H, int W, float* y, th_stream stream) {
@@ -525,7 +558,7 @@ static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, 
     TH_REQUIRE(c->mlp.ready, "MLP weights not set (th_set_mlp_weights)");
     if (mlp_is_fused(c, V))
         return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.pe, cb.f, f_ld, vd_table, vd_sel, vd_div, rgb_all,
-                                    cb.raw_c, s);
+                                    cb.raw_c, c->range_dev, s);
     const float* vd = vd_table;
     if (vd_sel != nullptr || vd_table != cb.vdc) {
         TH_TRY(th_gather_rows_launch(vd_table, 27, vd_sel, vd_div, m, cb.vdc, s));
@@ -577,14 +610,14 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
         const int fmt = mlp_row_format(c, V);
         TH_TRY(th_dparf_launch(pts, nullptr, nullptr, nullptr, sel, m, centres, rot, table, V, nc, 0.5f, cb.h, cb.pe,
                                dparf_row_format(c, V), nullptr, s));
-        if (idx) TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, fmt, s));
-        else TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, fmt, s));
+        if (idx) TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, fmt, s, c->range_dev));
+        else TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, fmt, s, c->range_dev));
         if (idx) TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir, sel, 1, 0, s));
         else TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir + 27LL * o, nullptr, 1, 1, s));
         if (idx) TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, 0, raw_out, s));
         else TH_TRY(th_scatter_raw_launch(cb.raw_c, nullptr, m, 1, raw_out + 4LL * o, s));
     }
-    return 0;
+    return th_range_snapshot(c, stream) < 0 ? -1 : 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -697,7 +730,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         {
             ProfScope ps2(pf, TH_PROF_GATHER, s);
             TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, sel, m, f->cams,
-                                       f->scale_xy, cb.f, f_ld, fmt, s));
+                                       f->scale_xy, cb.f, f_ld, fmt, s, c->range_dev));
         }
         {
             ProfScope ps3(pf, TH_PROF_MLP, s);
@@ -746,7 +779,11 @@ int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* r
     }
     TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, stats_host, s, slot >= 0 ? 2 : 0, slot >= 0 ? slot : 0));
     ProfScope sc(prof_of(c), TH_PROF_COMPOSITE, s);
-    return th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, mask, s);
+    TH_TRY(th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, mask, s));
+    const int snap = th_range_snapshot(c, stream);
+    TH_REQUIRE(snap >= 0, "range snapshot failed");
+    if (stats_host) stats_host[2] = snap;
+    return 0;
 }
 
 int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, th_stream stream) {
@@ -817,6 +854,9 @@ int th_eval_sigma_grid(th_ctx* c, const th_frame* f, const float* pts, int P, fl
     hipLaunchKernelGGL(extract_sigma_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, (const float4*)raw, mask, (long long)P,
                        sigma_out);
     TH_LAUNCH_CHECK();
+    const int snap = th_range_snapshot(c, stream);
+    TH_REQUIRE(snap >= 0, "range snapshot failed");
+    if (stats_host) stats_host[2] = snap;
     return 0;
 }
 

@@ -213,8 +213,11 @@ struct FusedParams {
     float* raw_c;       // [P][4]
     int P;
     int rgb_all;        // 0: RGB where sigma > 0, 1: everywhere, 2: nowhere (sigma-only consumers)
+    unsigned int* range;   // [TH_RANGE_SLOTS] launch-wide max |hi half| (fp16 bits) per split activation, or nullptr
     long long* dbg;     // optional cycle stamps (TH_FUSED_DBG)
 };
+// range-guard table slots (th_range_read): the tensors that pass through the fp16 hi/lo split
+enum { TH_RANGE_F = 0, TH_RANGE_S = 1, TH_RANGE_P = 2, TH_RANGE_N = 3, TH_RANGE_INTER = 4, TH_RANGE_F4 = 5, TH_RANGE_CONV = 6 };
 size_t th_fused_pack_bytes();
 // folded: nullptr or the three colour-folded fp32 layers {alpha_res_0, rgb_res_0, rgb_res_1} (in_f 260)
 int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store, FusedParams* out, hipStream_t s);
@@ -223,7 +226,7 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
 // or directly by the compacted sample index when vd_sel == nullptr
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all,
-                         float* raw_c, hipStream_t s);
+                         float* raw_c, unsigned int* range, hipStream_t s);
 
 struct th_ctx {
     void* fused_store = nullptr;
@@ -251,6 +254,12 @@ struct th_ctx {
     int prepass_rr = 0;
     int n_cu = 256;
     void* prof = nullptr;             // ThProf (th_api.hip)
+    // range guard (th_range_*): device table the kernels merge their maxima into, pinned snapshots + events
+    unsigned int* range_dev = nullptr;
+    unsigned int* range_host = nullptr;            // [kRangeSnaps][TH_RANGE_SLOTS]
+    static constexpr int kRangeSnaps = 4;
+    hipEvent_t range_ev[kRangeSnaps] = {};
+    int range_rr = 0, range_last = -1;
 };
 
 // ---- launchers (one group per .hip file) -------------------------------------------
@@ -301,9 +310,9 @@ int th_dparf_grid_build(const float* centres, int nc, void* ws, size_t ws_bytes,
 // k_pixfeat.hip
 int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world,
                         const ThPointSrc* ps, const int32_t* sel, int P, const float* cams, const float* scale,
-                        float* out, int ldo, int fmt, hipStream_t s);
+                        float* out, int ldo, int fmt, hipStream_t s, unsigned int* range = nullptr);
 int th_gather_chan_major_launch(const float* pf /*[V,C,Pall]*/, int V, int C, long long Pall, const int32_t* sel,
-                                int P, float* out /*[P,V,C]*/, int fmt, hipStream_t s);
+                                int P, float* out /*[P,V,C]*/, int fmt, hipStream_t s, unsigned int* range = nullptr);
 // k_mlp.hip
 size_t th_mlp_ws(int V, int P);
 // h [P*V,256], f [P*V,f_ld] (f_ld 384: full rows, 272: compact rows + colour-folded layers), vd rows [P,27]
@@ -341,7 +350,7 @@ int th_conv_pack_launch(const float* w, int COUT, int CIN, int KS, void* out, si
                         hipStream_t s);
 bool th_conv2d_built(int CIN, int COUT, int KS, int stride);
 int th_conv2d_launch(const float* x, int N, int CIN, int H, int W, const void* packed, float inv_scale, int COUT, int KS,
-                     int stride, float* y, hipStream_t s);
+                     int stride, float* y, hipStream_t s, unsigned int* range = nullptr);
 int th_maxpool3x3s2_launch(const float* x, int planes, int H, int W, float* y, hipStream_t s);
 size_t th_bn_ws(int N, int C, int HW);
 int th_bn_act_launch(const float* x, const float* res, int N, int C, int HW, const float* gamma, const float* beta,

@@ -61,6 +61,9 @@ SYMBOLS = {
     "th_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "th_set_mlp_weights": (C.c_int, [C.c_void_p, C.POINTER(ThMlpWeights), C.c_void_p]),
     "th_set_mlp_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "th_range_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "th_range_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
+    "th_range_last_slot": (C.c_int, [C.c_void_p]),
     "th_set_chunk_samples": (C.c_int, [C.c_int]),
     "th_set_vit_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(ThVitBlock), C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
@@ -149,7 +152,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 2:
+    if lib.th_abi_version() != 3:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -271,6 +274,89 @@ def _sync_weights(mod, kind):
     if own is None or own[0]() is not mod or own[1] != ver:
         (set_mlp_weights if kind == "mlp" else set_vit_weights)(mod)
         _ctx_owner[key] = (weakref.ref(mod), ver)
+        if kind == "mlp" and _range_fallback.pop(key[0], None):
+            # new weights: back to the mode the caller asked for (the guard re-checks them)
+            _check(load_library().th_set_mlp_mode(ctx(dev), _user_mode.get(key[0], 1)))
+
+
+# ---------------------------------------------------------------------------
+# range guard of the fp16 hi/lo split arithmetic (include/transhuman_hip.h: th_range_*)
+# ---------------------------------------------------------------------------
+RANGE_NAMES = ("f", "s", "p", "n", "inter", "fc4_in", "conv_in", "_")
+RANGE_FP16_LIMIT = 0x7B53          # 6.0e4 as an fp16 bit pattern (inf / NaN are larger)
+RANGE_FP16_FLOOR = 0x2400          # 2^-6
+RANGE_FP32_LIMIT = 0x476A6000      # 6.0e4 as an fp32 bit pattern (slot conv_in)
+_user_mode = {}                    # device index -> mode requested through set_mlp_mode (default 1)
+_range_fallback = {}               # device index -> True while the guard forces mode 0 on this context
+_range_epoch = {}                  # device index -> number of fallbacks so far (frames queued earlier are re-rendered)
+conv_fallback = False              # set when the stem convolutions' input left the fp16 range: stock convolutions from now on
+last_range = None                  # the last table read (debugging / tests)
+
+
+def _dev_index(device):
+    return torch.device(device).index if device is not None and torch.device(device).index is not None \
+        else torch.cuda.current_device()
+
+
+def range_read(slot, device=None):
+    """The launch-wide maxima of snapshot ``slot`` (th_range_read; waits for the work in front of the snapshot)."""
+    global last_range
+    out = (C.c_uint32 * 8)()
+    _check(load_library().th_range_read(ctx(device), int(slot), out))
+    last_range = list(out)
+    return last_range
+
+
+def range_verdict(vals):
+    """-> None when every split tensor stayed inside the range the fp16 hi/lo arithmetic resolves, else a text."""
+    bad = []
+    for i in range(6):
+        v = vals[i]
+        if v >= RANGE_FP16_LIMIT:
+            bad.append(f"{RANGE_NAMES[i]}: |x| reached the fp16 limit (bits 0x{v:04x})")
+        elif 0 < v < RANGE_FP16_FLOOR:
+            bad.append(f"{RANGE_NAMES[i]}: max |x| below 2^-6 (bits 0x{v:04x})")
+    return "; ".join(bad) if bad else None
+
+
+def _conv_range_bad(vals):
+    return vals[6] >= RANGE_FP32_LIMIT
+
+
+def _enter_fallback(device, why):
+    """Force the per-layer fp32 MFMA form of the MLP on this device until new weights are uploaded."""
+    import warnings
+    d = _dev_index(device)
+    warnings.warn("transhuman_amd: activations left the range of the fp16 hi/lo split MFMA kernel (" + why +
+                  "); re-rendering and continuing on the per-layer fp32 MFMA path for these weights", RuntimeWarning)
+    _check(load_library().th_set_mlp_mode(ctx(device), 0))
+    _range_fallback[d] = True
+    _range_epoch[d] = _range_epoch.get(d, 0) + 1
+
+
+def range_epoch(device=None):
+    return _range_epoch.get(_dev_index(device), 0)
+
+
+def _guard(device, slot):
+    """True when the snapshot is clean.  Otherwise the context has been switched to the fp32 path (and / or the
+    stem convolutions to the stock modules): the caller re-runs its work."""
+    global conv_fallback
+    if slot is None or slot < 0:
+        return True
+    vals = range_read(slot, device)
+    ok = True
+    if _conv_range_bad(vals) and not conv_fallback:
+        import warnings
+        warnings.warn("transhuman_amd: the ResNet-stem convolution input left the fp16 range; using the stock "
+                      "convolutions from now on", RuntimeWarning)
+        conv_fallback = True
+        ok = False
+    why = range_verdict(vals)
+    if why is not None and not _range_fallback.get(_dev_index(device)):
+        _enter_fallback(device, why)
+        ok = False
+    return ok
 
 
 # ---------------------------------------------------------------------------
@@ -413,7 +499,7 @@ _conv_cache = {}
 def conv2d_supported(conv):
     """True for the nn.Conv2d shapes th_conv2d is built for (the bias-free convolutions of the ResNet18 stem)."""
     ks, st, pd = conv.kernel_size, conv.stride, conv.padding
-    return (conv.bias is None and ks[0] == ks[1] and st[0] == st[1] and pd[0] == pd[1] == ks[0] // 2 and
+    return (not conv_fallback and conv.bias is None and ks[0] == ks[1] and st[0] == st[1] and pd[0] == pd[1] == ks[0] // 2 and
             conv.groups == 1 and conv.dilation == (1, 1) and
             bool(load_library().th_conv2d_supported(conv.in_channels, conv.out_channels, ks[0], st[0])))
 
@@ -547,8 +633,11 @@ def network_forward(net, pixel_feat, viewdir, pts_smpl, centres, rot, tokens, ma
     if P == 0:
         return raw
     ws = _ws(lib.th_network_workspace_bytes(V, P), pf.device)
-    _check(lib.th_network_forward(ctx(pf.device), _p(pf), _p(vd), _p(ps), _p(m), P, _p(c), _p(r), _p(t), V, t.shape[1],
-                                  _p(raw), _p(ws), ws.numel(), _stream()))
+    for _ in range(2):
+        _check(lib.th_network_forward(ctx(pf.device), _p(pf), _p(vd), _p(ps), _p(m), P, _p(c), _p(r), _p(t), V, t.shape[1],
+                                      _p(raw), _p(ws), ws.numel(), _stream()))
+        if _guard(pf.device, lib.th_range_last_slot(ctx(pf.device))):
+            break                                    # (else: the context is on the fp32 path now -- run again)
     return raw
 
 
@@ -687,8 +776,12 @@ def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=240
     points._prepass_pending = True          # only THIS Points object (it keeps the ray tensors alive) may consume it
 
 
-def render_rays(net, frame, points, white_bkgd=False):
-    """th_render_rays: rays -> (rgb [R,3], acc [R], depth [R], stats)."""
+def render_rays(net, frame, points, white_bkgd=False, defer_guard=False):
+    """th_render_rays: rays -> (rgb [R,3], acc [R], depth [R], stats).
+    Range guard: the frame's snapshot of the split-arithmetic maxima is read back after the call (a host wait for
+    the frame) and, if a tensor left the resolvable range, the frame is rendered again on the fp32 path.
+    ``defer_guard=True`` returns a fifth value, a callable ``check() -> bool`` (True = clean), instead: a frame
+    pipeline calls it after queuing the next frame so the host never idles the device."""
     lib = load_library()
     _sync_weights(net, "mlp")
     dev = frame.verts.device
@@ -697,7 +790,8 @@ def render_rays(net, frame, points, white_bkgd=False):
     acc = torch.empty(R, dtype=torch.float32, device=dev)
     dep = torch.empty(R, dtype=torch.float32, device=dev)
     if R == 0:                                   # empty ray list: nothing to launch (zero-size tensors have no address)
-        return rgb, acc, dep, dict(hit_rays=0, valid_samples=0, unmasked=0)
+        st0 = dict(hit_rays=0, valid_samples=0, unmasked=0)
+        return (rgb, acc, dep, st0, lambda: True) if defer_guard else (rgb, acc, dep, st0)
     need = lib.th_render_workspace_bytes(C.byref(frame.c), R, points.S)
     if getattr(points, "_prepass_pending", False) and points._prepass_keep[1].numel() >= need:
         points._prepass_pending = False
@@ -708,7 +802,18 @@ def render_rays(net, frame, points, white_bkgd=False):
     stats = (C.c_int64 * 4)()
     _check(lib.th_render_rays(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(rgb), _p(acc), _p(dep), int(white_bkgd),
                               _p(ws), ws.numel(), stats, _stream()))
-    return rgb, acc, dep, dict(hit_rays=stats[0], valid_samples=stats[1], unmasked=stats[3])
+    st = dict(hit_rays=stats[0], valid_samples=stats[1], unmasked=stats[3])
+    slot = int(stats[2])
+    if defer_guard:
+        return rgb, acc, dep, st, (lambda: _guard(dev, slot))
+    if not _guard(dev, slot):
+        if conv_fallback and getattr(frame, "rebuild", None) is not None:
+            frame = frame.rebuild()                  # frame constants again, through the stock convolutions
+        _check(lib.th_render_prepass_drop(ctx(dev), _p(ws)))
+        _check(lib.th_render_rays(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(rgb), _p(acc), _p(dep),
+                                  int(white_bkgd), _p(ws), ws.numel(), stats, _stream()))
+        st = dict(hit_rays=stats[0], valid_samples=stats[1], unmasked=stats[3])
+    return rgb, acc, dep, st
 
 
 def eval_sigma_grid(net, frame, pts):
@@ -721,14 +826,22 @@ def eval_sigma_grid(net, frame, pts):
         return out, dict(valid_samples=0)
     ws = _cached_ws(lib.th_sigma_grid_workspace_bytes(C.byref(frame.c), P), p.device)
     stats = (C.c_int64 * 4)()
-    _check(lib.th_eval_sigma_grid(ctx(p.device), C.byref(frame.c), _p(p), P, _p(out), _p(ws), ws.numel(), stats,
-                                  _stream()))
+    for _ in range(2):
+        _check(lib.th_eval_sigma_grid(ctx(p.device), C.byref(frame.c), _p(p), P, _p(out), _p(ws), ws.numel(), stats,
+                                      _stream()))
+        if _guard(p.device, int(stats[2])):
+            break
+        if conv_fallback and getattr(frame, "rebuild", None) is not None:
+            frame = frame.rebuild()
     return out, dict(valid_samples=stats[1])
 
 
 def set_mlp_mode(mode, device=None):
     """1 = fused fp16-split MFMA kernel (default), 0 = layer-by-layer fp32 MFMA GEMMs."""
     _check(load_library().th_set_mlp_mode(ctx(device), int(mode)))
+    d = _dev_index(device)
+    _user_mode[d] = int(mode)
+    _range_fallback.pop(d, None)
 
 
 def set_chunk_samples(n):

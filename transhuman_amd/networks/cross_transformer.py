@@ -14,12 +14,23 @@ ignored so ``load_state_dict(strict=True)`` of a reference checkpoint works.
 All arithmetic runs in the HIP library (transhuman_amd/csrc, C ABI in
 include/transhuman_hip.h); inference only (no autograd through the kernels).
 """
-import torch
-from torch import nn
+import os
+import sys
 
-from ..config import get_cfg
-from .encoder import SpatialEncoder, _PEBuffers
-from . import vision_transformer as ViT
+# Drop-in loading: the reference instantiates this file through imp.load_source(cfg.<x>_module, cfg.<x>_path)
+# (lib/networks/make_network.py:4-11, renderer/make_renderer.py:4-8) under WHATEVER module name the YAML gives --
+# 'lib.networks.cross_transformer' if only the path key is changed.  Relative imports would then resolve inside the
+# reference's `lib` package, so the package is imported absolutely, found through this file's own location.
+_REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _REPO not in sys.path:
+    sys.path.insert(0, _REPO)
+
+import torch                                                        # noqa: E402
+from torch import nn                                                # noqa: E402
+
+from transhuman_amd.config import get_cfg                           # noqa: E402
+from transhuman_amd.networks.encoder import SpatialEncoder, _PEBuffers   # noqa: E402
+from transhuman_amd.networks import vision_transformer as ViT       # noqa: E402
 
 
 class SpatialKeyValue(nn.Module):
@@ -67,7 +78,7 @@ class Network(nn.Module):
     def forward(self, pixel_feat, sincos_viewdir, DPaRF_param_dict, holder=None, face_idx=None, pts_mask=None):
         """pixel_feat [V,384,P]; sincos_viewdir [1,P,27]; holder [V,N_c,192];
         pts_mask bool [1,P] or None -> raw [1,P,4] (cross_transformer.py:207-271)."""
-        from .. import hip
+        from transhuman_amd import hip
         pts = DPaRF_param_dict["pts_smplcoord"]
         centres = DPaRF_param_dict["obs_smpl_smplcoord"]
         blend = DPaRF_param_dict["blend_mtx"]

@@ -16,13 +16,22 @@ What runs where
 Unlike the reference nothing here mutates ``batch`` (:459-462).
 """
 import os
-import pickle
+import sys
 
-import numpy as np
-import torch
+# Drop-in loading: the reference instantiates this file through imp.load_source(cfg.<x>_module, cfg.<x>_path)
+# (lib/networks/make_network.py:4-11, renderer/make_renderer.py:4-8) under WHATEVER module name the YAML gives --
+# 'lib.networks.cross_transformer' if only the path key is changed.  Relative imports would then resolve inside the
+# reference's `lib` package, so the package is imported absolutely, found through this file's own location.
+_REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if _REPO not in sys.path:
+    sys.path.insert(0, _REPO)
+import pickle                                                       # noqa: E402
 
-from ...config import get_cfg
-from ... import hip, synth
+import numpy as np                                                  # noqa: E402
+import torch                                                        # noqa: E402
+
+from transhuman_amd.config import get_cfg                           # noqa: E402
+from transhuman_amd import hip, synth                               # noqa: E402
 
 
 class Renderer:
@@ -40,15 +49,22 @@ class Renderer:
             self.faces = data["f"]
         self.vertex_can = torch.as_tensor(np.asarray(vertex_can)).contiguous()      # float64 like :48
         self.CR = torch.tensor([-1.5, -1.5, -1.5, 1.5, 1.5, 1.5])                  # :50
+        voxel2pc = None
         if pc2voxel_ind is None:
             num_voxel = cfg.num_class
             path = f"./kmeans_dict/kmeans_dict_{num_voxel}.npy"
-            d = np.load(path, allow_pickle=True).item()
-            pc2voxel_ind = np.asarray(d["pc2voxel_ind"])
+            pc2voxel_ind, voxel2pc = np.load(path, allow_pickle=True).item().values()     # :55 (same unpacking)
+            pc2voxel_ind = np.asarray(pc2voxel_ind)
         self.pc2voxel_ind = torch.as_tensor(np.asarray(pc2voxel_ind)).type(torch.int64)
-        # CSR of the cluster lists: members ascending inside a cluster == the
-        # order of dict_voxel2pc_ind's lists in the reference's files
-        self.csr_offsets, self.csr_members = synth.csr_from_assign(self.pc2voxel_ind.numpy())
+        if voxel2pc is not None:
+            # CSR straight from the file's cluster lists, in the file's order (the reference pools over
+            # dict_voxel2pc_ind.values(), :73 / :362-369)
+            lists = [np.asarray(v, dtype=np.int64).reshape(-1) for v in voxel2pc.values()]
+            self.csr_offsets = np.concatenate([[0], np.cumsum([len(v) for v in lists])]).astype(np.int64)
+            self.csr_members = np.concatenate(lists).astype(np.int64)
+        else:
+            # injected assignment: members ascending inside a cluster == the order of the lists in the reference's files
+            self.csr_offsets, self.csr_members = synth.csr_from_assign(self.pc2voxel_ind.numpy())
         self.num_clusters = len(self.csr_offsets) - 1
         self.voxel_PE_can = self._host_segment_mean(self.vertex_can)               # :73  (float64 [N_c,3])
         self._dev = {}
@@ -140,6 +156,9 @@ class Renderer:
                           tokens, centres, rot,
                           hull_thresh=cfg_hull() if hull_thresh is None else hull_thresh,
                           small_frame_rays=2400)
+        # (range guard, hip.render_rays: the same constants again -- through the stock convolutions -- if the stem's
+        # input left the fp16 range)
+        frame.rebuild = lambda: self.prepare_frame(batch, hull_thresh, fused_encoder_tail, compact_map)
         return frame
 
     # ---- reference API -------------------------------------------------------------------
@@ -228,6 +247,22 @@ class Renderer:
 
         for _ in range(lookahead - 1):
             pull()
+        # A frame is handed out one step late: its range-guard snapshot (hip.render_rays, defer_guard) is read back
+        # -- a host wait for that frame -- only after the shading of the NEXT frame has been queued, so the device
+        # never waits for the host.  A frame whose snapshot is not clean (or that was queued before an earlier frame
+        # switched the context to the fp32 path) is rendered again before it is yielded.
+        shaded = collections.deque()
+
+        def finish(ent):
+            rgb, acc, depth, stats, frame, cur, pts, check, epoch = ent
+            if not check() or epoch != hip.range_epoch(dev):
+                if hip.conv_fallback:
+                    frame = frame.rebuild()
+                    frame.c.small_frame_rays = small_frame_rays
+                rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd))
+            self.last_stats, self.last_frame, self.last_batch = stats, frame, cur
+            return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
+
         while queue:
             cur, pts, frame, ready = queue.popleft()
             main = torch.cuda.current_stream(dev)
@@ -237,11 +272,16 @@ class Renderer:
             # this frame's shading is not
             fence = torch.cuda.Event()
             fence.record(main)
-            rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd))
+            epoch = hip.range_epoch(dev)
+            rgb, acc, depth, stats, check = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
+                                                            defer_guard=True)
             side.wait_event(fence)
             pull()
-            self.last_stats, self.last_frame, self.last_batch = stats, frame, cur
-            yield {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
+            shaded.append((rgb, acc, depth, stats, frame, cur, pts, check, epoch))
+            if len(shaded) > 1:
+                yield finish(shaded.popleft())
+        while shaded:
+            yield finish(shaded.popleft())
 
     def render(self, batch, is_train=True):
         """:486-498 -- no hull mask, every sample shaded, RGB everywhere.
@@ -256,5 +296,5 @@ class Renderer:
 
 
 def cfg_hull():
-    from ...config import cfg_get
+    from transhuman_amd.config import cfg_get
     return float(cfg_get("hull_dist", 0.1))

@@ -7,11 +7,22 @@ evaluates (and discards) RGB for sigma>0 voxels (:84-99) -- `cube` only needs
 sigma_raw, which is what is produced here.  Marching cubes (PyMCubes, :103)
 stays a host step outside the hot path: it runs only if `mcubes` is importable.
 """
-import numpy as np
+import os
+import sys
 
-from ...config import get_cfg
-from ... import hip
-from .if_clight_renderer import Renderer as Base_Renderer
+# Drop-in loading: the reference instantiates this file through imp.load_source(cfg.<x>_module, cfg.<x>_path)
+# (lib/networks/make_network.py:4-11, renderer/make_renderer.py:4-8) under WHATEVER module name the YAML gives --
+# 'lib.networks.cross_transformer' if only the path key is changed.  Relative imports would then resolve inside the
+# reference's `lib` package, so the package is imported absolutely, found through this file's own location.
+_REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+if _REPO not in sys.path:
+    sys.path.insert(0, _REPO)
+
+import numpy as np                                                  # noqa: E402
+
+from transhuman_amd.config import get_cfg                           # noqa: E402
+from transhuman_amd import hip                                      # noqa: E402
+from transhuman_amd.networks.renderer.if_clight_renderer import Renderer as Base_Renderer   # noqa: E402
 
 
 class Renderer(Base_Renderer):
