@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 from transhuman_amd import synth                                    # noqa: E402
 from transhuman_amd.config import get_cfg                           # noqa: E402
-from transhuman_amd.dist import shard_ray_indices, gather_image, ImageGatherer, DeferredSum     # noqa: E402
+from transhuman_amd.dist import shard_ray_indices, gather_image, ImageGatherer, DeferredSum, TokenExchange   # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12        # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 SIGMA_BIAS = -1.7
@@ -235,8 +235,12 @@ def main():
     # stream while step i shades; every step still does one full frame of work (the look-ahead of the last timed
     # step replaces the constants the first timed step received from the warm-up).
     sharded = dist_on or emu
+    # TransHE is not replicated: frame j's tokens are computed by rank j % world and broadcast (1.15 MB) from the
+    # side stream, two collectives ahead of their use (transhuman_amd/dist.py TokenExchange)
+    tokens_x = TokenExchange() if dist_on else (TokenExchange(emulate=(emu, args.emulate_rank)) if emu else None)
     seq = None if args.no_pipeline else renderer.render_sequence(itertools.repeat(shard),
-                                                                  small_frame_rays=-1 if sharded else 2400)
+                                                                  small_frame_rays=-1 if sharded else 2400,
+                                                                  token_exchange=tokens_x)
 
     # The reference's R' <= 2400 switch (if_clight_renderer.py:551) looks at the WHOLE frame.  Shards are rendered in the
     # (overwhelmingly common) masked mode; the per-rank hit-ray counts th_render_rays reports anyway are summed with an
@@ -370,13 +374,15 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
         centre = 0.5 * (bounds[0] + bounds[1]).astype(np.float64)
         K = np.array([[600.0 * W / 512, 0, W / 2], [0, 600.0 * W / 512, H / 2], [0, 0, 1]], np.float32)
         n_views = 60
+        # the reference's virtual camera path (render_utils.py:318-364 gen_path_virt, as can_smpl_perform.py:40-42
+        # builds it once per sequence from the capture rig; frame i uses render_w2c[i % n_views], :68-70) over the
+        # synthetic 21-camera rig
+        from transhuman_amd.camera_path import gen_path_virt, synthetic_rig
+        render_w2c = gen_path_virt(synthetic_rig(centre=tuple(centre.tolist())), render_views=n_views)
 
         def camera(i):
-            th = 2 * math.pi * (i % n_views) / n_views
-            ca, sa = math.cos(th), math.sin(th)
-            R = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]], np.float64)
-            T = -R @ centre + np.array([0, 0, 3.0])
-            return K, R.astype(np.float32), T.reshape(3, 1).astype(np.float32)
+            RT = render_w2c[i % n_views]
+            return K, RT[:3, :3].astype(np.float32), RT[:3, 3:].astype(np.float32)
 
         # every pixel is a ray (rays that miss the body box get near = far = 0 from K9: no sample can pass the hull test,
         # they come out as background exactly like the pixels the reference never renders): no per-frame compaction of

@@ -276,6 +276,41 @@ int th_gen_rays(th_ctx* ctx, const float* K_host, const float* R_host, const flo
                 const float* bounds_host, int H, int W, float* ray_o, float* ray_d, float* near_out,
                 float* far_out, uint8_t* mask_at_box, th_stream stream);
 
+/* lib/utils/if_nerf/if_nerf_data_utils.py:49-62 (get_bound_2d_mask): the projected body box as an H x W uint8 mask
+ * (used by sample_ray_h36m :211-213 to restrict the foreground mask).  corners_xy_host = the eight box corners
+ * (get_bound_corners order, :33-46) projected with base_utils.project and rounded with np.round(..).astype(int)
+ * on the HOST (8 points; transhuman_amd/hip.py::bound_2d_mask keeps the reference's numpy expressions); the kernel
+ * rasterises the six faces with cv2.fillPoly's scan conversion (even-odd spans + 8-connected edges), vertex lists
+ * as in :55-60.  OpenCV is third-party and absent: parity unpinned against cv2 itself, bit-exact against the
+ * restatement in oracle/th_oracle.py. */
+int th_bound_mask(th_ctx* ctx, const int32_t* corners_xy_host /* [8][2] */, int H, int W, uint8_t* mask,
+                  th_stream stream);
+
+/* ---- K13: marching cubes over the sigma cube ------------------------------ */
+/* lib/networks/renderer/if_mesh_renderer.py:99-109: `mcubes.marching_cubes(np.pad(cube, 10), cfg.mesh_th)` and the
+ * index -> world transform `vertices * voxel_size + (can_bounds[0] - 10 voxel_size)`.  PyMCubes is third-party and
+ * absent (parity unpinned against mcubes itself): the published table-driven algorithm is restated in PyMCubes'
+ * conventions (corner / edge numbering of the Bourke table, corner "inside" <=> value <= iso, one shared vertex per
+ * cut edge at the float64 linear interpolation, table order of triangles) -- see csrc/k_mcubes.hip.
+ * cube: [X][Y][Z] fp32 on the device (already padded by the caller).  Usage:
+ *   th_marching_cubes_count  passes 1-2 (classification + prefix sums into `workspace`), waits for the stream and
+ *                            returns {n_vertices, n_triangles} in counts_host;
+ *   th_marching_cubes_emit   writes vertices (float64 [n_vertices,3] = index * scale + origin) and triangles
+ *                            (int32 [n_triangles,3], indices into the vertex array) for the grid slab
+ *                            x0 <= x < x1 of points / cells (0, X for everything); slabs of one count pass write
+ *                            disjoint contiguous ranges of the same arrays (multi-GPU: one slab per rank);
+ *   th_marching_cubes_range  {vertex, triangle} prefix at the first point of plane x (x = X: the totals): the
+ *                            range a slab [x0, x1) fills is [range(x0), range(x1)).
+ * Vertex order: owning grid point row-major, +x / +y / +z edge; triangle order: cell row-major, table order. */
+size_t th_marching_cubes_workspace_bytes(int X, int Y, int Z);
+int th_marching_cubes_count(th_ctx* ctx, const float* cube, int X, int Y, int Z, float iso, void* workspace,
+                            size_t workspace_bytes, int64_t* counts_host /* [2] */, th_stream stream);
+int th_marching_cubes_range(th_ctx* ctx, const void* workspace, int X, int Y, int Z, int x,
+                            int64_t* prefix_host /* [2] */, th_stream stream);
+int th_marching_cubes_emit(th_ctx* ctx, const float* cube, int X, int Y, int Z, float iso, const void* workspace,
+                           int x0, int x1, const double* scale_host /* [3] */, const double* origin_host /* [3] */,
+                           double* verts, int32_t* tris, th_stream stream);
+
 /* ---- K10: SMPL linear blend skinning ------------------------------------ */
 /* SMPL._call, lib/utils/SMPL.py:114-186, float64 like the reference.  Model arrays (DEVICE pointers, the fields
  * the reference reads from the SMPL pickle, :83-89): v_template [nv,3], shapedirs [nv,3,10], posedirs [nv,3,207],

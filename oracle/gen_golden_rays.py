@@ -54,6 +54,17 @@ def main():
     out = os.path.join(os.path.dirname(HERE), "tests", "golden", "g14_rays.npz")
     np.savez_compressed(out, **arrs)
     print("wrote", out, os.path.getsize(out), "bytes")
+    # virtual camera path of the free-viewpoint video (lib/utils/render_utils.py:318-364, numpy only): the
+    # reference's own function on the synthetic capture rig
+    from lib.utils import render_utils as ru
+    from transhuman_amd.camera_path import synthetic_rig
+    rig = synthetic_rig()
+    path60 = np.array(ru.gen_path_virt([m.copy() for m in rig], render_views=60))
+    centre = np.array([0.0, 0.1, 3.0])
+    path7c = np.array(ru.gen_path_virt([m.copy() for m in rig], center=centre, render_views=7))
+    out = os.path.join(os.path.dirname(HERE), "tests", "golden", "g16_path.npz")
+    np.savez_compressed(out, rig=np.array(rig), path60=path60, centre=centre, path7c=path7c)
+    print("wrote", out, os.path.getsize(out), "bytes")
 
 
 if __name__ == "__main__":

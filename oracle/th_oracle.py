@@ -352,7 +352,7 @@ def pixel_aligned(pixel_feat_map, xyz_w, batch):
 
 
 def render_fast(sd, batch, holder_feat_map, pixel_feat_map, offsets, members, can_centres64,
-                n_samples=64, vit_depth=12, small_frame_rays=2400, hull=0.1, chunk=32768):
+                n_samples=64, vit_depth=12, small_frame_rays=2400, hull=0.1, chunk=32768, white_bkgd=False):
     """Renderer.render_fast, if_clight_renderer.py:429-484 (+ _render :500-605,
     batchify_rays :607-656).  Encoder outputs are inputs here.
     Returns dict rgb_map [1,R,3], acc_map [1,R], depth_map [1,R]."""
@@ -382,7 +382,7 @@ def render_fast(sd, batch, holder_feat_map, pixel_feat_map, offsets, members, ca
             raws.append(network_forward(sd, pf, vd[s:s + chunk], ps[s:s + chunk], fc["centres"],
                                         fc["blend"], fc["tokens"], mm[s:s + chunk]))
         raw = torch.cat(raws, 0)
-    rgb, acc, depth, _ = raw2outputs(raw.view(Rp, n_samples, 4), zz, d)
+    rgb, acc, depth, _ = raw2outputs(raw.view(Rp, n_samples, 4), zz, d, white_bkgd)       # :593 (hit rays only)
     out["rgb_map"][0, hit] = rgb
     out["acc_map"][0, hit] = acc
     out["depth_map"][0, hit] = depth
@@ -487,6 +487,135 @@ def gen_rays(H, W, K, R, T, bounds):
     near[mask] = np.minimum(d0, d1).astype(np.float32)
     far[mask] = np.maximum(d0, d1).astype(np.float32)
     return dict(ray_o=ray_o, ray_d=ray_d, near=near, far=far, mask_at_box=mask)
+
+
+def bound_2d_mask(bounds, K, pose, H, W):
+    """lib/utils/if_nerf/if_nerf_data_utils.py:49-62 (get_bound_2d_mask).  The corner projection / rounding are the
+    reference's numpy expressions (:33-53, base_utils.py:178-187).  cv2.fillPoly is THIRD-PARTY and absent here
+    (PARITY UNPINNED against OpenCV itself): its scan conversion for integer vertices is restated from the
+    published source (imgproc/src/drawing.cpp: CollectPolyEdges draws every edge as an 8-connected line,
+    FillEdgeCollection fills each scanline between consecutive pairs of edge crossings, an edge active for
+    y0 <= y < y1, crossing x rounded half up, ends inclusive).  Plain loops: 6 polygons x 5 edges."""
+    mn, mx = np.asarray(bounds)[0], np.asarray(bounds)[1]
+    corners = np.array([[mn[0], mn[1], mn[2]], [mn[0], mn[1], mx[2]], [mn[0], mx[1], mn[2]], [mn[0], mx[1], mx[2]],
+                        [mx[0], mn[1], mn[2]], [mx[0], mn[1], mx[2]], [mx[0], mx[1], mn[2]], [mx[0], mx[1], mx[2]]])
+    xyz = np.dot(corners, np.asarray(pose)[:, :3].T) + np.asarray(pose)[:, 3:].T     # base_utils.project
+    xyz = np.dot(xyz, np.asarray(K).T)
+    c2 = np.round(xyz[:, :2] / xyz[:, 2:]).astype(int)                                 # :52
+    mask = np.zeros((H, W), dtype=np.uint8)
+    ys, xs = np.mgrid[0:H, 0:W]
+    for face in ([0, 1, 3, 2, 0], [4, 5, 7, 6, 5], [0, 1, 5, 4, 0], [2, 3, 7, 6, 2], [0, 2, 6, 4, 0], [1, 3, 7, 5, 1]):
+        pts = [(int(c2[v, 0]), int(c2[v, 1])) for v in face]
+        cross = [[] for _ in range(H)]
+        for e in range(5):
+            (x0, y0), (x1, y1) = pts[e], pts[(e + 1) % 5]
+            dx, dy = x1 - x0, y1 - y0
+            # the edge as an 8-connected line
+            if dx == 0 and dy == 0:
+                if 0 <= x0 < W and 0 <= y0 < H:
+                    mask[y0, x0] = 1
+            elif abs(dx) >= abs(dy):
+                for x in range(max(min(x0, x1), 0), min(max(x0, x1), W - 1) + 1):
+                    y = int(np.floor(float(y0) + float(x - x0) * (float(dy) / float(dx)) + 0.5))
+                    if 0 <= y < H:
+                        mask[y, x] = 1
+            else:
+                for y in range(max(min(y0, y1), 0), min(max(y0, y1), H - 1) + 1):
+                    x = int(np.floor(float(x0) + float(y - y0) * (float(dx) / float(dy)) + 0.5))
+                    if 0 <= x < W:
+                        mask[y, x] = 1
+            # scanline crossings
+            if y0 == y1:
+                continue
+            if y0 > y1:
+                x0, y0, x1, y1 = x1, y1, x0, y0
+            for y in range(max(y0, 0), min(y1, H)):
+                cross[y].append(int(np.floor(float(x0) + float(y - y0) * (float(x1 - x0) / float(y1 - y0)) + 0.5)))
+        for y in range(H):
+            c = sorted(cross[y])
+            for i in range(0, len(c) - 1, 2):
+                a, b = max(c[i], 0), min(c[i + 1], W - 1)
+                if a <= b:
+                    mask[y, a:b + 1] = 1
+    return mask
+
+
+# ---------------------------------------------------------------------------
+# SURVEY 8f-4: marching cubes (consumer of the sigma cube), PLY, PSNR
+# ---------------------------------------------------------------------------
+_MC_EDGE_PT = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1], [0, 0, 1],
+                        [0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])
+_MC_EDGE_AX = np.array([0, 1, 0, 1, 0, 1, 0, 1, 2, 2, 2, 2])
+
+
+def mc_case_table():
+    """the published 256 x 16 triangle table (Lorensen & Cline 1987, Bourke / Bloyd numbering), tests/golden/mc_case_table.npz"""
+    import os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return np.load(os.path.join(here, "tests", "golden", "mc_case_table.npz"))["tri"].astype(np.int64)
+
+
+def marching_cubes(cube, iso, scale=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0)):
+    """mcubes.marching_cubes(cube, iso) as if_mesh_renderer.py:103 calls it, followed by the index -> world transform
+    of :106-108.  PyMCubes is THIRD-PARTY and absent (PARITY UNPINNED against mcubes itself): its published algorithm
+    (marchingcubes.h: corner m of cell (i,j,k) in the Bourke numbering sets bit m when value <= iso; one vertex per
+    cut edge at x1 + (x2 - x1) (iso - f1) / (f2 - f1), float64, midpoint if f1 == f2; triangles from the case table)
+    is restated with numpy.  Vertex order: owning grid point row-major, +x / +y / +z edge; triangle order: cell
+    row-major, table order (the device kernel's order; PyMCubes' own order follows from its traversal).
+    -> (vertices float64 [nv,3], triangles int64 [nt,3])"""
+    c = np.asarray(cube, dtype=np.float32)
+    X, Y, Z = c.shape
+    inside = c <= np.float32(iso)
+    f = c.astype(np.float64)
+    flags = np.zeros((X, Y, Z), dtype=np.int64)
+    flags[:-1] |= (inside[:-1] != inside[1:]) * 1
+    flags[:, :-1] |= (inside[:, :-1] != inside[:, 1:]) * 2
+    flags[:, :, :-1] |= (inside[:, :, :-1] != inside[:, :, 1:]) * 4
+    pop = (flags & 1) + ((flags >> 1) & 1) + ((flags >> 2) & 1)
+    vbase = np.cumsum(pop.reshape(-1)) - pop.reshape(-1)
+    nv = int(pop.sum())
+    verts = np.zeros((nv, 3), dtype=np.float64)
+    idx = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij"), -1).astype(np.float64)
+    vb = vbase.reshape(X, Y, Z)
+    for a in range(3):
+        sel = (flags >> a) & 1 == 1
+        f0 = f[sel]
+        f1 = np.roll(f, -1, axis=a)[sel]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = np.where(f1 == f0, 0.5, (float(np.float32(iso)) - f0) / (f1 - f0))
+        p = idx[sel].copy()
+        p[:, a] = p[:, a] + t
+        rank = np.zeros_like(flags)
+        for b in range(a):
+            rank = rank + ((flags >> b) & 1)
+        verts[vb[sel] + rank[sel]] = p
+    verts = verts * np.asarray(scale, dtype=np.float64)[None] + np.asarray(origin, dtype=np.float64)[None]
+    # cells
+    ins = inside.astype(np.int64)
+    case = (ins[:-1, :-1, :-1] | ins[1:, :-1, :-1] << 1 | ins[1:, 1:, :-1] << 2 | ins[:-1, 1:, :-1] << 3 |
+            ins[:-1, :-1, 1:] << 4 | ins[1:, :-1, 1:] << 5 | ins[1:, 1:, 1:] << 6 | ins[:-1, 1:, 1:] << 7)
+    table = mc_case_table()
+    ntri = (table >= 0).sum(1) // 3
+    cells = np.argwhere((case != 0) & (case != 255))                      # row-major order
+    cs = case[cells[:, 0], cells[:, 1], cells[:, 2]]
+    counts = ntri[cs]
+    tbase = np.cumsum(counts) - counts
+    tris = np.zeros((int(counts.sum()), 3), dtype=np.int64)
+    for k in range(15):                                                   # k-th edge slot of the table row
+        has = table[cs, k] >= 0
+        e = table[cs[has], k]
+        pt = cells[has] + _MC_EDGE_PT[e]
+        ax = _MC_EDGE_AX[e]
+        fl = flags[pt[:, 0], pt[:, 1], pt[:, 2]]
+        rank = np.where(ax >= 1, fl & 1, 0) + np.where(ax >= 2, (fl >> 1) & 1, 0)
+        tris[tbase[has] + k // 3, k % 3] = vb[pt[:, 0], pt[:, 1], pt[:, 2]] + rank
+    return verts, tris
+
+
+def psnr_metric(img_pred, img_gt):
+    """lib/evaluators/if_nerf.py:34-37"""
+    mse = np.mean((img_pred - img_gt) ** 2)
+    return -10 * np.log(mse) / np.log(10)
 
 
 # ---------------------------------------------------------------------------

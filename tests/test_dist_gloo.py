@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from transhuman_amd.dist import ImageGatherer, DeferredSum, gather_image, shard_ray_indices
+from transhuman_amd.dist import ImageGatherer, DeferredSum, TokenExchange, gather_image, shard_ray_indices, _tile_skew
 
 
 def _free_port():
@@ -51,6 +51,34 @@ def _worker(rank, world, port, H, W, q):
             img2 = ga(full[idx2] * (fr + 1.0))
             want = int((full[:, 3] > 0.5).sum()) + fr * world * (world + 1) // 2
             ok = ok and ds.result() == want and torch.equal(img2, full * (fr + 1.0))
+        # TransHE sharded over the frames of a stream: frame j's tokens come from rank j % world (its own
+        # communicator), every rank ends up with the owner's tensor and runs the "ViT" for its own frames only;
+        # interleaved with the image gather of the render stream exactly like Renderer.render_sequence + bench.step
+        tx = TokenExchange()
+        calls = []
+        for fr in range(2 * world + 1):
+            def vit(fr=fr):
+                calls.append(fr)
+                return torch.full((3, 7, 192), float(fr)) + torch.arange(192.0) * (rank + 1)   # rank-specific payload
+            tok = tx(vit, (3, 7, 192), torch.device("cpu"))
+            want_tok = torch.full((3, 7, 192), float(fr)) + torch.arange(192.0) * (fr % world + 1)
+            ok = ok and torch.equal(tok, want_tok)
+            ok = ok and torch.equal(ga(full[idx2] * (fr + 1.0)), full * (fr + 1.0))
+        ok = ok and calls == [fr for fr in range(2 * world + 1) if fr % world == rank] and tx.computed == len(calls)
+        # mesh workload: voxel runs of 4096 dealt to the ranks (bench.py run_secondary), sigma gathered back
+        g = 32
+        nvox = g * g * g
+        sig_full = torch.rand(nvox, generator=torch.Generator().manual_seed(7))
+        vox = torch.arange(nvox)
+        run = vox // 4096
+        per_slice = max(1, (g * g) // 4096)
+        mine = vox[((run % per_slice + _tile_skew(world) * (run // per_slice)) % world) == rank]
+        sig = gather_image(sig_full[mine][:, None], mine, nvox, world)[:, 0]
+        ok = ok and torch.equal(sig, sig_full)
+        cover = torch.zeros(nvox, dtype=torch.int64)
+        cover[mine] = 1
+        dist.all_reduce(cover)
+        ok = ok and int(cover.min()) == 1 and int(cover.max()) == 1
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -97,3 +125,19 @@ def test_shards_are_balanced_over_a_centred_subject():
         assert int(seen.min()) == 1 and int(seen.max()) == 1
         mean = sum(counts) / world
         assert max(counts) <= 1.04 * mean and min(counts) >= 0.96 * mean, (world, counts)
+
+
+def test_token_exchange_emulation_counts_the_owned_frames():
+    """bench.py --emulate-world N: the per-rank work of an N-rank job on one device (no process group) -- the ViT runs
+    for the frames this rank owns (and once more if its first frame is not its own)"""
+    for world, rank in ((8, 0), (8, 5), (3, 2)):
+        tx = TokenExchange(emulate=(world, rank))
+        calls = []
+        for fr in range(17):
+            def vit(fr=fr):
+                calls.append(fr)
+                return torch.full((1, 2, 192), float(fr))
+            tok = tx(vit, (1, 2, 192), torch.device("cpu"))
+            assert tok.shape == (1, 2, 192)
+        owned = [fr for fr in range(17) if fr % world == rank]
+        assert calls == ([0] if rank != 0 else []) + owned

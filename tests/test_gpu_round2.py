@@ -191,3 +191,110 @@ def test_torch_default_init_vs_oracle(hip, gpu):
     assert maxdiff(out["rgb_map"].cpu(), ref["rgb_map"]) < 1e-4
     assert maxdiff(out["acc_map"].cpu(), ref["acc_map"]) < 1e-4
     print("default-init range table:", [hex(v) for v in hip.last_range], "fallback:", dict(hip._range_fallback))
+
+
+def test_bound_2d_mask_equals_oracle(hip, gpu):
+    """8f-2: th_bound_mask (the six box faces rasterised like cv2.fillPoly) bit-exact against the oracle's restatement,
+    on-axis / oblique cameras and a box that leaves the image"""
+    from util import gold
+    g = gold("g14_rays")
+    cases = []
+    for name in ("axis", "oblique"):
+        H, W = [int(v) for v in g[f"{name}_HW"]]
+        pose = np.concatenate([g[f"{name}_R"].numpy(), g[f"{name}_T"].numpy()], axis=1)
+        cases.append((g[f"{name}_bounds"].numpy(), g[f"{name}_K"].numpy(), pose, H, W))
+    K = np.array([[90.0, 0.0, 30.0], [0, 90.0, 20.0], [0, 0, 1]], np.float32)
+    pose = np.concatenate([np.eye(3, dtype=np.float32), np.array([[1.2], [0.0], [0.0]], np.float32)], axis=1)
+    cases.append((np.array([[-0.5, -0.5, 2.0], [0.5, 0.5, 3.0]], np.float32), K, pose, 40, 56))
+    K5 = np.array([[600.0, 0.0, 256.0], [0, 600.0, 256.0], [0, 0, 1]], np.float32)
+    pose5 = np.concatenate([np.eye(3, dtype=np.float32), np.zeros((3, 1), np.float32)], axis=1)
+    cases.append((np.array([[-0.4, -0.8, 2.7], [0.45, 0.95, 3.3]], np.float32), K5, pose5, 512, 512))
+    for b, K, pose, H, W in cases:
+        m = hip.bound_2d_mask(b, K, pose, H, W, device=gpu).cpu().numpy()
+        ref = O.bound_2d_mask(b, K, pose, H, W)
+        assert m.shape == ref.shape and np.array_equal(m, ref), (H, W, int((m != ref).sum()))
+        assert ref.sum() > 0
+
+
+def test_marching_cubes_equals_oracle(hip, gpu):
+    """8f-4: th_marching_cubes_* bit-exact against the oracle restatement (same vertex / triangle order by
+    construction: float64 vertices equal, index lists equal), whole grid and slab by slab (the multi-GPU split),
+    incl. the index -> world transform and empty results"""
+    from util import gold
+    g = gold("g17_mcubes")
+    for name in ("ellipsoid", "blobs", "noise_padded"):
+        vol, iso = g[name + "_vol"], float(g[name + "_iso"])
+        scale, origin = (0.005, 0.006, 0.007), (-0.4, 0.25, 2.6)
+        rv, rf = O.marching_cubes(vol.numpy(), iso, scale=scale, origin=origin)
+        v, f = hip.marching_cubes(vol.to(gpu), iso, scale=scale, origin=origin)
+        assert v.dtype == torch.float64 and f.dtype == torch.int32
+        assert tuple(v.shape) == rv.shape and tuple(f.shape) == rf.shape, name
+        assert np.array_equal(f.cpu().numpy(), rf.astype(np.int32)), name
+        assert np.array_equal(v.cpu().numpy(), rv), name
+        # slabs [0,7) [7,15) [15,X): disjoint contiguous ranges that tile the full arrays
+        X = vol.shape[0]
+        full_v, full_f = torch.zeros_like(v), torch.zeros_like(f)
+        ends = [0, 7, 15, X]
+        prev_v = prev_t = 0
+        for a, b in zip(ends[:-1], ends[1:]):
+            sv, sf, (v0, v1), (t0, t1) = hip.marching_cubes(vol.to(gpu), iso, scale=scale, origin=origin, x_range=(a, b))
+            assert v0 == prev_v and t0 == prev_t
+            full_v[v0:v1], full_f[t0:t1] = sv[v0:v1], sf[t0:t1]
+            prev_v, prev_t = v1, t1
+        assert prev_v == v.shape[0] and prev_t == f.shape[0]
+        assert torch.equal(full_v, v) and torch.equal(full_f, f)
+    v, f = hip.marching_cubes(torch.zeros((5, 6, 7), device=gpu), 20.0)
+    assert tuple(v.shape) == (0, 3) and tuple(f.shape) == (0, 3)
+
+
+def test_mesh_renderer_produces_the_iso_surface(hip, gpu, net, tmp_path):
+    """if_mesh_renderer.Renderer.render end to end (:46-113): cube (padded by 10 like :101) -> device marching cubes
+    at cfg.mesh_th -> world coordinates -> PLY.  The mesh equals the oracle's on the same cube, is closed, and lies
+    inside the body box."""
+    from transhuman_amd.config import get_cfg
+    from transhuman_amd.mesh import read_ply
+    from transhuman_amd.networks.renderer import if_mesh_renderer
+    cfg = get_cfg()
+    cfg.N_samples, cfg.num_class = 32, 300
+    b = synth.make_batch(32, 32, 3, seed=0)
+    b["pts"] = synth.make_grid_pts(b, 40)
+    bd = synth.batch_to(b, gpu)
+    r = if_mesh_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=synth_assign(300))
+    old_th = cfg.mesh_th
+    try:
+        cfg.mesh_th = 0.5                                  # the synthetic weights' sigma_raw is O(1)
+        out = r.render(bd)
+    finally:
+        cfg.mesh_th = old_th
+    cube, mesh = out["cube"], out["mesh"]
+    assert cube.shape == (60, 60, 60) and float(np.abs(cube[:10]).max()) == 0.0
+    assert mesh.vertices.shape[0] > 100 and mesh.is_watertight
+    voxel = np.array(cfg.voxel_size, dtype=np.float64)
+    LB = b["can_bounds"][0].numpy().astype(np.float64)[0] - 10 * voxel
+    rv, rf = O.marching_cubes(cube, 0.5, scale=voxel, origin=LB)
+    assert np.array_equal(mesh.vertices.cpu().numpy(), rv) and np.array_equal(mesh.faces.cpu().numpy(), rf)
+    path = mesh.export(str(tmp_path / "0.ply"))
+    v2, f2 = read_ply(path)
+    assert v2.shape[0] == rv.shape[0] and f2.shape[0] == rf.shape[0]
+
+
+def test_white_background_vs_reference_golden(hip, gpu, net):
+    """with cfg.white_bkgd the reference's render_fast leaves rays that miss the hull BLACK (they are never
+    composited, if_clight_renderer.py:459-476) and adds (1 - acc) to the rays that hit it; Renderer.render
+    (:486-498) composites every ray.  Golden from the reference itself (oracle/gen_golden_white.py)."""
+    from util import gold
+    from transhuman_amd.config import get_cfg
+    from transhuman_amd.networks.renderer import if_clight_renderer
+    g = gold("g11w_render_white")
+    cfg = get_cfg()
+    cfg.N_samples, cfg.num_class = 32, 300
+    b = synth.batch_to(synth.make_batch(64, 64, 3, seed=0, focal=210.0), gpu)
+    r = if_clight_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=synth_assign(300))
+    cfg.white_bkgd = True
+    try:
+        out = r.render_fast(b, is_train=False)
+    finally:
+        cfg.white_bkgd = False
+    assert maxdiff(out["rgb_map"][0].cpu(), g["rgb"]) < 1e-4 and maxdiff(out["acc_map"][0].cpu(), g["acc"]) < 1e-4
+    black = (g["rgb"].abs().sum(-1) == 0)
+    assert float(out["rgb_map"][0].cpu()[black].abs().max()) == 0.0

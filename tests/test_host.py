@@ -96,3 +96,28 @@ def test_algorithmic_flop_accounting():
     assert bench.algorithmic_mlp_flops(3, 1, 0) == 2 * 1543040
     assert bench.algorithmic_mlp_flops(3, 0, 1) == 2 * 764416
     assert bench.algorithmic_mlp_flops(1, 1, 1) == 2 * 823424
+
+
+def test_gen_path_virt_vs_reference_golden():
+    """the virtual camera orbit of the free-viewpoint video (render_utils.py:318-364): our restatement against the
+    reference's own function on the synthetic 21-camera rig (tests/golden/g16_path.npz, oracle/gen_golden_rays.py)"""
+    import os
+    from transhuman_amd.camera_path import gen_path_virt, synthetic_rig
+    from util import GOLD
+    g = np.load(os.path.join(GOLD, "g16_path.npz"))
+    rig = synthetic_rig()
+    assert np.array_equal(np.array(rig), g["rig"]), "the rig generator must reproduce the golden's input"
+    before = [m.copy() for m in rig]
+    p60 = np.array(gen_path_virt(rig, render_views=60))
+    assert all(np.array_equal(a, b) for a, b in zip(rig, before)), "the input list must not be mutated"
+    assert p60.shape == (60, 4, 4) and np.abs(p60 - g["path60"]).max() < 1e-12
+    p7 = np.array(gen_path_virt(rig, center=g["centre"], render_views=7))
+    assert np.abs(p7 - g["path7c"]).max() < 1e-12
+    # properties: rigid world-to-camera matrices, a closed orbit around the rig centre
+    for m in p60:
+        assert np.abs(m[:3, :3] @ m[:3, :3].T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(m[:3, :3]) - 1) < 1e-12
+        assert np.array_equal(m[3], [0, 0, 0, 1])
+    centres = np.array([-m[:3, :3].T @ m[:3, 3] for m in p60])
+    rig_c = np.array([-m[:3, :3].T @ m[:3, 3] for m in rig]).mean(0)
+    d = np.linalg.norm(centres - rig_c, axis=1)
+    assert d.min() > 1.5 and d.max() < 5.0

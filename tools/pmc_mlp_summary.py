@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Per-launch medians of the counters tools/pmc_mlp.sh collected over mlp_fused_kernel (full-size launches only:
+the largest grid of the run), plus the derived ratios DESIGN.md quotes.
+
+    python tools/pmc_mlp_summary.py gpurun_out/DIR > profiles/rNN_x_pmc_mlp.txt
+"""
+import csv
+import glob
+import statistics
+import sys
+from collections import defaultdict
+
+
+def main():
+    d = sys.argv[1]
+    vals = {}
+    for path in sorted(glob.glob(f"{d}/pass_*_counter_collection.csv")):
+        p = path.split("pass_")[1][0]
+        rows = list(csv.DictReader(open(path)))
+        if not rows:
+            continue
+        gmax = max(int(r["Grid_Size"]) for r in rows)
+        agg = defaultdict(list)
+        for r in rows:
+            if int(r["Grid_Size"]) == gmax:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        n = 0
+        for k, v in sorted(agg.items()):
+            vals[k] = statistics.median(v)
+            n = len(v)
+            print(f"{p}  {k:38s} {vals[k]:18.0f}")
+        print(f"#  pass {p}: {n} launches of {gmax // 256} tiles, VGPRs {rows[0]['VGPR_Count']}+{rows[0]['Accum_VGPR_Count']}, "
+              f"scratch {rows[0]['Scratch_Size']} B/lane, LDS {rows[0]['LDS_Block_Size']}")
+    g = vals.get
+    if g("SQ_WAVE_CYCLES") and g("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # SQ_* count quad-cycles (4 clocks) except SQ_VALU_MFMA_BUSY_CYCLES (clocks, summed over the SIMDs)
+        wave_clk = 4.0 * g("SQ_WAVE_CYCLES")
+        print(f"# derived: MFMA busy = {g('SQ_VALU_MFMA_BUSY_CYCLES'):.3e} / (4 * {g('SQ_WAVE_CYCLES'):.3e}) = "
+              f"{100.0 * g('SQ_VALU_MFMA_BUSY_CYCLES') / wave_clk:.1f} % of wave cycles")
+        if g("SQ_WAIT_INST_ANY"):
+            print(f"#          waiting on any counter {100.0 * g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.1f} %, "
+                  f"on LDS {100.0 * g('SQ_WAIT_INST_LDS', 0) / g('SQ_WAVE_CYCLES'):.1f} %, "
+                  f"VALU issue {100.0 * g('SQ_ACTIVE_INST_VALU', 0) / g('SQ_WAVE_CYCLES'):.1f} %, "
+                  f"LDS issue {100.0 * g('SQ_ACTIVE_INST_LDS', 0) / g('SQ_WAVE_CYCLES'):.1f} %")
+    if g("SQ_LDS_BANK_CONFLICT") and g("SQ_LDS_IDX_ACTIVE"):
+        print(f"#          LDS bank-conflict cycles / LDS active cycles = "
+              f"{100.0 * g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE'):.1f} %")
+    if g("SQ_INSTS_MFMA"):
+        print(f"#          instructions per launch: MFMA {g('SQ_INSTS_MFMA'):.3e}, VALU {g('SQ_INSTS_VALU', 0):.3e}, "
+              f"SALU {g('SQ_INSTS_SALU', 0):.3e}")
+
+
+if __name__ == "__main__":
+    main()

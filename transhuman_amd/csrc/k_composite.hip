@@ -14,7 +14,8 @@
 __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict__ raw, const float* __restrict__ zin,
                                                         ThPointSrc ps, int white, float* __restrict__ rgb,
                                                         float* __restrict__ acc, float* __restrict__ depth,
-                                                        float* __restrict__ wout, const uint8_t* __restrict__ mask) {
+                                                        float* __restrict__ wout, const uint8_t* __restrict__ mask,
+                                                        const int32_t* __restrict__ ray_hit) {
     const int lane = threadIdx.x & 63;
     int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= ps.R) return;
@@ -60,7 +61,10 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict
         sd += __shfl_xor(sd, o); sa += __shfl_xor(sa, o);
     }
     if (lane == 0) {
-        if (white) { float bg = 1.0f - sa; sr += bg; sg += bg; sb += bg; }
+        // white background: render_fast composites only the rays that hit the hull and scatters them into zeros
+        // (if_clight_renderer.py:467-476), so a ray that misses stays black even with white_bkgd; Renderer.render
+        // (:486-498) composites every ray (ray_hit == nullptr or all ones)
+        if (white && (ray_hit == nullptr || ray_hit[ray] != 0)) { float bg = 1.0f - sa; sr += bg; sg += bg; sb += bg; }
         rgb[3 * ray] = sr; rgb[3 * ray + 1] = sg; rgb[3 * ray + 2] = sb;
         acc[ray] = sa;
         depth[ray] = sd;
@@ -68,10 +72,10 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict
 }
 
 int th_composite_launch(const float* raw, const float* z, const ThPointSrc& ps, int white, float* rgb, float* acc,
-                        float* depth, float* wout, const uint8_t* mask, hipStream_t s) {
+                        float* depth, float* wout, const uint8_t* mask, hipStream_t s, const int32_t* ray_hit) {
     if (ps.R <= 0) return 0;
     hipLaunchKernelGGL(composite_kernel, dim3(th_cdiv(ps.R, 4)), dim3(256), 0, s, (const float4*)raw, z, ps, white, rgb,
-                       acc, depth, wout, mask);
+                       acc, depth, wout, mask, ray_hit);
     TH_LAUNCH_CHECK();
     return 0;
 }

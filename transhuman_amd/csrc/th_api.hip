@@ -35,9 +35,11 @@ struct ProfScope {
     ProfScope(ThProf* p_, int phase_, hipStream_t s_) : p(p_), phase(phase_), s(s_) {
         if (p && p->on) { a = p->get(); if (a) (void)hipEventRecord(a, s); }
     }
-    ~ProfScope() {
+    void close() {
         if (a) { hipEvent_t b = p->get(); if (b) { (void)hipEventRecord(b, s); p->spans.push_back({phase, a, b}); } }
+        a = nullptr;
     }
+    ~ProfScope() { close(); }
 };
 static ThProf* prof_of(th_ctx* c);
 
@@ -472,6 +474,46 @@ int th_gen_rays(th_ctx* c, const float* K_host, const float* R_host, const float
                               (hipStream_t)stream);
 }
 
+int th_bound_mask(th_ctx* c, const int32_t* corners_xy_host, int H, int W, uint8_t* mask, th_stream stream) {
+    TH_REQUIRE(c && corners_xy_host && mask && H > 0 && W > 0, "bad argument");
+    return th_bound_mask_launch(corners_xy_host, H, W, mask, (hipStream_t)stream);
+}
+
+size_t th_marching_cubes_workspace_bytes(int X, int Y, int Z) { return th_mc_ws(X, Y, Z) + 256; }
+
+int th_marching_cubes_count(th_ctx* c, const float* cube, int X, int Y, int Z, float iso, void* ws, size_t ws_bytes,
+                            int64_t* counts_host, th_stream stream) {
+    TH_REQUIRE(c && cube && ws && counts_host, "null argument");
+    TH_REQUIRE(ws_bytes >= th_marching_cubes_workspace_bytes(X, Y, Z), "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    long long* cnt = (long long*)((char*)ws + th_mc_ws(X, Y, Z));
+    TH_TRY(th_mc_count_launch(cube, X, Y, Z, iso, ws, th_mc_ws(X, Y, Z), cnt, s));
+    long long h[2];
+    TH_HIP(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, s));
+    TH_HIP(hipStreamSynchronize(s));
+    counts_host[0] = h[0]; counts_host[1] = h[1];
+    return 0;
+}
+
+int th_marching_cubes_range(th_ctx* c, const void* ws, int X, int Y, int Z, int x, int64_t* prefix_host, th_stream stream) {
+    TH_REQUIRE(c && ws && prefix_host && x >= 0 && x <= X, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    long long* cnt = (long long*)((char*)ws + th_mc_ws(X, Y, Z)) + 4;
+    TH_TRY(th_mc_prefix_launch(ws, X, Y, Z, x, cnt, s));
+    long long h[2];
+    TH_HIP(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, s));
+    TH_HIP(hipStreamSynchronize(s));
+    prefix_host[0] = h[0]; prefix_host[1] = h[1];
+    return 0;
+}
+
+int th_marching_cubes_emit(th_ctx* c, const float* cube, int X, int Y, int Z, float iso, const void* ws, int x0, int x1,
+                           const double* scale_host, const double* origin_host, double* verts, int32_t* tris,
+                           th_stream stream) {
+    TH_REQUIRE(c && cube && ws && scale_host && origin_host && verts && tris, "null argument");
+    return th_mc_emit_launch(cube, X, Y, Z, iso, ws, x0, x1, scale_host, origin_host, verts, tris, (hipStream_t)stream);
+}
+
 size_t th_smpl_workspace_bytes(int n_verts) { return th_smpl_ws(n_verts); }
 
 int th_smpl_lbs(th_ctx* c, const th_smpl_model* m, const float* pose_aa, const float* rot, const double* beta,
@@ -647,7 +689,7 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
 // stage A only and leave the counts on their way to host_pinned[16..]; 2: stage A already ran into this workspace.
 static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long long P, bool ray_mode, ThArena& ar,
                         float** raw_out, const uint8_t** mask_out, int64_t* stats_host, hipStream_t s, int prepass = 0,
-                        int slot = 0) {
+                        int slot = 0, const int32_t** ray_hit_out = nullptr) {
     const int R = ps.R, S = ps.S, V = f->V;
     const bool compact = f->map_channels == TH_MAP_COMPACT;
     const int f_ld = compact ? 272 : 384;
@@ -679,7 +721,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         TH_HIP(hipStreamWaitEvent(s, c->prepass[slot].ev, 0));      // the prepass may have run on another stream
         TH_HIP(hipEventSynchronize(c->prepass[slot].ev));
     } else {
-    ProfScope* sc = new ProfScope(pf, TH_PROF_HULL, s);
+    ProfScope sc_hull(pf, TH_PROF_HULL, s);          // (RAII: an early error return closes the span)
     const bool no_hull = f->hull_thresh < 0.f;   // Renderer.render (:486-498): every sample shaded, RGB everywhere
     if (no_hull) {
         TH_HIP(hipMemsetAsync(info, 0, 16 * 4, s));
@@ -700,7 +742,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         TH_TRY(th_compact_mask(mask, P, idx, info + 2, cws, cws_b, s));
     }
     // (raw is NOT cleared: its consumers read it through the mask -- 268 MB of memset + dense re-read saved per frame)
-    delete sc;
+    sc_hull.close();
     if (prepass == 1) {
         TH_HIP(hipMemcpyAsync(c->host_pinned + 16 + 4 * slot, info, 4 * 4, hipMemcpyDeviceToHost, s));
         if (!c->prepass[slot].ev) TH_HIP(hipEventCreateWithFlags(&c->prepass[slot].ev, hipEventDisableTiming));
@@ -745,6 +787,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     }
     *raw_out = raw;
     *mask_out = mask;
+    if (ray_hit_out) *ray_hit_out = ray_mode ? ray_hit : nullptr;
     return 0;
 }
 
@@ -777,9 +820,10 @@ int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* r
         t.valid = false;                              // consumed, or stale for this workspace
         if (t.rays == (const void*)rays->ray_o && t.R == R && t.S == S) slot = k;
     }
-    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, stats_host, s, slot >= 0 ? 2 : 0, slot >= 0 ? slot : 0));
+    const int32_t* ray_hit = nullptr;
+    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, stats_host, s, slot >= 0 ? 2 : 0, slot >= 0 ? slot : 0, &ray_hit));
     ProfScope sc(prof_of(c), TH_PROF_COMPOSITE, s);
-    TH_TRY(th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, mask, s));
+    TH_TRY(th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, mask, s, ray_hit));
     const int snap = th_range_snapshot(c, stream);
     TH_REQUIRE(snap >= 0, "range snapshot failed");
     if (stats_host) stats_host[2] = snap;

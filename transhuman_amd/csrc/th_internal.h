@@ -325,7 +325,7 @@ int th_scatter_raw_launch(const float* raw_c, const int32_t* sel, int P, int rgb
 // k_composite.hip
 // mask (optional, uint8 per sample): raw is only read where mask != 0, elsewhere it counts as zero
 int th_composite_launch(const float* raw, const float* z, const ThPointSrc& ps, int white, float* rgb, float* acc,
-                        float* depth, float* wout, const uint8_t* mask, hipStream_t s);
+                        float* depth, float* wout, const uint8_t* mask, hipStream_t s, const int32_t* ray_hit = nullptr);
 int th_view_embed_launch(const float* d, int R, int res, float* out, hipStream_t s);
 // k_vit.hip
 size_t th_vit_ws(int V, int N, int dim, int heads);
@@ -339,6 +339,14 @@ int th_smpl_launch(const th_smpl_model& m, const float* pose_aa, const float* R,
 // k_rays.hip
 int th_gen_rays_launch(const float* K, const float* R, const float* T, const float* bounds, int H, int W, float* ray_o,
                        float* ray_d, float* near_out, float* far_out, uint8_t* mask, hipStream_t s);
+// k_mcubes.hip
+size_t th_mc_ws(int X, int Y, int Z);
+int th_mc_count_launch(const float* cube, int X, int Y, int Z, float iso, void* ws, size_t ws_bytes, long long* counts_dev,
+                       hipStream_t s);
+int th_mc_emit_launch(const float* cube, int X, int Y, int Z, float iso, const void* ws, int x0, int x1, const double* scale,
+                      const double* origin, double* verts, int* tris, hipStream_t s);
+int th_mc_prefix_launch(const void* ws, int X, int Y, int Z, int x, long long* out_dev, hipStream_t s);
+int th_bound_mask_launch(const int32_t* corners_xy /* host [8][2] */, int H, int W, uint8_t* mask, hipStream_t s);
 // k_encoder.hip
 int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
                               const int* dims, int V, int H, int W, const float* wc, const float* bc, float* out,

@@ -118,6 +118,61 @@ class ImageGatherer:
         return img
 
 
+class TokenExchange:
+    """TransHE (the ViT over the N_c tokens, vision_transformer.py:371-383) computed by ONE rank per frame instead
+    of by every rank: frame j belongs to rank j % world, which paints / groups / runs the ViT and broadcasts the
+    [V, N_c, 192] tokens (1.15 MB at N_c = 500) -- the other ranks skip that work for frame j.  Ray sharding leaves
+    the per-frame constants replicated; of those the ViT is the one piece whose OUTPUT is small, so it is the one
+    worth moving over xGMI (the 0.82 GB feature map is not: recomputing its 0.8 ms encoder is cheaper than any
+    exchange).  At N = 8 a rank runs the ViT for every 8th frame only.
+
+    All ranks see the frames in the same order, so the broadcast roots agree without negotiation.  The collective
+    has its own communicator (never queued behind the image gather of the render stream) and is issued from
+    whatever stream is current -- Renderer.render_sequence calls it from its side stream, i.e. under the shading of
+    the previous frame, ``lookahead`` frames ahead of use.
+
+    ``emulate=(world, rank)`` (one GPU, no process group): the owner test is applied, non-owned frames re-use the
+    last tokens this rank computed -- the per-rank WORK of an N-rank job for timing, not its image."""
+
+    def __init__(self, world=None, rank=None, group=None, emulate=None):
+        self.emulate = emulate
+        if emulate is not None:
+            self.world, self.rank = emulate
+            self.group = None
+        else:
+            import torch.distributed as dist
+            self.world = dist.get_world_size() if world is None else world
+            self.rank = dist.get_rank() if rank is None else rank
+            self.group = dist.new_group() if group is None else group
+        self.frame = 0
+        self.computed = 0           # frames whose tokens this rank produced itself
+        self._last = None
+
+    def owner(self, j):
+        return j % self.world
+
+    def __call__(self, compute, shape, device, dtype=torch.float32):
+        """tokens of the next frame: ``compute()`` on the owner, a receive buffer elsewhere, then the broadcast"""
+        j = self.frame
+        self.frame += 1
+        mine = self.owner(j) == self.rank
+        if mine:
+            tok = compute().contiguous()
+            assert tuple(tok.shape) == tuple(shape) and tok.dtype == dtype
+            self.computed += 1
+        if self.emulate is not None:
+            if mine or self._last is None:
+                if not mine:
+                    tok = compute().contiguous()
+                self._last = tok
+            return self._last
+        if not mine:
+            tok = torch.empty(tuple(shape), dtype=dtype, device=device)
+        import torch.distributed as dist
+        dist.broadcast(tok, src=self.owner(j), group=self.group)
+        return tok
+
+
 class DeferredSum:
     """Sum of one integer per rank (the whole-frame hit-ray count of the reference's R' <= 2400 rule,
     if_clight_renderer.py:551) that never stalls the render stream: the 8-byte all-reduce runs on its own

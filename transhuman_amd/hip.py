@@ -104,6 +104,15 @@ SYMBOLS = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "th_gen_rays": (C.c_int, [C.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, C.c_int, C.c_int, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "th_bound_mask": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "th_marching_cubes_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "th_marching_cubes_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                          C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
+    "th_marching_cubes_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(C.c_int64), C.c_void_p]),
+    "th_marching_cubes_emit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                         C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
     "th_smpl_workspace_bytes": (C.c_size_t, [C.c_int]),
     "th_smpl_lbs": (C.c_int, [C.c_void_p, C.POINTER(ThSmplModel), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -684,6 +693,63 @@ def gen_rays(K, R, T, bounds, H, W, device=None, compact=True):
     if not compact:
         return dict(ray_o=ray_o, ray_d=ray_d, near=near, far=far, mask_at_box=m)
     return dict(ray_o=ray_o[m], ray_d=ray_d[m], near=near[m], far=far[m], mask_at_box=m)
+
+
+def bound_corners_2d(bounds, K, pose):
+    """The eight corners of ``bounds`` [2,3] projected into the camera (K [3,3], pose = [R|T] [3,4]) and rounded
+    to integer pixels exactly like if_nerf_data_utils.py:33-53 (get_bound_corners, base_utils.project :178-187,
+    np.round(..).astype(int)); the dtype of the inputs is kept, as numpy would."""
+    import numpy as np
+    bounds, K, pose = np.asarray(bounds), np.asarray(K), np.asarray(pose)
+    mn, mx = bounds[0], bounds[1]
+    corners = np.array([[mn[0], mn[1], mn[2]], [mn[0], mn[1], mx[2]], [mn[0], mx[1], mn[2]], [mn[0], mx[1], mx[2]],
+                        [mx[0], mn[1], mn[2]], [mx[0], mn[1], mx[2]], [mx[0], mx[1], mn[2]], [mx[0], mx[1], mx[2]]])
+    xyz = np.dot(corners, pose[:, :3].T) + pose[:, 3:].T
+    xyz = np.dot(xyz, K.T)
+    xy = xyz[:, :2] / xyz[:, 2:]
+    return np.round(xy).astype(int)
+
+
+def bound_2d_mask(bounds, K, pose, H, W, device=None):
+    """th_bound_mask: get_bound_2d_mask (if_nerf_data_utils.py:49-62) -> uint8 [H, W] device tensor."""
+    import numpy as np
+    lib = load_library()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    c2 = np.ascontiguousarray(bound_corners_2d(bounds, K, pose), dtype=np.int32)
+    mask = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    _check(lib.th_bound_mask(ctx(dev), c2.ctypes.data_as(C.POINTER(C.c_int32)), H, W, _p(mask), _stream()))
+    return mask
+
+
+def marching_cubes(cube, iso, scale=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0), x_range=None):
+    """th_marching_cubes_*: mcubes.marching_cubes(cube, iso) on the device (if_mesh_renderer.py:103) with the
+    index -> world transform of :106-108 applied (vertex = index * scale + origin, float64).
+    cube: [X,Y,Z] fp32 device tensor.  -> (vertices float64 [nv,3], triangles int32 [nt,3]) device tensors.
+    x_range=(x0, x1): only the grid slab x0 <= x < x1 is emitted (multi-GPU z-slab style sharding); returns
+    (vertices, triangles, (v0, v1), (t0, t1)) where the slab filled rows [v0, v1) / [t0, t1) of the full arrays."""
+    lib = load_library()
+    c = _f32(cube)
+    assert c.dim() == 3
+    X, Y, Z = c.shape
+    dev = c.device
+    ws = _ws(lib.th_marching_cubes_workspace_bytes(X, Y, Z), dev)
+    counts = (C.c_int64 * 2)()
+    _check(lib.th_marching_cubes_count(ctx(dev), _p(c), X, Y, Z, float(iso), _p(ws), ws.numel(), counts, _stream()))
+    nv, nt = int(counts[0]), int(counts[1])
+    verts = torch.zeros((nv, 3), dtype=torch.float64, device=dev)
+    tris = torch.zeros((nt, 3), dtype=torch.int32, device=dev)
+    sc = (C.c_double * 3)(*[float(v) for v in scale])
+    og = (C.c_double * 3)(*[float(v) for v in origin])
+    x0, x1 = (0, X) if x_range is None else (int(x_range[0]), int(x_range[1]))
+    if nv > 0:
+        _check(lib.th_marching_cubes_emit(ctx(dev), _p(c), X, Y, Z, float(iso), _p(ws), x0, x1, sc, og,
+                                          _p(verts), _p(tris) if nt > 0 else _p(verts), _stream()))
+    if x_range is None:
+        return verts, tris
+    a, b = (C.c_int64 * 2)(), (C.c_int64 * 2)()
+    _check(lib.th_marching_cubes_range(ctx(dev), _p(ws), X, Y, Z, max(x0, 0), a, _stream()))
+    _check(lib.th_marching_cubes_range(ctx(dev), _p(ws), X, Y, Z, min(x1, X), b, _stream()))
+    return verts, tris, (int(a[0]), int(b[0])), (int(a[1]), int(b[1]))
 
 
 class SmplModel:

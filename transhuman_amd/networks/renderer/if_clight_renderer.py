@@ -101,7 +101,7 @@ class Renderer:
         return self._dev[key]
 
     # ---- per-frame constants ---------------------------------------------------------
-    def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True):
+    def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True, token_exchange=None):
         """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
 
         fused_encoder_tail=True (default): the ResNet stem runs through SpatialEncoder.trunk (K12 / K11), its tail
@@ -114,7 +114,9 @@ class Renderer:
         ([V,H,W,260]) and the lift is folded into the four layers that read those channels (alpha_res_0,
         rgb_res_0, rgb_res_1, reduction_layer: W' = [W_lat | W_col Wc], b' = b + W_col bc) -- a third less
         map/gather/staging traffic and 12 % fewer MLP MACs, same function.
-        All forms give the same tokens / pixels to fp32 rounding (tests/test_gpu_parity.py)."""
+        All forms give the same tokens / pixels to fp32 rounding (tests/test_gpu_parity.py).
+        token_exchange (multi-GPU, transhuman_amd.dist.TokenExchange): callable(compute, shape, device) that either
+        runs ``compute`` (paint -> group -> TransHE) here or receives the tokens from the rank that did."""
         cfg = get_cfg()
         assert cfg.time_steps == 1                                                  # :412
         t = 0
@@ -137,19 +139,30 @@ class Renderer:
             else:
                 map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2], cw, cb)
             scale = hip.feat_scale(enc.feat_scale(H, W), image_shape, dev)
-            grouped = hip.paint_group_nhwc(map_nhwc, batch["input_smpl_vertice"][t][0], cams, scale, viz,
-                                           enc.reduction_layer.weight, enc.reduction_layer.bias, off, mem,
-                                           color_w=cw if compact_map else None, color_b=cb if compact_map else None)
+
+            def group():
+                return hip.paint_group_nhwc(map_nhwc, batch["input_smpl_vertice"][t][0], cams, scale, viz,
+                                            enc.reduction_layer.weight, enc.reduction_layer.bias, off, mem,
+                                            color_w=cw if compact_map else None, color_b=cb if compact_map else None)
             pix_scale = scale
         else:
             holder_map, holder_scale, pixel_map, pixel_scale = enc(images)          # :399
             V, _, H, W = pixel_map.shape
-            grouped = hip.paint_group(holder_map, batch["input_smpl_vertice"][t][0], cams,
-                                      hip.feat_scale(holder_scale, image_shape, dev), viz, off, mem)
+
+            def group():
+                return hip.paint_group(holder_map, batch["input_smpl_vertice"][t][0], cams,
+                                       hip.feat_scale(holder_scale, image_shape, dev), viz, off, mem)
             map_nhwc = hip.nchw_to_nhwc(pixel_map)
             pix_scale = hip.feat_scale(pixel_scale, image_shape, dev)
-        self.last_grouped = grouped
-        tokens = self.net.ViT(grouped, self._pe_norm(V, dev), mask=None)            # :538
+
+        def make_tokens():
+            self.last_grouped = group()
+            return self.net.ViT(self.last_grouped, self._pe_norm(V, dev), mask=None)    # :538
+
+        if token_exchange is None:
+            tokens = make_tokens()
+        else:
+            tokens = token_exchange(make_tokens, (V, self.num_clusters, get_cfg().embed_size), dev)
         centres = hip.segment_mean(batch["tar_smpl_vertice_smplcoord"][0], off, mem)   # :543
         rot = hip.segment_mean_rot(batch["blend_mtx"][0], off, mem)                 # :544 + cross_transformer.py:185
         frame = hip.Frame(batch["tar_smpl_vertice"][0], batch["Rh"][0], batch["Th"][0], cams, pix_scale, map_nhwc,
@@ -158,6 +171,7 @@ class Renderer:
                           small_frame_rays=2400)
         # (range guard, hip.render_rays: the same constants again -- through the stock convolutions -- if the stem's
         # input left the fp16 range)
+        # (a rebuilt frame computes its own tokens: the exchange's frame counter must not advance twice)
         frame.rebuild = lambda: self.prepare_frame(batch, hull_thresh, fused_encoder_tail, compact_map)
         return frame
 
@@ -183,7 +197,7 @@ class Renderer:
         self.last_stats = stats
         return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
 
-    def render_sequence(self, batches, ray_slice=None, small_frame_rays=2400, lookahead=1):
+    def render_sequence(self, batches, ray_slice=None, small_frame_rays=2400, lookahead=1, token_exchange=None):
         """A stream of frames (free-viewpoint video / evaluation loops: the reference calls render_fast once per
         dataset item, run.py:96-118) as a two-stage software pipeline on two HIP streams:
 
@@ -198,7 +212,9 @@ class Renderer:
         order per frame.  Generator: yields render_fast's dict per batch; ``self.last_batch`` / ``self.last_frame`` /
         ``self.last_stats`` describe the frame just yielded.  ``lookahead`` frames are taken from ``batches`` ahead
         of the one being shaded; the iterator is advanced with the side stream current, so device work it issues
-        for a coming frame (ray generation, SMPL skinning, uploads) also runs under the shading of the current one."""
+        for a coming frame (ray generation, SMPL skinning, uploads) also runs under the shading of the current one.
+        ``token_exchange`` (transhuman_amd.dist.TokenExchange, multi-GPU): TransHE of frame j runs on rank j % world
+        only and its tokens are broadcast from the side stream."""
         import collections
         cfg = get_cfg()
         sl = slice(None) if ray_slice is None else ray_slice
@@ -216,7 +232,7 @@ class Renderer:
                 if V <= 4 and pts.R > 0:
                     hip.render_prepass(pts, b["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
                                        n_clusters=len(self.csr_offsets) - 1, slot=1 + j % nslots)
-                frame = self.prepare_frame(b)
+                frame = self.prepare_frame(b, token_exchange=token_exchange)
                 frame.c.small_frame_rays = small_frame_rays
                 ready = torch.cuda.Event()
                 ready.record(side)

@@ -1,11 +1,13 @@
-"""Mesh-reconstruction renderer: density cube over a voxel grid.
+"""Mesh-reconstruction renderer: density cube over a voxel grid, then the iso-surface.
 
 Drop-in for /root/reference/lib/networks/renderer/if_mesh_renderer.py
 (`Renderer.render`, :46-113).  The hull mask, DPaRF, pixel gather and the
 sigma branch of the MLP run through th_eval_sigma_grid; the reference also
 evaluates (and discards) RGB for sigma>0 voxels (:84-99) -- `cube` only needs
-sigma_raw, which is what is produced here.  Marching cubes (PyMCubes, :103)
-stays a host step outside the hot path: it runs only if `mcubes` is importable.
+sigma_raw, which is what is produced here.  Marching cubes (:103, PyMCubes in the reference) runs on the device too
+(th_marching_cubes_*, K13): the padded cube never leaves HBM before the mesh exists; `mesh` is a
+transhuman_amd.mesh.Mesh (vertices / faces / export(path) like the trimesh object the visualiser uses,
+lib/visualizers/if_nerf_mesh.py:25-35).
 """
 import os
 import sys
@@ -38,16 +40,13 @@ class Renderer(Base_Renderer):
         self.last_stats = stats
         if pts_slice is not None:
             return {"sigma": sigma}
-        cube = sigma.view(*sh[1:4]).detach().cpu().numpy()           # :99-100
-        cube = np.pad(cube, 10, mode="constant")                     # :101
-        mesh = None
-        try:                                                         # :103-109 (host, third-party)
-            import mcubes
-            import trimesh
-            vertices, triangles = mcubes.marching_cubes(cube, cfg.mesh_th)
-            can_bounds = batch["can_bounds"][0].cpu().numpy()
-            LB = (can_bounds[0] - 10 * np.array(cfg.voxel_size))[None, ...]
-            mesh = trimesh.Trimesh(vertices * np.array(cfg.voxel_size)[None, ...] + LB, triangles)
-        except ImportError:
-            pass
+        import torch
+        from transhuman_amd.mesh import Mesh
+        cube_d = torch.nn.functional.pad(sigma.view(*sh[1:4]), (10, 10, 10, 10, 10, 10))     # :99-101 (np.pad 10, zeros)
+        voxel = np.array(cfg.voxel_size, dtype=np.float64)
+        can_bounds = batch["can_bounds"][0].cpu().numpy().astype(np.float64)
+        LB = can_bounds[0] - 10 * voxel                                                        # :107
+        verts, tris = hip.marching_cubes(cube_d, cfg.mesh_th, scale=voxel, origin=LB)         # :103-108
+        mesh = Mesh(verts, tris.to(torch.int64))
+        cube = cube_d.detach().cpu().numpy()
         return {"cube": cube, "mesh": mesh}
