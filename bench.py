@@ -7,7 +7,7 @@
 
 A "step" is one pass of the hot path over one synthetic 512x512 frame with 64
 samples/ray, V=3 reference views, N_c=500 tokens (BASELINE.json configs[1]):
-encoder (stock torch/MIOpen, feeds the path) -> paint/group -> TransHE ->
+encoder (hand-written HIP too: K12 convolutions, K11 BatchNorm, K8 upsample/concat) -> paint/group -> TransHE ->
 DPaRF tables -> [sample placement, hull mask, compaction, DPaRF, pixel gather,
 per-point MLP, compositing] -> image.  All inputs are resident in HBM before
 the timed region.  With N>1 GPUs the frame's rays are dealt to ranks in
@@ -16,8 +16,8 @@ interleaved 8x8-pixel tiles, per-frame constants are recomputed on every rank
 one RCCL all_gather -- "strong" scaling: total work fixed, value = rays of the
 frame / max-over-ranks time.
 
-Rank 0 prints ONE JSON line; `roofline` is for the dominant stage (the per-point
-MLP on the fp32 MFMA pipe), measured live with HIP events on the launch stream;
+Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (the fused per-point MLP: fp32-class arithmetic
+as three fp16 MFMA products per MAC), measured live with HIP events on the launch stream;
 `cpu_baseline` is the CPU oracle (oracle/th_oracle.py, a port of the reference
 arithmetic) timed on this host on a bounded sample of the same frame.
 """
@@ -77,10 +77,10 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
         kernel = "per-point MLP stage (gemm_f32_mfma_kernel x14 + glue kernels), rank 0"
     # HBM bytes per full launch (524288 samples) from the committed PMC passes (profiles/r01_i_pmc_hbm.txt:
     # 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction applied); algorithmic = 524288 * (3 views * (1024 B stok + 2 * 1088 B f) + 256 B pe)
-    traffic = 6.32e9 if mlp_mode == 1 else None
+    traffic = 6.91e9 if mlp_mode == 1 else None
     return {"bound": "mfma", "kernel": kernel, "achieved": achieved / 1e12, "peak": peak / 1e12,
             "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "traffic_note": "HBM bytes per 524288-sample launch, rocprofv3 PMC (profiles/r01_i_pmc_hbm.txt); "
+            "traffic_note": "HBM bytes per 524288-sample launch, rocprofv3 PMC (profiles/r02_c_pmc_hbm.txt); "
                             "algorithmic 5.17e9",
             "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK,
             "algorithmic_flop_per_step": flops_step, "kernel_ms_per_step": stage_ms,
@@ -159,6 +159,151 @@ def cpu_baseline(batch, assign, n_samples, stride=64, gpu_img=None):
     return res
 
 
+def oracle_rays_check(batch_cpu, assign, n_samples, ray_idx, gpu_img, sd=None):
+    """max |rgb, acc| of the GPU image against the CPU oracle on the rays `ray_idx` of the frame (masked branch)"""
+    from oracle import th_oracle as O
+    from transhuman_amd.networks.cross_transformer import Network
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    if sd is None:
+        torch.manual_seed(0)
+        sd = synth.det_state_dict(Network().state_dict(), seed=0, sigma_bias=SIGMA_BIAS)
+    off, mem = synth.csr_from_assign(assign)
+    body = batch_cpu["tar_smpl_vertice_smplcoord"][0].numpy()
+    can = torch.from_numpy(body.astype(np.float64) * 1.02 + 0.001)
+    can_c = torch.stack([can[torch.as_tensor(mem[off[i]:off[i + 1]], dtype=torch.long)].mean(0)
+                         for i in range(len(off) - 1)])
+    sub = dict(batch_cpu)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        sub[k] = batch_cpu[k][:, ray_idx]
+    with torch.no_grad():
+        hol, pix = O.encoder_forward(sd, batch_cpu["input_imgs"][0][0])
+        o_out, _ = O.render_fast(sd, sub, hol, pix, off, mem, can_c, n_samples=n_samples, vit_depth=12, small_frame_rays=-1)
+    ref = torch.cat([o_out["rgb_map"][0], o_out["acc_map"][0][:, None]], dim=1).double()
+    d = gpu_img[ray_idx].detach().cpu().double()[:, :4] - ref
+    return {"rays": int(len(ray_idx)), "rays_hit": int((o_out["acc_map"][0] > 0).sum()),
+            "max_abs_rgb_acc": float(d.abs().max()),
+            "psnr_rgb_db": float(-10.0 * torch.log10(torch.clamp((d[:, :3] ** 2).mean(), min=1e-30)))}
+
+
+def time_steps(fn, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, out
+
+
+def run_extras(dev, net, args, H, W, V):
+    """The other configurations of BASELINE.json / SURVEY 8d, measured AFTER (outside) the timed region of the
+    headline run on the same device, each with its own oracle spot check: S-dense (every sample of a hit ray inside
+    the hull), C4 (N_c = 1500), C3 (orbit along the reference's gen_path_virt, rays generated on device) and C5
+    (sigma on a grid^3 voxel grid + marching cubes).  Short runs (3 frames each): secondary numbers."""
+    from oracle import th_oracle as O
+    from transhuman_amd import hip
+    from transhuman_amd.networks.renderer.if_clight_renderer import Renderer
+    from transhuman_amd.networks.renderer.if_mesh_renderer import Renderer as MeshRenderer
+    cfg = get_cfg()
+    extra = {}
+    rs = np.random.RandomState(3)
+
+    def frame_case(name, nc, dense):
+        cfg.num_class = nc
+        bc = synth.make_batch(H, W, V, seed=0, all_rays=True, dense=dense)
+        body = bc["tar_smpl_vertice_smplcoord"][0].numpy()
+        assign = load_assign(nc, body)
+        r = Renderer(net, vertex_can=body.astype(np.float64) * 1.02 + 0.001, pc2voxel_ind=assign)
+        b = synth.batch_to(bc, dev)
+        seq = r.render_sequence(itertools.repeat(b))
+        ms, out = time_steps(lambda: next(seq), 3, warmup=2)
+        img = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
+        hit = torch.nonzero(out["acc_map"][0] > 0).reshape(-1).cpu().numpy()
+        idx = np.sort(np.concatenate([rs.choice(hit, 192, replace=False), rs.choice(H * W, 64, replace=False)]))
+        chk = oracle_rays_check(bc, assign, args.samples, idx, img)
+        extra[name] = {"ms_per_frame": ms, "rays_per_s": H * W / ms * 1e3, "valid_samples": int(r.last_stats["valid_samples"]),
+                       "n_clusters": nc, "gpu_vs_oracle": chk}
+        seq.close()
+
+    frame_case("S_dense", args.nc, True)
+    frame_case("C4_nc1500", 1500, False)
+    cfg.num_class = args.nc
+
+    # C3: orbit (the reference's virtual camera path, rays on device)
+    bc = synth.make_batch(H, W, V, seed=0, all_rays=True)
+    body = bc["tar_smpl_vertice_smplcoord"][0].numpy()
+    assign = load_assign(args.nc, body)
+    r = Renderer(net, vertex_can=body.astype(np.float64) * 1.02 + 0.001, pc2voxel_ind=assign)
+    b = synth.batch_to(bc, dev)
+    verts = bc["tar_smpl_vertice"][0].numpy()
+    bounds = np.stack([verts.min(0), verts.max(0)]).astype(np.float32)
+    bounds[0, 2] -= 0.05; bounds[1, 2] += 0.05
+    K = np.array([[600.0 * W / 512, 0, W / 2], [0, 600.0 * W / 512, H / 2], [0, 0, 1]], np.float32)
+    from transhuman_amd.camera_path import gen_path_virt, synthetic_rig
+    centre = 0.5 * (bounds[0] + bounds[1]).astype(np.float64)
+    w2c = gen_path_virt(synthetic_rig(centre=tuple(centre.tolist())), render_views=60)
+
+    def frames():
+        i = 0
+        while True:
+            RT = w2c[i % 60]
+            rays = hip.gen_rays(K, RT[:3, :3].astype(np.float32), RT[:3, 3:].astype(np.float32), bounds, H, W, device=dev,
+                                compact=False)
+            sh = dict(b)
+            for k in ("ray_o", "ray_d", "near", "far"):
+                sh[k] = rays[k][None]
+            yield sh
+            i += 1
+    seq = r.render_sequence(frames())
+    ms, out = time_steps(lambda: next(seq), 6, warmup=2)
+    lb = r.last_batch
+    img = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
+    hit = torch.nonzero(out["acc_map"][0] > 0).reshape(-1).cpu().numpy()
+    idx = np.sort(np.concatenate([rs.choice(hit, min(192, len(hit)), replace=False), rs.choice(H * W, 64, replace=False)]))
+    bc2 = dict(bc)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        bc2[k] = lb[k].cpu()
+    extra["C3_orbit"] = {"ms_per_frame": ms, "rays_per_s": H * W / ms * 1e3, "camera_path": "gen_path_virt(21-camera rig, 60 views)",
+                         "hit_rays": int(r.last_stats["hit_rays"]), "gpu_vs_oracle": oracle_rays_check(bc2, assign, args.samples, idx, img)}
+    seq.close()
+
+    # C5: sigma grid + marching cubes
+    g = args.grid
+    mr = MeshRenderer(net, vertex_can=body.astype(np.float64) * 1.02 + 0.001, pc2voxel_ind=assign)
+    mb = dict(bc)
+    mb["pts"] = synth.make_grid_pts(bc, g)
+    mbd = synth.batch_to(mb, dev)
+    old_th = cfg.mesh_th
+    cfg.mesh_th = 0.5                      # sigma_raw of the synthetic weights is O(1) (the reference's 20 fits trained weights)
+    try:
+        ms, out = time_steps(lambda: mr.render(mbd), 2, warmup=1)
+        flat = mbd["pts"].reshape(-1, 3)
+        sig_ms, _ = time_steps(lambda: hip.eval_sigma_grid(net, mr.prepare_frame(mbd), flat), 2, warmup=0)
+        cube = out["cube"][10:-10, 10:-10, 10:-10]
+        # oracle on a sample of voxels near the surface + a few anywhere
+        nz = np.flatnonzero(cube.reshape(-1) != 0)
+        pick = np.sort(np.concatenate([rs.choice(nz, 1500, replace=False), rs.choice(g * g * g, 500, replace=False)]))
+        torch.manual_seed(0)
+        from transhuman_amd.networks.cross_transformer import Network
+        sd = synth.det_state_dict(Network().state_dict(), seed=0, sigma_bias=SIGMA_BIAS)
+        off, mem = synth.csr_from_assign(assign)
+        can = torch.from_numpy(body.astype(np.float64) * 1.02 + 0.001)
+        can_c = torch.stack([can[torch.as_tensor(mem[off[i]:off[i + 1]], dtype=torch.long)].mean(0) for i in range(len(off) - 1)])
+        with torch.no_grad():
+            hol, pix = O.encoder_forward(sd, bc["input_imgs"][0][0])
+            ref = O.render_sigma_grid(sd, mb, mb["pts"].reshape(-1, 3)[pick].reshape(1, -1, 1, 1, 3), hol, pix, off, mem, can_c)
+        d = np.abs(cube.reshape(-1)[pick] - ref.reshape(-1).numpy())
+        mesh = out["mesh"]
+        extra["C5_mesh"] = {"grid": g, "ms_per_frame": ms, "sigma_grid_ms": sig_ms, "voxels_per_s": g ** 3 / ms * 1e3,
+                            "valid_voxels": int(mr.last_stats["valid_samples"]), "mesh_vertices": int(mesh.vertices.shape[0]),
+                            "mesh_triangles": int(mesh.faces.shape[0]), "mesh_th": 0.5,
+                            "gpu_vs_oracle": {"voxels": int(len(pick)), "max_abs_sigma": float(d.max())}}
+    finally:
+        cfg.mesh_th = old_th
+    return extra
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +317,7 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--nc", type=int, default=500)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short post-run measurements of the other configurations")
     ap.add_argument("--cpu-stride", type=int, default=128)
     ap.add_argument("--mlp-mode", type=int, default=1, help="1 fused fp16-split MFMA kernel, 0 per-layer fp32 MFMA")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -262,8 +408,6 @@ def main():
             img = gatherer(local)
             if whole_frame_hits.result() <= 2400:
                 fr = renderer.last_frame if seq is not None else None
-                if fr is not None:
-                    fr.c.small_frame_rays = 1 << 30
                 out = renderer.render_fast(shard, frame=fr, small_frame_rays=1 << 30)
                 local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
                 img = gatherer(local)
@@ -315,7 +459,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 (fp16 hi/lo x3 MFMA emulation)" if args.mlp_mode == 1 else "f32",
             "data": "synthetic",
             "config": {
                 "workload": f"S-{args.workload}: synthetic capsule body (6890 verts), {H}x{W} rays, {args.samples} "
@@ -334,8 +478,17 @@ def main():
         }
         if emu:
             res["config"]["emulated_rank0_of"] = emu
+        if world == 1 and not emu:
+            # the reference's own call pattern (run.py:96-118 calls renderer.render_fast per item, no look-ahead):
+            # measured after the timed region on the same device
+            ms_rf, _ = time_steps(lambda: renderer.render_fast(shard), max(3, args.steps // 2), warmup=1)
+            res["render_fast_ms_per_step"] = ms_rf
+            res["render_fast_rays_per_s"] = R / ms_rf * 1e3
         if world == 1 and not args.no_cpu_baseline and not emu:
             res["cpu_baseline"] = cpu_baseline(batch_cpu, assign, args.samples, stride=args.cpu_stride, gpu_img=img)
+        if world == 1 and not args.no_extras and not args.no_cpu_baseline and not emu and args.workload == "real":
+            res["extra"] = run_extras(dev, net, args, H, W, V)
+            cfg.num_class = args.nc
     else:
         res = None
     finish(dist_on, res)

@@ -298,3 +298,113 @@ def test_white_background_vs_reference_golden(hip, gpu, net):
     assert maxdiff(out["rgb_map"][0].cpu(), g["rgb"]) < 1e-4 and maxdiff(out["acc_map"][0].cpu(), g["acc"]) < 1e-4
     black = (g["rgb"].abs().sum(-1) == 0)
     assert float(out["rgb_map"][0].cpu()[black].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------
+# full-size checks (BASELINE.json configs 4 and 5 at their own sizes)
+# ---------------------------------------------------------------------------
+def _oracle_frame_bits(b, sd, assign):
+    off, mem = csr(assign)
+    with torch.no_grad():
+        hol, pix = O.encoder_forward(sd, b["input_imgs"][0][0])
+    return hol, pix, off, mem, can_centres64(assign)
+
+
+def test_full_size_frame_nc1500_properties_and_oracle_sample(hip, gpu, net):
+    """C4 at full size: 512 x 512 rays x 64 samples, V = 3, N_c = 1500 with the reference's own (ragged) kmeans
+    file.  Size-independent properties over the whole frame + the CPU oracle on a sample of its rays."""
+    from transhuman_amd.config import get_cfg
+    from transhuman_amd.networks.renderer import if_clight_renderer
+    from util import real_assign
+    cfg = get_cfg()
+    cfg.N_samples, cfg.num_class = 64, 1500
+    assign = real_assign(1500)
+    bc = synth.make_batch(512, 512, 3, seed=0, all_rays=True)
+    b = synth.batch_to(bc, gpu)
+    r = if_clight_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=assign)
+    out = r.render_fast(b, is_train=False)
+    st = dict(r.last_stats)
+    rgb, acc = out["rgb_map"][0], out["acc_map"][0]
+    assert rgb.shape == (512 * 512, 3) and st["hit_rays"] > 30000 and st["valid_samples"] > 1500000 and st["unmasked"] == 0
+    assert torch.isfinite(rgb).all() and torch.isfinite(acc).all()
+    assert float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5 and float(rgb.min()) >= 0.0
+    P = hip.Points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], 64)
+    m, hit = hip.hull_mask(P, b["tar_smpl_vertice"][0])
+    assert int(hit.sum()) == st["hit_rays"] and int(m.sum()) == st["valid_samples"]
+    assert float(acc[~hit].abs().max()) == 0.0 and float(rgb[~hit].abs().max()) == 0.0      # misses are exactly zero
+    again = r.render_fast(b, is_train=False)
+    assert torch.equal(again["rgb_map"], out["rgb_map"]) and torch.equal(again["acc_map"], out["acc_map"])   # run to run
+    # ray-sharded == whole frame, bit for bit (8 ranks' shards)
+    from transhuman_amd.dist import shard_ray_indices
+    frame = r.prepare_frame(b)
+    idx = shard_ray_indices(512, 512, 8, 5, tile_major=True).to(gpu)
+    sh = dict(b)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        sh[k] = b[k][:, idx].contiguous()
+    whole = r.render_fast(b, frame=frame, small_frame_rays=-1)
+    part = r.render_fast(sh, frame=frame, small_frame_rays=-1)
+    assert torch.equal(part["rgb_map"][0], whole["rgb_map"][0][idx])
+    # oracle on 96 rays (64 of them hits)
+    rs = np.random.RandomState(11)
+    hits = torch.nonzero(hit).reshape(-1).cpu().numpy()
+    pick = np.sort(np.concatenate([rs.choice(hits, 64, replace=False), rs.choice(512 * 512, 32, replace=False)]))
+    sd = make_sd()
+    hol, pix, off, mem, cc = _oracle_frame_bits(bc, sd, assign)
+    sub = dict(bc)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        sub[k] = bc[k][:, pick]
+    with torch.no_grad():
+        ref, _ = O.render_fast(sd, sub, hol, pix, off, mem, cc, n_samples=64, small_frame_rays=-1)
+    assert maxdiff(rgb[pick].cpu(), ref["rgb_map"][0]) < 1e-4 and maxdiff(acc[pick].cpu(), ref["acc_map"][0]) < 1e-4
+    assert float(ref["acc_map"].max()) > 0.05
+
+
+def test_full_size_sigma_grid_256_and_mesh(hip, gpu, net):
+    """C5 at full size: sigma on a 256^3 grid (16.8 M voxels) + marching cubes.  Properties (zero exactly outside the
+    hull, invariance to how the voxels are split into passes / shards, closed mesh inside the box) + the CPU oracle on
+    a sample of voxels."""
+    from transhuman_amd.config import get_cfg
+    from transhuman_amd.networks.renderer import if_mesh_renderer
+    cfg = get_cfg()
+    cfg.N_samples, cfg.num_class = 64, 500
+    assign = synth_assign(500)
+    bc = synth.make_batch(64, 64, 3, seed=0)
+    bc["pts"] = synth.make_grid_pts(bc, 256)
+    b = synth.batch_to(bc, gpu)
+    r = if_mesh_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=assign)
+    old = cfg.mesh_th
+    cfg.mesh_th = 0.5
+    try:
+        out = r.render(b)
+    finally:
+        cfg.mesh_th = old
+    cube = torch.from_numpy(out["cube"][10:-10, 10:-10, 10:-10])
+    assert cube.shape == (256, 256, 256) and torch.isfinite(cube).all()
+    flat = b["pts"].reshape(-1, 3)
+    m, _ = hip.hull_mask(hip.Points(pts=flat), b["tar_smpl_vertice"][0])
+    m = m.view(-1).cpu()
+    assert int(m.sum()) == r.last_stats["valid_samples"] > 200000
+    assert float(cube.reshape(-1)[~m].abs().max()) == 0.0
+    # a shard (every 8th run of 4096 voxels, like bench.py deals them) equals the full evaluation bit for bit
+    frame = r.prepare_frame(b)
+    run = torch.arange(256 ** 3, device=gpu) // 4096
+    mine = torch.nonzero(run % 8 == 3).reshape(-1)
+    part = r.render(b, frame=frame, pts_slice=mine)["sigma"]
+    full = r.render(b, frame=frame, pts_slice=torch.arange(256 ** 3, device=gpu))["sigma"]
+    assert torch.equal(part, full[mine])
+    mesh = out["mesh"]
+    assert mesh.vertices.shape[0] > 10000 and mesh.is_watertight
+    v = mesh.vertices.cpu().numpy()
+    box = bc["can_bounds"][0].numpy().astype(np.float64)
+    voxel = np.array(cfg.voxel_size)
+    lo = box[0] - 10 * voxel
+    assert (v >= lo - 1e-9).all() and (v <= lo + voxel * 275 + 1e-9).all()
+    # oracle on 1200 voxels (1000 inside the hull)
+    rs = np.random.RandomState(5)
+    ins = np.flatnonzero(m.numpy())
+    pick = np.sort(np.concatenate([rs.choice(ins, 1000, replace=False), rs.choice(256 ** 3, 200, replace=False)]))
+    sd = make_sd()
+    hol, pix, off, mem, cc = _oracle_frame_bits(bc, sd, assign)
+    with torch.no_grad():
+        ref = O.render_sigma_grid(sd, bc, bc["pts"].reshape(-1, 3)[pick].reshape(1, -1, 1, 1, 3), hol, pix, off, mem, cc)
+    assert maxdiff(cube.reshape(-1)[pick], ref.reshape(-1)) < 1e-4

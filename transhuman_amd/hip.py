@@ -267,6 +267,8 @@ def _sync_weights(mod, kind):
     parameter list and the addresses of its first / last tensor are read (25 us instead of 0.9 ms for the
     310-tensor Network: the walk used to leave the GPU idle in front of the per-sample stage)."""
     import weakref
+    if not torch.cuda.is_available():
+        raise HipError("no HIP device visible: the TransHuman hot path needs an MI355X (gfx950); there is no CPU fallback")
     ent = _param_lists.get(id(mod))
     if ent is None or ent[0]() is not mod or ent[2] >= 256:
         ent = [weakref.ref(mod), list(mod.parameters()), 0]
@@ -842,12 +844,14 @@ def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=240
     points._prepass_pending = True          # only THIS Points object (it keeps the ray tensors alive) may consume it
 
 
-def render_rays(net, frame, points, white_bkgd=False, defer_guard=False):
+def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_frame_rays=None):
     """th_render_rays: rays -> (rgb [R,3], acc [R], depth [R], stats).
     Range guard: the frame's snapshot of the split-arithmetic maxima is read back after the call (a host wait for
     the frame) and, if a tensor left the resolvable range, the frame is rendered again on the fp32 path.
     ``defer_guard=True`` returns a fifth value, a callable ``check() -> bool`` (True = clean), instead: a frame
-    pipeline calls it after queuing the next frame so the host never idles the device."""
+    pipeline calls it after queuing the next frame so the host never idles the device.
+    ``small_frame_rays``: the R' threshold of if_clight_renderer.py:551 for THIS call (applied to a copy of the
+    frame descriptor; None = the frame's own value)."""
     lib = load_library()
     _sync_weights(net, "mlp")
     dev = frame.verts.device
@@ -858,7 +862,11 @@ def render_rays(net, frame, points, white_bkgd=False, defer_guard=False):
     if R == 0:                                   # empty ray list: nothing to launch (zero-size tensors have no address)
         st0 = dict(hit_rays=0, valid_samples=0, unmasked=0)
         return (rgb, acc, dep, st0, lambda: True) if defer_guard else (rgb, acc, dep, st0)
-    need = lib.th_render_workspace_bytes(C.byref(frame.c), R, points.S)
+    fc = frame.c
+    if small_frame_rays is not None and int(small_frame_rays) != fc.small_frame_rays:
+        fc = ThFrame.from_buffer_copy(frame.c)
+        fc.small_frame_rays = int(small_frame_rays)
+    need = lib.th_render_workspace_bytes(C.byref(fc), R, points.S)
     if getattr(points, "_prepass_pending", False) and points._prepass_keep[1].numel() >= need:
         points._prepass_pending = False
         ws = points._prepass_keep[1]                        # the workspace its prepass ran in
@@ -866,7 +874,7 @@ def render_rays(net, frame, points, white_bkgd=False, defer_guard=False):
         ws = _cached_ws(need, dev)
         _check(lib.th_render_prepass_drop(ctx(dev), _p(ws)))  # a token queued there for other (possibly freed) rays
     stats = (C.c_int64 * 4)()
-    _check(lib.th_render_rays(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(rgb), _p(acc), _p(dep), int(white_bkgd),
+    _check(lib.th_render_rays(ctx(dev), C.byref(fc), C.byref(points.c), _p(rgb), _p(acc), _p(dep), int(white_bkgd),
                               _p(ws), ws.numel(), stats, _stream()))
     st = dict(hit_rays=stats[0], valid_samples=stats[1], unmasked=stats[3])
     slot = int(stats[2])
@@ -875,8 +883,11 @@ def render_rays(net, frame, points, white_bkgd=False, defer_guard=False):
     if not _guard(dev, slot):
         if conv_fallback and getattr(frame, "rebuild", None) is not None:
             frame = frame.rebuild()                  # frame constants again, through the stock convolutions
+            keep_sfr = fc.small_frame_rays
+            fc = ThFrame.from_buffer_copy(frame.c)
+            fc.small_frame_rays = keep_sfr
         _check(lib.th_render_prepass_drop(ctx(dev), _p(ws)))
-        _check(lib.th_render_rays(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(rgb), _p(acc), _p(dep),
+        _check(lib.th_render_rays(ctx(dev), C.byref(fc), C.byref(points.c), _p(rgb), _p(acc), _p(dep),
                                   int(white_bkgd), _p(ws), ws.numel(), stats, _stream()))
         st = dict(hit_rays=stats[0], valid_samples=stats[1], unmasked=stats[3])
     return rgb, acc, dep, st

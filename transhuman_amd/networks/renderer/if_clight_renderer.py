@@ -183,6 +183,7 @@ class Renderer:
         Without a ready ``frame`` the ray-only stage (hull mask, compaction) is queued first, then the
         per-frame constants, then the shading: the sample count is on the host by the time it is needed."""
         cfg = get_cfg()
+        self._check_sampling_options(cfg)
         sl = slice(None) if ray_slice is None else ray_slice
         pts = hip.Points(batch["ray_o"][0][sl], batch["ray_d"][0][sl], batch["near"][0][sl], batch["far"][0][sl],
                          n_samples=cfg.N_samples)
@@ -192,10 +193,45 @@ class Renderer:
                 hip.render_prepass(pts, batch["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
                                    n_clusters=len(self.csr_offsets) - 1)
             frame = self.prepare_frame(batch)
-            frame.c.small_frame_rays = small_frame_rays
-        rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd))
+        # (the threshold applies to THIS call whether or not the frame constants were handed in)
+        rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
+                                                 small_frame_rays=small_frame_rays)
         self.last_stats = stats
         return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
+
+    def _check_sampling_options(self, cfg):
+        """The reference jitters the sample depths when cfg.perturb > 0 and the network is in train() mode
+        (:276-283) and adds noise to sigma when cfg.raw_noise_std > 0 (nerf_net_utils.py:39-46).  run.py sets
+        cfg.perturb = 0 for every inference entry point (run.py:22,68,123) although it keeps network.train(); the
+        YAML default is perturb: 1.  Neither randomisation exists in the HIP path: refuse instead of silently
+        rendering deterministic samples."""
+        if float(getattr(cfg, "perturb", 0.0)) > 0.0 and self.net.training:
+            raise NotImplementedError("cfg.perturb > 0 with the network in train() mode asks for stratified depth jitter "
+                                      "(if_clight_renderer.py:276-283): training-time sampling is outside this inference "
+                                      "path -- set cfg.perturb = 0 like run.py:22,68,123 do")
+        if float(getattr(cfg, "raw_noise_std", 0.0)) > 0.0:
+            raise NotImplementedError("cfg.raw_noise_std > 0 (density noise, nerf_net_utils.py:39-46) is a training option")
+
+    def render_fast_sharded(self, batch, my_idx, gatherer, hit_sum, frame=None):
+        """One rank's part of a ray-sharded frame with the reference's WHOLE-FRAME R' <= 2400 rule (:551): the shard
+        is rendered in the (overwhelmingly common) masked mode, the per-rank hit-ray counts are summed
+        (``hit_sum``: transhuman_amd.dist.DeferredSum, its own communicator / stream) while the image is assembled
+        (``gatherer``: dist.ImageGatherer over ``my_idx``), and only if the frame total is <= 2400 the shard is
+        rendered again un-masked and gathered again -- every sharded caller gets the reference's branch.
+        -> dense [R, 5] image (rgb | acc | depth) on every rank."""
+        sh = dict(batch)
+        for k in ("ray_o", "ray_d", "near", "far"):
+            sh[k] = batch[k][:, my_idx].contiguous()
+        if frame is None:
+            frame = self.prepare_frame(batch)
+        out = self.render_fast(sh, frame=frame, small_frame_rays=-1)
+        hit_sum.start(self.last_stats["hit_rays"])
+        cat = lambda o: torch.cat([o["rgb_map"][0], o["acc_map"][0][:, None], o["depth_map"][0][:, None]], dim=1)
+        img = gatherer(cat(out))
+        if hit_sum.result() <= 2400:
+            out = self.render_fast(sh, frame=frame, small_frame_rays=1 << 30)
+            img = gatherer(cat(out))
+        return img
 
     def render_sequence(self, batches, ray_slice=None, small_frame_rays=2400, lookahead=1, token_exchange=None):
         """A stream of frames (free-viewpoint video / evaluation loops: the reference calls render_fast once per
@@ -217,6 +253,7 @@ class Renderer:
         only and its tokens are broadcast from the side stream."""
         import collections
         cfg = get_cfg()
+        self._check_sampling_options(cfg)
         sl = slice(None) if ray_slice is None else ray_slice
         it = iter(batches)
         lookahead = max(1, min(int(lookahead), 3))           # (th_render_prepass keeps at most 4 tokens)
@@ -233,7 +270,6 @@ class Renderer:
                     hip.render_prepass(pts, b["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
                                        n_clusters=len(self.csr_offsets) - 1, slot=1 + j % nslots)
                 frame = self.prepare_frame(b, token_exchange=token_exchange)
-                frame.c.small_frame_rays = small_frame_rays
                 ready = torch.cuda.Event()
                 ready.record(side)
             return b, pts, frame, ready
@@ -274,8 +310,8 @@ class Renderer:
             if not check() or epoch != hip.range_epoch(dev):
                 if hip.conv_fallback:
                     frame = frame.rebuild()
-                    frame.c.small_frame_rays = small_frame_rays
-                rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd))
+                rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
+                                                         small_frame_rays=small_frame_rays)
             self.last_stats, self.last_frame, self.last_batch = stats, frame, cur
             return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
 
@@ -290,7 +326,7 @@ class Renderer:
             fence.record(main)
             epoch = hip.range_epoch(dev)
             rgb, acc, depth, stats, check = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
-                                                            defer_guard=True)
+                                                            defer_guard=True, small_frame_rays=small_frame_rays)
             side.wait_event(fence)
             pull()
             shaded.append((rgb, acc, depth, stats, frame, cur, pts, check, epoch))
@@ -303,6 +339,7 @@ class Renderer:
         """:486-498 -- no hull mask, every sample shaded, RGB everywhere.
         Forward only (the HIP kernels carry no autograd)."""
         cfg = get_cfg()
+        self._check_sampling_options(cfg)
         frame = self.prepare_frame(batch, hull_thresh=-1.0)
         pts = hip.Points(batch["ray_o"][0], batch["ray_d"][0], batch["near"][0], batch["far"][0],
                          n_samples=cfg.N_samples)
