@@ -349,8 +349,9 @@ def test_render_sequence_equals_per_frame_render(hip, gpu, net):
         torch.cuda.synchronize()
         for i in range(len(frames)):
             for k in ("rgb_map", "acc_map", "depth_map"):
-                # (frame constants are recomputed: MIOpen conv summation order, like test_prepass_equals_plain_render)
-                assert maxdiff(got[i][k].cpu(), ref[i][k].cpu()) < 1e-5, (rep, i, k)
+                # (frame constants are recomputed on the side stream: every kernel of the path -- K12 convolutions, K11
+                # BatchNorm with fixed-order partial sums, K8, TransHE -- is deterministic, so the images are identical)
+                assert torch.equal(got[i][k], ref[i][k]), (rep, i, k)
     assert list(r.render_sequence(iter([]))) == []
 
 
@@ -614,7 +615,7 @@ def test_prepass_equals_plain_render(hip, gpu, net):
     assert torch.equal(rgb0, rgb2) and st0 == st2
     auto = r.render_fast(b)                               # prepass -> prepare_frame -> shading
     assert r.last_stats == st0
-    assert maxdiff(auto["rgb_map"][0].cpu(), rgb0.cpu()) < 1e-5    # (frame constants recomputed: MIOpen conv order)
+    assert torch.equal(auto["rgb_map"][0], rgb0)          # (frame constants recomputed: deterministic kernels end to end)
 
 
 def test_weight_updates_are_picked_up(hip, gpu, net):

@@ -464,8 +464,15 @@ __device__ __forceinline__ const uint4* wslice(const FusedLayer& L, int wave, in
     return L.w + ((long long)wave * L.KB + kb0) * (ct * 2 * 64);
 }
 
+// FM_NUM_VGPR (build experiment): cap the architectural VGPRs so that the wave's unified allocation (VGPRs + AGPRs)
+// stays below 512 and a low-register kernel of another stream can become co-resident on the same SIMDs
+#ifdef FM_NUM_VGPR
+#define FM_VGPR_ATTR __attribute__((amdgpu_num_vgpr(FM_NUM_VGPR)))
+#else
+#define FM_VGPR_ATTR
+#endif
 template <int V, int FM>
-__global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
+__global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedParams P) {
     using FL = FLay<FM>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* abuf = lds;
@@ -488,6 +495,8 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
         dbg_t = clock64();
     }
 
+    // view means multiply by 1/V (one rounding away from torch.mean's division; 10 VALU instructions less per value)
+    constexpr float inv_v = 1.0f / (float)V;
     // range guard: launch-wide maxima as they stood when this tile started (uniform -> scalar loads)
     unsigned rmax = 0u;
     const unsigned seen_s = P.range ? P.range[TH_RANGE_S] : 0u, seen_p = P.range ? P.range[TH_RANGE_P] : 0u,
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
             float a = acc2[c][0][e];
 #pragma unroll
             for (int r = 1; r < V; ++r) a = a + acc2[c][r][e];
-            m[e] = a / (float)V;
+            m[e] = a * inv_v;
         }
         store_tile_h<STR256>(m, myrow, wave * 64 + c * 32, mbuf, mbuf + 32 * STR256, lane, rmax);
 #pragma unroll
@@ -900,7 +909,7 @@ __global__ __launch_bounds__(256, 1) void mlp_fused_kernel(FusedParams P) {
                 float a = acc2[0][0][e] + acc2[1][0][e];
 #pragma unroll
                 for (int r = 1; r < V; ++r) a = a + (acc2[0][r][e] + acc2[1][r][e]);
-                m[e] = a / (float)V;
+                m[e] = a * inv_v;
             }
             store_tile_h<STR128>(m, myrow, wave * 32, f4_hi, f4_lo, lane, rmax);
             range_commit(P.range, TH_RANGE_F4, seen_4, rmax);

@@ -1,4 +1,4 @@
-"""SpatialEncoder -- feeds the hot path, itself outside the HIP scope.
+"""SpatialEncoder -- feeds the hot path.
 
 Mirrors /root/reference/lib/networks/encoder.py:50-155: torchvision-ResNet18
 stem (conv1/bn1/relu, maxpool, layer1, layer2), each latent bilinearly
@@ -7,7 +7,12 @@ upsampled (align_corners=True) to HxW, concatenated with a 1x1 colour lift
 ``holder_feat_map``.  torchvision is not installed in this image, so the trunk
 is restated here with torchvision's parameter names (``encoder.model.*``,
 including the never-executed layer3/layer4) to stay ``strict=True``
-checkpoint-compatible.  Runs as stock PyTorch-ROCm (MIOpen) ops.
+checkpoint-compatible.
+
+On a GPU the stem runs as hand-written HIP end to end (``trunk``: K12 fp16-split MFMA convolutions + max pooling,
+K11 train-mode BatchNorm / ReLU / residual), and Renderer.prepare_frame replaces the tail of ``forward`` (three
+upsamples + colour lift + concat + reduction) by K8 / th_paint_group_nhwc; ``forward`` itself (the reference's op
+order, stock torch modules for the tail) is kept for callers that want the two NCHW maps and for the CPU tests.
 """
 import os
 
