@@ -364,16 +364,24 @@ def test_render_ray_sharding_equals_full(hip, gpu, net):
     idx = torch.arange(64 * 64, device=gpu)
     # shards of <= 2400 hit rays would fall into the reference's un-masked branch (:551), which also
     # shades out-of-hull samples; sharded rendering therefore pins the switch off for every shard
-    frame.c.small_frame_rays = -1
-    full2 = r.render_fast(b, frame=frame)["rgb_map"][0]
+    full2 = r.render_fast(b, frame=frame, small_frame_rays=-1)["rgb_map"][0]
     parts2 = torch.zeros_like(full2)
     for rank in range(2):
         sel = idx[rank::2]
         bb = dict(b)
         for k in ("ray_o", "ray_d", "near", "far"):
             bb[k] = b[k][:, sel]
-        parts2[sel] = r.render_fast(bb, frame=frame)["rgb_map"][0]
+        parts2[sel] = r.render_fast(bb, frame=frame, small_frame_rays=-1)["rgb_map"][0]
     assert torch.equal(parts2, full2)
+    # the threshold is a property of the CALL, also when the frame constants are handed in: the default
+    # 2400 puts the same shard into the reference's un-masked branch
+    bb = dict(b)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        bb[k] = b[k][:, idx[0::2]]
+    r.render_fast(bb, frame=frame)
+    assert r.last_stats["unmasked"] == 1
+    r.render_fast(bb, frame=frame, small_frame_rays=-1)
+    assert r.last_stats["unmasked"] == 0
 
 
 def test_mesh_sigma_cube_vs_golden(hip, gpu, net):
@@ -526,14 +534,13 @@ def test_generated_rays_render(hip, gpu, net):
     # dense form (every pixel a ray; rays that miss the box carry near = far = 0 and render as background): the image of
     # the masked list scattered into the frame, with the same frame constants
     frame = r.prepare_frame(bb)
-    frame.c.small_frame_rays = -1
-    sparse = r.render_fast(bb, frame=frame)
+    sparse = r.render_fast(bb, frame=frame, small_frame_rays=-1)
     dense_rays = hip.gen_rays(cam["K"].astype(np.float32), cam["R"].astype(np.float32), cam["T"].astype(np.float32), bounds,
                               48, 48, device=gpu, compact=False)
     bd = dict(b)
     for k in ("ray_o", "ray_d", "near", "far"):
         bd[k] = dense_rays[k][None]
-    dense = r.render_fast(bd, frame=frame)
+    dense = r.render_fast(bd, frame=frame, small_frame_rays=-1)
     m = dense_rays["mask_at_box"]
     assert torch.equal(m, rays["mask_at_box"]) and 0 < int(m.sum()) < m.numel()
     for k in ("rgb_map", "acc_map", "depth_map"):

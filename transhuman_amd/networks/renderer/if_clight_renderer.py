@@ -190,8 +190,19 @@ class Renderer:
         if frame is None:
             V = batch["input_imgs"][0].reshape(-1, *batch["input_imgs"][0].shape[2:]).shape[0]
             if V <= 4 and pts.R > 0:
-                hip.render_prepass(pts, batch["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
-                                   n_clusters=len(self.csr_offsets) - 1)
+                # the ray-only stage (hull mask, compaction: ~10 launches, 0.85 ms) runs on a second stream beside the
+                # per-frame constants (encoder, paint, TransHE: ~110 latency-bound launches) instead of in front of them;
+                # th_render_rays waits for its event
+                dev = pts.ray_o.device
+                side = self._dev.get(("hull_stream", str(dev)))
+                if side is None:
+                    side = self._dev[("hull_stream", str(dev))] = torch.cuda.Stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    hip.render_prepass(pts, batch["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
+                                       n_clusters=len(self.csr_offsets) - 1)
+                for t in (pts.ray_o, pts.ray_d, pts.near, pts.far):
+                    t.record_stream(side)
             frame = self.prepare_frame(batch)
         # (the threshold applies to THIS call whether or not the frame constants were handed in)
         rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
