@@ -107,6 +107,10 @@ int th_set_mlp_mode(th_ctx* ctx, int mode);
 #define TH_RANGE_SLOTS 8
 #define TH_RANGE_FP16_LIMIT 0x7B53u     /* 6.0e4 */
 #define TH_RANGE_FP16_FLOOR 0x2400u     /* 2^-6  */
+/* slot 7: fp16 bit pattern of max |a| of the operands of TransHE's dense layers (th_gemm_h3).  Slots 6 and 7 are
+ * written by the stream that computes a frame's constants and are sticky (not cleared by a snapshot; slot 7 is cleared by
+ * th_set_vit_weights).  th_set_vit_mode(ctx, 0) moves TransHE's dense layers back to the fp32 MFMA GEMMs. */
+int th_set_vit_mode(th_ctx* ctx, int mode);
 int th_range_snapshot(th_ctx* ctx, th_stream stream);
 int th_range_read(th_ctx* ctx, int slot, uint32_t* out /* [TH_RANGE_SLOTS] */);
 int th_range_last_slot(th_ctx* ctx);

@@ -408,3 +408,27 @@ def test_full_size_sigma_grid_256_and_mesh(hip, gpu, net):
     with torch.no_grad():
         ref = O.render_sigma_grid(sd, bc, bc["pts"].reshape(-1, 3)[pick].reshape(1, -1, 1, 1, 3), hol, pix, off, mem, cc)
     assert maxdiff(cube.reshape(-1)[pick], ref.reshape(-1)) < 1e-4
+
+
+def test_vit_fp16_split_gemms_equal_fp32_gemms(hip, gpu, net):
+    """TransHE's dense layers on the fp16-split MFMA path (th_gemm_h3: LayerNorm fused, GELU, residual accumulate)
+    against the fp32 MFMA GEMMs of the same library and the oracle, N_c = 300 / 500 / 1500 (ragged row tiles), V = 1 / 3"""
+    import ctypes as C
+    from util import gold
+    lib = hip.load_library()
+    for V, nc in ((3, 300), (1, 500), (3, 1500)):
+        x = torch.from_numpy(synth.smooth_noise((V, nc, 192), 31 + nc, passes=0))
+        pe = O.normalize_pe(can_centres64(synth_assign(500) if nc == 500 else synth_assign(300))[None].repeat(V, 1, 1)) \
+            if nc != 1500 else (torch.rand(V, nc, 3) * 2 - 1)
+        if pe.shape[1] != nc:
+            pe = (torch.rand(V, nc, 3, generator=torch.Generator().manual_seed(nc)) * 2 - 1)
+        out_h3 = net.ViT(x.to(gpu), pe.to(gpu), mask=None).cpu()
+        try:
+            hip._check(lib.th_set_vit_mode(hip.ctx(gpu), 0))
+            out_f32 = net.ViT(x.to(gpu), pe.to(gpu), mask=None).cpu()
+        finally:
+            hip._check(lib.th_set_vit_mode(hip.ctx(gpu), 1))
+        assert torch.isfinite(out_h3).all()
+        assert maxdiff(out_h3, out_f32) < 3e-5, (V, nc, maxdiff(out_h3, out_f32))
+        if nc <= 500:
+            assert maxdiff(out_h3, O.vit_forward(x, pe, make_sd(), 12)) < 1e-4

@@ -302,3 +302,222 @@ static int gemm_launch(const float* A, int lda, int M, const ThPacked& W, int fl
     TH_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- fp16-split form for the small-M layers of TransHE ---------------------------------------------------------------
+// The ViT's dense layers are 1500..4500 rows x 192..768: on the fp32 matrix pipe a 16-row workgroup spends 48..192
+// MFMAs of 32 cycles per column tile and the launch is as long as that chain (8..15 us per layer, 890 us per forward).
+// Here both operands are split into fp16 hi + lo (x = hi + lo to 2^-22) and three v_mfma_f32_16x16x32_f16 products
+// accumulate in fp32 (hi*lo + lo*hi + hi*hi: the fused MLP's fp32-class scheme): 18..72 MFMAs of 16 cycles.
+//   workgroup = 16 rows x 64 columns (4 waves x one 16-column tile): ceil(M/16) x ceil(N/64) workgroups;
+//   the WHOLE K range of the 16 rows is converted once into LDS planes [16][K] hi | lo (row stride 2K + 16 B: an odd
+//   number of 16-byte slots, conflict-free ds_read_b128 A fragments); LN = true normalises the rows on the way in;
+//   weight fragments (pre-split, pre-scaled, th_pack_linear_h3) stream from L2 through a 6-deep register ring.
+typedef _Float16 g_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 g_h4 __attribute__((ext_vector_type(4)));
+
+__global__ void h3_absmax_kernel(const float* __restrict__ w, long long n, unsigned int* __restrict__ out) {
+    float m = 0.f;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(w[i]));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));
+}
+
+__global__ void h3_pack_kernel(const float* __restrict__ W, int N, int K, int NB, int KB32,
+                               const unsigned int* __restrict__ amax_bits, uint4* __restrict__ out, float* __restrict__ inv_out) {
+    float amax = __uint_as_float(*amax_bits);
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) amax = 1.f;
+    int e;
+    frexpf(amax, &e);                          // amax = m * 2^e, m in [0.5, 1)
+    const float scale = ldexpf(1.f, 13 - e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) inv_out[0] = ldexpf(1.f, e - 13);
+    const long long total = (long long)NB * KB32 * 2 * 64;
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(o & 63);
+        long long q = o >> 6;
+        const int plane = (int)(q & 1); q >>= 1;
+        const int kb = (int)(q % KB32);
+        const int nb = (int)(q / KB32);
+        const int n = nb * 16 + (lane & 15);
+        const int k0 = kb * 32 + 8 * (lane >> 4);
+        g_h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            const float x = (n < N && k < K) ? W[(long long)n * K + k] * scale : 0.f;
+            const _Float16 hi = (_Float16)x;
+            v[j] = plane == 0 ? hi : (_Float16)(x - (float)hi);
+        }
+        out[o] = *reinterpret_cast<uint4*>(&v);
+    }
+}
+
+int th_pack_linear_h3(const th_linear& lin, void* storage_h3, ThPacked* out, hipStream_t s) {
+    TH_REQUIRE(lin.w != nullptr && out->w != nullptr && out->N == lin.out_f && out->K == lin.in_f, "pack the fp32 image first");
+    out->KB32 = (lin.in_f + 31) / 32;
+    uint4* w16 = (uint4*)storage_h3;
+    const size_t img = th_align((size_t)out->NB * out->KB32 * 2 * 64 * 16);
+    float* sc = (float*)((char*)storage_h3 + img);
+    unsigned int* amax = (unsigned int*)(sc + 4);
+    TH_HIP(hipMemsetAsync(amax, 0, 4, s));
+    hipLaunchKernelGGL(h3_absmax_kernel, dim3(64), dim3(256), 0, s, lin.w, (long long)lin.out_f * lin.in_f, amax);
+    hipLaunchKernelGGL(h3_pack_kernel, dim3(256), dim3(256), 0, s, lin.w, lin.out_f, lin.in_f, out->NB, out->KB32, amax, w16, sc);
+    TH_LAUNCH_CHECK();
+    out->w16 = w16;
+    out->scale16 = sc;
+    return 0;
+}
+
+#define H3_RING 6
+template <bool LN>
+__global__ __launch_bounds__(256) void gemm_h3_kernel(const float* __restrict__ A, int lda, int M, int Kreal,
+                                                      const uint4* __restrict__ W16, const float* __restrict__ inv_scale,
+                                                      const float* __restrict__ bias, int N, int NB, int KB32,
+                                                      float* __restrict__ C, int ldc, int flags,
+                                                      const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                      float ln_eps, unsigned int* __restrict__ range) {
+    extern __shared__ __attribute__((aligned(16))) char h3_lds[];
+    __shared__ float ln_mean[16], ln_rstd[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * 16;
+    const int nb = blockIdx.y * 4 + wave;
+    const bool wave_active = nb < NB;
+    const int KP = KB32 * 32;
+    const int stride = 2 * KP + 16;                        // bytes per LDS row of a plane
+    char* a_hi = h3_lds;
+    char* a_lo = h3_lds + 16 * stride;
+
+    // weight fragments of the first ring stages: requested before the operand is staged
+    uint4 bq[H3_RING][2];
+    const uint4* wl = W16 + ((long long)nb * KB32) * 128 + lane;
+    if (wave_active) {
+#pragma unroll
+        for (int j = 0; j < H3_RING; ++j)
+            if (j < KB32) { bq[j][0] = wl[j * 128]; bq[j][1] = wl[j * 128 + 64]; }
+    }
+    if (LN) {
+        // 16 threads per row, two passes like layernorm_kernel (k_vit.hip); K <= 256
+        const int row = tid >> 4, sub = tid & 15, gm = m0 + row;
+        float v[16];
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * (sub + 16 * q);
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gm < M && k < Kreal) x = *reinterpret_cast<const float4*>(A + (long long)gm * lda + k);
+            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            sum += (x.x + x.y) + (x.z + x.w);
+        }
+        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum / (float)Kreal;
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * (sub + 16 * q);
+            if (k < Kreal) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { float d = v[4 * q + e] - mean; ss += d * d; }
+            }
+        }
+        for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o);
+        if (sub == 0) { ln_mean[row] = mean; ln_rstd[row] = 1.0f / __fsqrt_rn(ss / (float)Kreal + ln_eps); }
+        __syncthreads();
+    }
+    // stage + split the 16 x KP operand
+    unsigned rmax = 0u;
+    const int c4n = KP / 4;
+    for (int idx = tid; idx < 16 * c4n; idx += 256) {
+        const int row = idx / c4n, c4 = idx - row * c4n, gm = m0 + row, gk = 4 * c4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gm < M && gk < Kreal) {
+            v = *reinterpret_cast<const float4*>(A + (long long)gm * lda + gk);     // (K % 4 == 0 is required)
+            if (LN) {
+                const float mu = ln_mean[row], rs = ln_rstd[row];
+                const float4 w4 = *reinterpret_cast<const float4*>(ln_w + gk), b4 = *reinterpret_cast<const float4*>(ln_b + gk);
+                v.x = (v.x - mu) * rs * w4.x + b4.x;
+                v.y = (v.y - mu) * rs * w4.y + b4.y;
+                v.z = (v.z - mu) * rs * w4.z + b4.z;
+                v.w = (v.w - mu) * rs * w4.w + b4.w;
+            }
+        }
+        const float x4[4] = {v.x, v.y, v.z, v.w};
+        g_h4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16 hi = (_Float16)x4[e];
+            hv[e] = hi;
+            lv[e] = (_Float16)(x4[e] - (float)hi);
+            rmax = max(rmax, (unsigned)(__builtin_bit_cast(unsigned short, hi) & 0x7fffu));
+        }
+        *reinterpret_cast<g_h4*>(a_hi + row * stride + 8 * c4) = hv;
+        *reinterpret_cast<g_h4*>(a_lo + row * stride + 8 * c4) = lv;
+    }
+    if (range != nullptr && rmax > range[TH_RANGE_VIT]) atomicMax(range + TH_RANGE_VIT, rmax);
+    __syncthreads();
+    if (!wave_active) return;
+
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int aoff = (lane & 15) * stride + 16 * (lane >> 4);
+    for (int kb0 = 0; kb0 < KB32; kb0 += H3_RING) {
+#pragma unroll
+        for (int j = 0; j < H3_RING; ++j) {
+            const int kb = kb0 + j;
+            if (kb < KB32) {
+                const g_h8 ah = *reinterpret_cast<const g_h8*>(a_hi + aoff + kb * 64);
+                const g_h8 al = *reinterpret_cast<const g_h8*>(a_lo + aoff + kb * 64);
+                const g_h8 bh = *reinterpret_cast<const g_h8*>(&bq[j][0]);
+                const g_h8 bl = *reinterpret_cast<const g_h8*>(&bq[j][1]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+                if (kb + H3_RING < KB32) { bq[j][0] = wl[(kb + H3_RING) * 128]; bq[j][1] = wl[(kb + H3_RING) * 128 + 64]; }
+            }
+        }
+    }
+    const int act = flags & 15;
+    const bool accum = (flags & TH_GEMM_ACCUM) != 0;
+    const int col = nb * 16 + (lane & 15);
+    if (col >= N) return;
+    const float inv = inv_scale[0], bv = bias[col];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + 4 * (lane >> 4) + r;
+        if (row < M) {
+            float v = acc[r] * inv + bv;
+            if (act == TH_ACT_RELU) v = fmaxf(v, 0.0f);
+            else if (act == TH_ACT_GELU) v = th_gelu_erf(v);
+            float* dst = C + (long long)row * ldc + col;
+            if (accum) v = *dst + v;
+            *dst = v;
+        }
+    }
+}
+
+bool th_gemm_h3_ok(int M, const ThPacked& W, bool ln) {
+    return W.w16 != nullptr && M > 0 && M <= 8192 && (W.K & 3) == 0 && W.K <= 768 && (!ln || W.K <= 256);
+}
+
+int th_gemm_h3(const float* A, int lda, int M, const ThPacked& W, const float* ln_w, const float* ln_b, float eps, int flags,
+               float* C, int ldc, unsigned int* range, hipStream_t s) {
+    const bool ln = ln_w != nullptr;
+    TH_REQUIRE(th_gemm_h3_ok(M, W, ln), "th_gemm_h3: unsupported shape / layer not packed for the fp16-split path");
+    TH_REQUIRE((lda & 3) == 0 && (((uintptr_t)A) & 15) == 0, "A must be 16-byte aligned with lda % 4 == 0");
+    const int KP = W.KB32 * 32;
+    const size_t lds = (size_t)2 * 16 * (2 * KP + 16);
+    static bool attr = false;
+    if (!attr) {
+        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * (2 * 768 + 16)));
+        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * (2 * 768 + 16)));
+        attr = true;
+    }
+    dim3 grid(th_cdiv(M, 16), th_cdiv(W.NB, 4));
+    if (ln)
+        hipLaunchKernelGGL(gemm_h3_kernel<true>, grid, dim3(256), lds, s, A, lda, M, W.K, W.w16, W.scale16, W.b, W.N, W.NB, W.KB32,
+                           C, ldc, flags, ln_w, ln_b, eps, range);
+    else
+        hipLaunchKernelGGL(gemm_h3_kernel<false>, grid, dim3(256), lds, s, A, lda, M, W.K, W.w16, W.scale16, W.b, W.N, W.NB, W.KB32,
+                           C, ldc, flags, ln_w, ln_b, eps, range);
+    TH_LAUNCH_CHECK();
+    return 0;
+}

@@ -456,7 +456,7 @@ size_t th_vit_ws(int V, int N, int dim, int heads) {
 }
 
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
-                  size_t ws_bytes, hipStream_t s) {
+                  size_t ws_bytes, hipStream_t s, unsigned int* range, bool allow_h3) {
     TH_REQUIRE(W.ready, "ViT weights not set (th_set_vit_weights)");
     const int dim = W.dim, heads = W.heads;
     TH_REQUIRE(dim == heads * 64, "attention kernel is built for head_dim 64 (ViT-tiny: 192 = 3 x 64)");
@@ -483,9 +483,15 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
     // the two pre-LayerNorms of a block run inside the GEMM that consumes them (TH_VIT_SEPARATE_LN=1: own launches)
     static const bool separate_ln = getenv("TH_VIT_SEPARATE_LN") != nullptr;
     const bool fuse_ln = !separate_ln && th_gemm_ln_ok(T, W.blocks[0].qkv) && th_gemm_ln_ok(T, W.blocks[0].fc1);
+    // dense layers on the fp16-split MFMA path (th_gemm_h3; TH_VIT_GEMM_F32=1: the fp32 MFMA GEMMs)
+    static const bool f32_gemm = getenv("TH_VIT_GEMM_F32") != nullptr;
+    const bool h3 = allow_h3 && !f32_gemm && !separate_ln && th_gemm_h3_ok(T, W.blocks[0].qkv, true) && th_gemm_h3_ok(T, W.blocks[0].fc1, true) &&
+                    th_gemm_h3_ok(T, W.blocks[0].proj, false) && th_gemm_h3_ok(T, W.blocks[0].fc2, false);
     for (int b = 0; b < W.depth; ++b) {
         const ThVitBlockPacked& B = W.blocks[b];
-        if (fuse_ln) {
+        if (h3) {
+            TH_TRY(th_gemm_h3(X, dim, T, B.qkv, B.ln1_w, B.ln1_b, 1e-6f, TH_ACT_NONE, Q, 3 * dim, range, s));
+        } else if (fuse_ln) {
             TH_TRY(th_gemm_ln(X, dim, T, B.qkv, B.ln1_w, B.ln1_b, 1e-6f, TH_ACT_NONE, Q, 3 * dim, s));
         } else {
             hipLaunchKernelGGL(layernorm_kernel, dim3(th_cdiv(T, 4)), dim3(256), 0, s, X, T, dim, B.ln1_w, B.ln1_b, 1e-6f, Y);
@@ -496,6 +502,12 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
         } else {
             hipLaunchKernelGGL(kv_split_kernel, dim3(Npad / 64, heads, V), dim3(256), 0, s, Q, N, Npad, dim, Kp, Vp);
             hipLaunchKernelGGL(attn2_kernel, dim3(th_cdiv(N, 16), heads, V), dim3(64), 0, s, Q, Kp, Vp, N, Npad, dim, scale, Y);
+        }
+        if (h3) {
+            TH_TRY(th_gemm_h3(Y, dim, T, B.proj, nullptr, nullptr, 0.f, TH_ACT_NONE | TH_GEMM_ACCUM, X, dim, range, s));
+            TH_TRY(th_gemm_h3(X, dim, T, B.fc1, B.ln2_w, B.ln2_b, 1e-6f, TH_ACT_GELU, Q, 4 * dim, range, s));
+            TH_TRY(th_gemm_h3(Q, 4 * dim, T, B.fc2, nullptr, nullptr, 0.f, TH_ACT_NONE | TH_GEMM_ACCUM, X, dim, range, s));
+            continue;
         }
         TH_TRY(th_gemm(Y, dim, T, B.proj, TH_ACT_NONE | TH_GEMM_ACCUM, X, dim, s));
         if (fuse_ln) {

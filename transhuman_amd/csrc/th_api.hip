@@ -236,7 +236,9 @@ int th_range_snapshot(th_ctx* c, th_stream stream) {
     if (!c->range_ev[slot]) TH_HIP(hipEventCreateWithFlags(&c->range_ev[slot], hipEventDisableTiming));
     TH_HIP(hipMemcpyAsync(c->range_host + slot * TH_RANGE_SLOTS, c->range_dev, TH_RANGE_SLOTS * sizeof(unsigned int),
                           hipMemcpyDeviceToHost, s));
-    TH_HIP(hipMemsetAsync(c->range_dev, 0, TH_RANGE_SLOTS * sizeof(unsigned int), s));
+    // per-frame slots only: the stem-convolution and TransHE slots are written from the stream that computes the NEXT
+    // frame's constants (clearing them here could erase that frame's maxima) -- they are sticky until new weights arrive
+    TH_HIP(hipMemsetAsync(c->range_dev, 0, TH_RANGE_CONV * sizeof(unsigned int), s));
     TH_HIP(hipEventRecord(c->range_ev[slot], s));
     c->range_last = slot;
     return slot;
@@ -252,6 +254,12 @@ int th_range_read(th_ctx* c, int slot, uint32_t* out) {
 
 int th_range_last_slot(th_ctx* c) { return c ? c->range_last : -1; }
 
+int th_set_vit_mode(th_ctx* c, int mode) {
+    TH_REQUIRE(c && (mode == 0 || mode == 1), "mode must be 0 (fp32 MFMA GEMMs) or 1 (fp16-split MFMA GEMMs)");
+    c->vit_mode = mode;
+    return 0;
+}
+
 int th_set_mlp_mode(th_ctx* c, int mode) {
     TH_REQUIRE(c && (mode == 0 || mode == 1), "mode must be 0 (layer-by-layer fp32 MFMA) or 1 (fused fp16-split MFMA)");
     c->mlp_mode = mode;
@@ -264,7 +272,9 @@ int th_set_vit_weights(th_ctx* c, int depth, int dim, int heads, const th_vit_bl
     TH_REQUIRE(depth > 0 && dim == heads * 64, "ViT must have head_dim 64");
     hipStream_t s = (hipStream_t)stream;
     size_t per = ThPacked::bytes(3 * dim, dim) + ThPacked::bytes(dim, dim) + ThPacked::bytes(4 * dim, dim) +
-                 ThPacked::bytes(dim, 4 * dim) + th_align(4 * dim * sizeof(float));
+                 ThPacked::bytes(dim, 4 * dim) + th_align(4 * dim * sizeof(float)) +
+                 ThPacked::bytes_h3(3 * dim, dim) + ThPacked::bytes_h3(dim, dim) + ThPacked::bytes_h3(4 * dim, dim) +
+                 ThPacked::bytes_h3(dim, 4 * dim);
     size_t total = per * depth + th_align(2 * dim * sizeof(float));
     if (c->vit_store) { TH_HIP(hipFree(c->vit_store)); c->vit_store = nullptr; }
     TH_HIP(hipMalloc(&c->vit_store, total));
@@ -283,6 +293,11 @@ int th_set_vit_weights(th_ctx* c, int depth, int dim, int heads, const th_vit_bl
         TH_TRY(th_pack_linear(B.proj, base + off, &P.proj, s)); off += ThPacked::bytes(dim, dim);
         TH_TRY(th_pack_linear(B.fc1, base + off, &P.fc1, s)); off += ThPacked::bytes(4 * dim, dim);
         TH_TRY(th_pack_linear(B.fc2, base + off, &P.fc2, s)); off += ThPacked::bytes(dim, 4 * dim);
+        // fp16-split images of the same four layers (th_gemm_h3: the ViT's small-M GEMMs on the fp16 matrix pipe)
+        TH_TRY(th_pack_linear_h3(B.qkv, base + off, &P.qkv, s)); off += ThPacked::bytes_h3(3 * dim, dim);
+        TH_TRY(th_pack_linear_h3(B.proj, base + off, &P.proj, s)); off += ThPacked::bytes_h3(dim, dim);
+        TH_TRY(th_pack_linear_h3(B.fc1, base + off, &P.fc1, s)); off += ThPacked::bytes_h3(4 * dim, dim);
+        TH_TRY(th_pack_linear_h3(B.fc2, base + off, &P.fc2, s)); off += ThPacked::bytes_h3(dim, 4 * dim);
         float* ln = (float*)(base + off); off += th_align(4 * dim * sizeof(float));
         P.ln1_w = ln; P.ln1_b = ln + dim; P.ln2_w = ln + 2 * dim; P.ln2_b = ln + 3 * dim;
         TH_HIP(hipMemcpyAsync(P.ln1_w, B.ln1_w, dim * 4, hipMemcpyDeviceToDevice, s));
@@ -294,6 +309,7 @@ int th_set_vit_weights(th_ctx* c, int depth, int dim, int heads, const th_vit_bl
     c->vit.norm_w = nf; c->vit.norm_b = nf + dim;
     TH_HIP(hipMemcpyAsync(c->vit.norm_w, norm_w, dim * 4, hipMemcpyDeviceToDevice, s));
     TH_HIP(hipMemcpyAsync(c->vit.norm_b, norm_b, dim * 4, hipMemcpyDeviceToDevice, s));
+    TH_HIP(hipMemsetAsync(c->range_dev + TH_RANGE_VIT, 0, sizeof(unsigned int), s));   // new weights: sticky maximum cleared
     TH_HIP(hipStreamSynchronize(s));
     c->vit.ready = true;
     return 0;
@@ -435,7 +451,8 @@ int th_vit_forward(th_ctx* c, const float* x, const float* pe, int V, int N, flo
                    th_stream stream) {
     TH_REQUIRE(c && x && pe && out && ws, "null argument");
     ProfScope sc(prof_of(c), TH_PROF_VIT, (hipStream_t)stream);
-    return th_vit_launch(c->vit, x, pe, V, N, out, ws, ws_bytes, (hipStream_t)stream);
+    return th_vit_launch(c->vit, x, pe, V, N, out, ws, ws_bytes, (hipStream_t)stream, c->vit_mode == 1 ? c->range_dev : nullptr,
+                         c->vit_mode == 1);
 }
 
 int th_dparf_encode(th_ctx* c, const float* pts, const int32_t* sel, int P, const float* centres, const float* rot,

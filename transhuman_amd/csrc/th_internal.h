@@ -61,15 +61,32 @@ struct ThPacked {
     float* w = nullptr;
     float* b = nullptr;
     int N = 0, K = 0, NB = 0, KB = 0;
+    // optional second image for th_gemm_h3 (fp16 hi/lo split x3 on v_mfma_f32_16x16x32_f16, the fused MLP's fp32-class
+    // arithmetic): [NB][KB32][hi | lo][64 lanes] 16-byte B-operand fragments of the weights scaled by a power of two
+    // (max |w| -> [2^12, 2^13): lo halves stay normal numbers); scale16[0] = its inverse (device scalar)
+    const uint4* w16 = nullptr;
+    const float* scale16 = nullptr;
+    int KB32 = 0;
     static size_t bytes(int out_f, int in_f) {
         size_t nb = (out_f + 15) / 16, kb = (in_f + 15) / 16;
         return th_align(nb * kb * 256 * sizeof(float)) + th_align(nb * 16 * sizeof(float));
+    }
+    static size_t bytes_h3(int out_f, int in_f) {
+        size_t nb = (out_f + 15) / 16, kb32 = (in_f + 31) / 32;
+        return th_align(nb * kb32 * 2 * 64 * 16) + th_align(64);
     }
 };
 
 enum { TH_ACT_NONE = 0, TH_ACT_RELU = 1, TH_ACT_GELU = 2, TH_GEMM_ACCUM = 16 };
 
 int th_pack_linear(const th_linear& lin, void* storage, ThPacked* out, hipStream_t s);
+// adds the fp16-split image (storage_h3: ThPacked::bytes_h3 bytes) to an already packed layer
+int th_pack_linear_h3(const th_linear& lin, void* storage_h3, ThPacked* out, hipStream_t s);
+// C = act([LayerNorm](A) W^T + b) (+C) on the fp16-split MFMA path (layers packed with th_pack_linear_h3, M <= 8192,
+// K <= 768); range: the guard's slot TH_RANGE_VIT takes max |a| of the split operand
+bool th_gemm_h3_ok(int M, const ThPacked& W, bool ln);
+int th_gemm_h3(const float* A, int lda, int M, const ThPacked& W, const float* ln_w, const float* ln_b, float eps, int flags,
+               float* C, int ldc, unsigned int* range, hipStream_t s);
 // C[M,N] = act(A[M,K] W^T + b) (+ C if TH_GEMM_ACCUM)
 int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float* C, int ldc, hipStream_t s);
 // C = act(LayerNorm(A rows; ln_w, ln_b, eps) W^T + b) (+ C): the normalisation happens inside the GEMM
@@ -217,7 +234,8 @@ struct FusedParams {
     long long* dbg;     // optional cycle stamps (TH_FUSED_DBG)
 };
 // range-guard table slots (th_range_read): the tensors that pass through the fp16 hi/lo split
-enum { TH_RANGE_F = 0, TH_RANGE_S = 1, TH_RANGE_P = 2, TH_RANGE_N = 3, TH_RANGE_INTER = 4, TH_RANGE_F4 = 5, TH_RANGE_CONV = 6 };
+enum { TH_RANGE_F = 0, TH_RANGE_S = 1, TH_RANGE_P = 2, TH_RANGE_N = 3, TH_RANGE_INTER = 4, TH_RANGE_F4 = 5, TH_RANGE_CONV = 6,
+       TH_RANGE_VIT = 7 };
 size_t th_fused_pack_bytes();
 // folded: nullptr or the three colour-folded fp32 layers {alpha_res_0, rgb_res_0, rgb_res_1} (in_f 260)
 int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store, FusedParams* out, hipStream_t s);
@@ -233,6 +251,7 @@ struct th_ctx {
     FusedParams fused{};
     bool fused_ready = false;
     int mlp_mode = 1;                 // 1: fused fp16x3-split MFMA kernel, 0: layer-by-layer fp32 MFMA
+    int vit_mode = 1;                 // 1: TransHE dense layers on the fp16-split MFMA path (th_gemm_h3), 0: fp32 MFMA
     int device = 0;
     void* mlp_store = nullptr;
     void* vit_store = nullptr;
@@ -330,7 +349,7 @@ int th_view_embed_launch(const float* d, int R, int res, float* out, hipStream_t
 // k_vit.hip
 size_t th_vit_ws(int V, int N, int dim, int heads);
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
-                  size_t ws_bytes, hipStream_t s);
+                  size_t ws_bytes, hipStream_t s, unsigned int* range = nullptr, bool allow_h3 = true);
 
 // k_smpl.hip
 size_t th_smpl_ws(int nv);

@@ -61,6 +61,7 @@ SYMBOLS = {
     "th_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "th_set_mlp_weights": (C.c_int, [C.c_void_p, C.POINTER(ThMlpWeights), C.c_void_p]),
     "th_set_mlp_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "th_set_vit_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "th_range_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_range_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "th_range_last_slot": (C.c_int, [C.c_void_p]),
@@ -293,7 +294,7 @@ def _sync_weights(mod, kind):
 # ---------------------------------------------------------------------------
 # range guard of the fp16 hi/lo split arithmetic (include/transhuman_hip.h: th_range_*)
 # ---------------------------------------------------------------------------
-RANGE_NAMES = ("f", "s", "p", "n", "inter", "fc4_in", "conv_in", "_")
+RANGE_NAMES = ("f", "s", "p", "n", "inter", "fc4_in", "conv_in", "vit_in")
 RANGE_FP16_LIMIT = 0x7B53          # 6.0e4 as an fp16 bit pattern (inf / NaN are larger)
 RANGE_FP16_FLOOR = 0x2400          # 2^-6
 RANGE_FP32_LIMIT = 0x476A6000      # 6.0e4 as an fp32 bit pattern (slot conv_in)
@@ -301,6 +302,7 @@ _user_mode = {}                    # device index -> mode requested through set_
 _range_fallback = {}               # device index -> True while the guard forces mode 0 on this context
 _range_epoch = {}                  # device index -> number of fallbacks so far (frames queued earlier are re-rendered)
 conv_fallback = False              # set when the stem convolutions' input left the fp16 range: stock convolutions from now on
+vit_fallback = False               # set when an operand of TransHE's fp16-split GEMMs left the fp16 range: fp32 MFMA GEMMs
 last_range = None                  # the last table read (debugging / tests)
 
 
@@ -352,11 +354,18 @@ def range_epoch(device=None):
 def _guard(device, slot):
     """True when the snapshot is clean.  Otherwise the context has been switched to the fp32 path (and / or the
     stem convolutions to the stock modules): the caller re-runs its work."""
-    global conv_fallback
+    global conv_fallback, vit_fallback
     if slot is None or slot < 0:
         return True
     vals = range_read(slot, device)
     ok = True
+    if vals[7] >= RANGE_FP16_LIMIT and not vit_fallback:
+        import warnings
+        warnings.warn("transhuman_amd: an operand of TransHE's dense layers left the fp16 range; using the fp32 MFMA "
+                      "GEMMs from now on", RuntimeWarning)
+        _check(load_library().th_set_vit_mode(ctx(device), 0))
+        vit_fallback = True
+        ok = False
     if _conv_range_bad(vals) and not conv_fallback:
         import warnings
         warnings.warn("transhuman_amd: the ResNet-stem convolution input left the fp16 range; using the stock "
@@ -881,7 +890,7 @@ def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_f
     if defer_guard:
         return rgb, acc, dep, st, (lambda: _guard(dev, slot))
     if not _guard(dev, slot):
-        if conv_fallback and getattr(frame, "rebuild", None) is not None:
+        if (conv_fallback or vit_fallback) and getattr(frame, "rebuild", None) is not None:
             frame = frame.rebuild()                  # frame constants again, through the stock convolutions
             keep_sfr = fc.small_frame_rays
             fc = ThFrame.from_buffer_copy(frame.c)
@@ -908,7 +917,7 @@ def eval_sigma_grid(net, frame, pts):
                                       _stream()))
         if _guard(p.device, int(stats[2])):
             break
-        if conv_fallback and getattr(frame, "rebuild", None) is not None:
+        if (conv_fallback or vit_fallback) and getattr(frame, "rebuild", None) is not None:
             frame = frame.rebuild()
     return out, dict(valid_samples=stats[1])
 

@@ -197,6 +197,8 @@ class Renderer:
                 side = self._dev.get(("hull_stream", str(dev)))
                 if side is None:
                     side = self._dev[("hull_stream", str(dev))] = torch.cuda.Stream(dev)
+                if os.environ.get("TH_HULL_SAME_STREAM") == "1":       # A/B switch: the ray-only stage in front, same stream
+                    side = torch.cuda.current_stream(dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
                     hip.render_prepass(pts, batch["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
@@ -319,7 +321,7 @@ class Renderer:
         def finish(ent):
             rgb, acc, depth, stats, frame, cur, pts, check, epoch = ent
             if not check() or epoch != hip.range_epoch(dev):
-                if hip.conv_fallback:
+                if hip.conv_fallback or hip.vit_fallback:
                     frame = frame.rebuild()
                 rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
                                                          small_frame_rays=small_frame_rays)
