@@ -121,3 +121,42 @@ def test_gen_path_virt_vs_reference_golden():
     rig_c = np.array([-m[:3, :3].T @ m[:3, 3] for m in rig]).mean(0)
     d = np.linalg.norm(centres - rig_c, axis=1)
     assert d.min() > 1.5 and d.max() < 5.0
+
+
+def test_evaluator_psnr_images_and_files(tmp_path):
+    """lib/evaluators/if_nerf.py:34-37, :41-62, :121-130, :146-170: MSE / PSNR of the masked ray list, the cropped
+    full-frame images and the files run.py --type evaluate leaves behind"""
+    from PIL import Image
+    from transhuman_amd.evaluator import Evaluator, bounding_rect, to_uint8
+    from transhuman_amd.config import get_cfg
+    from oracle import th_oracle as O
+    cfg = get_cfg()
+    H = W = 24
+    rs = np.random.RandomState(0)
+    mask = np.zeros((H, W), bool)
+    mask[5:17, 8:20] = rs.uniform(size=(12, 12)) < 0.8
+    mask[5, 8] = mask[16, 19] = True
+    n = int(mask.sum())
+    gt = rs.uniform(size=(n, 3))
+    pred = np.clip(gt + rs.normal(0, 0.02, size=(n, 3)), 0, 1)
+    batch = {"rgb": torch.from_numpy(gt)[None], "mask_at_box": torch.from_numpy(mask.reshape(-1))[None],
+             "human_name": ["CoreView_313"], "frame_index": torch.tensor([7]), "cam_ind": torch.tensor([3])}
+    ev = Evaluator(result_dir=str(tmp_path / "res"))
+    r = ev.evaluate({"rgb_map": torch.from_numpy(pred)[None]}, batch, H, W)
+    assert abs(r["psnr"] - O.psnr_metric(pred, gt)) < 1e-12 and abs(r["mse"] - np.mean((pred - gt) ** 2)) < 1e-15
+    assert bounding_rect(mask) == (8, 5, 12, 12)
+    img = np.array(Image.open(tmp_path / "res" / "CoreView_313" / "pred" / "frame7_view3.png"))
+    assert img.shape == (12, 12, 3) and img.dtype == np.uint8
+    full = np.zeros((H, W, 3))
+    full[mask] = pred
+    assert np.array_equal(img, to_uint8(full[5:17, 8:20]))
+    assert (tmp_path / "res" / "CoreView_313" / "gt" / "frame7_view3_gt.png").exists()
+    s = ev.summarize()
+    assert abs(s["psnr"] - r["psnr"]) < 1e-12 and np.load(tmp_path / "res" / "psnr.npy").shape == (1,)
+    old = cfg.white_bkgd
+    cfg.white_bkgd = True
+    try:
+        p2, _ = ev.images(pred, gt, batch, H, W)
+        assert (p2[~mask[5:17, 8:20]] == 1.0).all()
+    finally:
+        cfg.white_bkgd = old
