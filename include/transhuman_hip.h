@@ -173,6 +173,8 @@ int th_segment_mean_rot_f64(th_ctx* ctx, const double* blend, const int32_t* csr
 /* channel counts of the channels-last pixel map */
 #define TH_MAP_FULL    384   /* pixel_feat_map as the reference builds it: 256 latent + 128 lifted colour  */
 #define TH_MAP_COMPACT 260   /* 256 latent | r g b | 0 : the colour lift is folded into the consumers        */
+#define TH_MAP_SPLIT   256   /* the compact map as two planes: [V,H,W,256] latents (1 KiB rows: one aligned wave load per
+                                corner texel) immediately followed by [V,H,W,4] (r, g, b, 0); same consumers / folds as 260 */
 
 /* ---- K8: encoder tail written channels-last + painting from that map ------ */
 /* encoder.py:133-146: bilinear-upsample (align_corners=True) the three ResNet latents
@@ -184,6 +186,9 @@ int th_segment_mean_rot_f64(th_ctx* ctx, const double* blend, const int32_t* csr
 int th_upsample_concat_nhwc(th_ctx* ctx, const float* img, const float* lat0, const float* lat1,
                             const float* lat2, const int32_t* dims_host, int V, int H, int W,
                             const float* color_w, const float* color_b, float* out_nhwc, th_stream stream);
+/* the compact map in the TH_MAP_SPLIT layout: out = [V,H,W,256] latents followed by [V,H,W,4] (r, g, b, 0) */
+int th_upsample_concat_split(th_ctx* ctx, const float* img, const float* lat0, const float* lat1, const float* lat2,
+                             const int32_t* dims_host, int V, int H, int W, float* out, th_stream stream);
 /* paint_neural_human + can_body_grouping without materialising holder_feat_map: reduction_layer
  * (1x1 conv C->out_f, encoder.py:85,146) commutes with the bilinear sampling at :168-172, so the C-channel
  * channels-last map is sampled at the projected vertices and the layer is applied to those V*n_verts
@@ -353,7 +358,8 @@ typedef struct {
     const float* scale_xy;         /* [2]                                     */
     const float* pixel_map_nhwc;   /* [V,H,W,map_channels]                    */
     int          V, H, W;
-    int          map_channels;     /* TH_MAP_FULL (384) or TH_MAP_COMPACT (260, needs upsample_color weights) */
+    int          map_channels;     /* TH_MAP_FULL (384), TH_MAP_COMPACT (260) or TH_MAP_SPLIT (256 + 4; the last two need
+                                      upsample_color weights) */
     const float* tokens;           /* [V,N_c,192] ViT output                  */
     const float* centres;          /* [N_c,3]                                 */
     const float* rot;              /* [N_c,9]                                 */

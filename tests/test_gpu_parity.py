@@ -438,7 +438,7 @@ def test_fused_encoder_tail_equals_reference_order(hip, gpu, net):
     g_ref = r.last_grouped.clone()
     for compact in (False, True):
         f_new = r.prepare_frame(b, fused_encoder_tail=True, compact_map=compact)
-        assert f_new.map.shape[-1] == (260 if compact else 384)
+        assert f_new.map.shape[-1] == (256 if compact else 384)          # compact: hip.SplitMap (256 latents + r g b 0 plane)
         assert maxdiff(r.last_grouped.cpu(), g_ref.cpu()) < 5e-5
         assert maxdiff(f_new.tokens.cpu(), f_ref.tokens.cpu()) < 1e-4
     # compact map = the 256 latent channels of the full map | r g b | 0

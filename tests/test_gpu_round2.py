@@ -432,3 +432,35 @@ def test_vit_fp16_split_gemms_equal_fp32_gemms(hip, gpu, net):
         assert maxdiff(out_h3, out_f32) < 3e-5, (V, nc, maxdiff(out_h3, out_f32))
         if nc <= 500:
             assert maxdiff(out_h3, O.vit_forward(x, pe, make_sd(), 12)) < 1e-4
+
+
+def test_split_map_equals_interleaved_map(hip, gpu, net):
+    """TH_MAP_SPLIT (latents as 1 KiB rows + an r g b 0 plane, the default) against the interleaved 260-channel map: the
+    same texels, so tokens and images are identical bit for bit; non-square image, both MLP forms"""
+    from transhuman_amd.config import get_cfg
+    from transhuman_amd.networks.renderer import if_clight_renderer
+    get_cfg().N_samples, get_cfg().num_class = 32, 300
+    r = if_clight_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=synth_assign(300))
+    b = synth.batch_to(synth.make_batch(64, 48, 3, seed=0, focal=150.0), gpu)
+    f_split = r.prepare_frame(b)
+    g_split = r.last_grouped.clone()
+    f_int = r.prepare_frame(b, compact_map="interleaved")
+    assert isinstance(f_split.map, hip.SplitMap) and tuple(f_int.map.shape[-1:]) == (260,)
+    assert torch.equal(f_split.map.interleaved(), f_int.map)
+    assert torch.equal(g_split, r.last_grouped) and torch.equal(f_split.tokens, f_int.tokens)
+    for mode in (1, 0):
+        hip.set_mlp_mode(mode)
+        try:
+            a = r.render_fast(b, frame=f_split)
+            c = r.render_fast(b, frame=f_int)
+        finally:
+            hip.set_mlp_mode(1)
+        assert r.last_stats["valid_samples"] > 5000
+        for k in ("rgb_map", "acc_map", "depth_map"):
+            assert torch.equal(a[k], c[k]), (mode, k)
+    # gathered rows: 260-wide rows from the split map == rows from the interleaved map (incl. border clamping)
+    pts = torch.randn(500, 3, device=gpu) * 0.5 + torch.tensor([0.0, 0.1, 3.0], device=gpu)
+    cams = hip.pack_cams(b["input_R"][0][0], b["input_T"][0][0], b["input_K"][0][0])
+    rows_s = hip.pixel_gather(f_split.map, pts, cams, f_split.scale, row_floats=272)
+    rows_i = hip.pixel_gather(f_int.map, pts, cams, f_int.scale, row_floats=272)
+    assert torch.equal(rows_s, rows_i) and float(rows_s[..., 260:].abs().max()) == 0.0

@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
                                                                    const float* __restrict__ img,
                                                                    const float* __restrict__ wc,
                                                                    const float* __restrict__ bc, int H, int W,
-                                                                   int NG, int CO, float* __restrict__ out) {
+                                                                   int NG, int CO, float* __restrict__ out,
+                                                                   float* __restrict__ rgb4) {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane, y = blockIdx.y;
@@ -50,8 +51,9 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
         if (wave == 0 && x < W) {
             long long hw = (long long)H * W;
             const float* ip = img + (long long)v * 3 * hw + (long long)y * W + x;
-            *reinterpret_cast<float4*>(out + (((long long)v * H + y) * W + x) * CO + 256) =
-                make_float4(ip[0], ip[hw], ip[2 * hw], 0.f);
+            // (split layout: the colour plane [V,H,W,4] behind the 256-channel latent plane)
+            float* dst = rgb4 ? rgb4 + (((long long)v * H + y) * W + x) * 4 : out + (((long long)v * H + y) * W + x) * CO + 256;
+            *reinterpret_cast<float4*>(dst) = make_float4(ip[0], ip[hw], ip[2 * hw], 0.f);
         }
         return;
     }
@@ -89,13 +91,14 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
 
 int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
                               const int* dims /* h0,w0,h1,w1,h2,w2 */, int V, int H, int W, const float* wc,
-                              const float* bc, float* out, hipStream_t s) {
+                              const float* bc, float* out, hipStream_t s, int split) {
     UpsSrc s0{lat0, 64, dims[0], dims[1], 0};
     UpsSrc s1{lat1, 64, dims[2], dims[3], 64};
     UpsSrc s2{lat2, 128, dims[4], dims[5], 128};
-    const int NG = wc ? 6 : 5, CO = wc ? 384 : 260;
+    const int NG = wc ? 6 : 5, CO = wc ? 384 : (split ? 256 : 260);
+    float* rgb4 = (!wc && split) ? out + (long long)V * H * W * 256 : nullptr;
     hipLaunchKernelGGL(upsample_concat_nhwc_kernel, dim3(th_cdiv(W, 64), H, V * NG), dim3(256), 0, s, s0, s1, s2, img, wc,
-                       bc, H, W, NG, CO, out);
+                       bc, H, W, NG, CO, out, rgb4);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -102,6 +102,9 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
     const int p0 = (int)(grp / V) * PG_G;
     const int nrow = min(PG_G, P - p0);
     const float* m = map + (long long)v * H * W * C;
+    // split layout (C == 256): the r, g, b, 0 texels live in a [V,H,W,4] plane behind the latents; they are output
+    // column 64 (float4) of a row exactly like channels 256..259 of the interleaved 260-channel map
+    const float4* rgbp = C == 256 ? reinterpret_cast<const float4*>(map + (long long)V * H * W * 256) + (long long)v * H * W : nullptr;
     const int C4 = C / 4, L4 = ldo / 4;
 
     // ---- phase 1 ----
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
             }
         }
         // columns >= 256 of the 4 rows: lane = 4*t + j handles float4 column 64 + t of row r0 + j
-        if (C4 <= 65 && L4 <= 68) {
+        if (C4 <= 65 && L4 <= 68 && L4 > 64) {
             const int j = lane & (PG_B - 1), t = lane / PG_B, i = min(r0 + j, nrow - 1);
             const int c4 = 64 + t;
             // this lane's row parameters live in lane i (phase 1): fetch them across lanes
@@ -145,7 +148,9 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
             const float w00 = __shfl(b.w00, i), w01 = __shfl(b.w01, i), w10 = __shfl(b.w10, i), w11 = __shfl(b.w11, i);
             if (lane < 4 * PG_B && c4 < L4 && r0 + j < nrow) {
                 float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c4 < C4)
+                if (rgbp != nullptr && c4 == 64)
+                    r = pg_blend(rgbp[i00], rgbp[i01], rgbp[i10], rgbp[i11], w00, w01, w10, w11);
+                else if (c4 < C4)
                     r = pg_blend(reinterpret_cast<const float4*>(m + (long long)i00 * C)[c4],
                                  reinterpret_cast<const float4*>(m + (long long)i01 * C)[c4],
                                  reinterpret_cast<const float4*>(m + (long long)i10 * C)[c4],
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
             float* orow = out + ((long long)(p0 + r0 + j) * V + v) * ldo;
             if (lane < C4)
                 pg_store4<SPLIT>(orow, ldo, lane, pg_blend(q[j][0], q[j][1], q[j][2], q[j][3], w[j][0], w[j][1], w[j][2], w[j][3]), rm);
-            if (!(C4 <= 65 && L4 <= 68)) {
+            if (!(C4 <= 65 && L4 <= 68) && L4 > 64) {
                 // wide maps (full 384-channel map): remaining columns row by row
                 const int i = r0 + j;
                 const int i00 = __builtin_amdgcn_readlane(b.i00, i), i01 = __builtin_amdgcn_readlane(b.i01, i);

@@ -364,6 +364,12 @@ int th_segment_mean_rot_f64(th_ctx* c, const double* blend, const int32_t* off, 
     return th_segmean_rot_launch(blend, off, mem, nc, rot, (hipStream_t)stream);
 }
 
+int th_upsample_concat_split(th_ctx* c, const float* img, const float* lat0, const float* lat1, const float* lat2,
+                             const int32_t* dims_host, int V, int H, int W, float* out, th_stream stream) {
+    TH_REQUIRE(c && img && lat0 && lat1 && lat2 && dims_host && out, "null argument");
+    return th_upsample_concat_launch(img, lat0, lat1, lat2, dims_host, V, H, W, nullptr, nullptr, out, (hipStream_t)stream, 1);
+}
+
 int th_upsample_concat_nhwc(th_ctx* c, const float* img, const float* lat0, const float* lat1, const float* lat2,
                             const int32_t* dims_host, int V, int H, int W, const float* color_w, const float* color_b,
                             float* out_nhwc, th_stream stream) {
@@ -374,6 +380,7 @@ int th_upsample_concat_nhwc(th_ctx* c, const float* img, const float* lat0, cons
 }
 
 size_t th_paint_group_nhwc_workspace_bytes(int V, int n_verts, int C, int out_f) {
+    if (C == TH_MAP_SPLIT) C = TH_MAP_COMPACT;       // gathered rows are 260 wide either way
     size_t rows = (size_t)V * n_verts;
     return th_align(rows * C * 4) + th_align(rows * out_f * 4) + ThPacked::bytes(out_f, C) +
            th_align((size_t)(out_f * 260 + out_f) * 4);
@@ -384,7 +391,7 @@ int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, i
                         const th_linear* color_lift, const int32_t* off, const int32_t* mem, int nc, float* tokens,
                         void* ws, size_t ws_bytes, th_stream stream) {
     TH_REQUIRE(c && map_nhwc && verts && cams && scale && reduction && off && mem && tokens && ws, "null argument");
-    const bool compact = C == TH_MAP_COMPACT;
+    const bool compact = C == TH_MAP_COMPACT || C == TH_MAP_SPLIT;
     TH_REQUIRE(reduction->in_f == (compact ? TH_MAP_FULL : C), "reduction layer must take the (full) map's channel count");
     TH_REQUIRE(!compact || (color_lift && color_lift->w && lin_ok(*color_lift, 128, 3)),
                "a compact map needs the upsample_color layer (3 -> 128) to fold into the reduction layer");
@@ -393,13 +400,14 @@ int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, i
     hipStream_t s = (hipStream_t)stream;
     ThArena ar(ws, ws_bytes);
     const size_t rows = (size_t)V * nv;
-    float* g = ar.take<float>(rows * C);              // [nv][V][C]
+    const int CR = C == TH_MAP_SPLIT ? TH_MAP_COMPACT : C;     // width of a gathered row
+    float* g = ar.take<float>(rows * CR);             // [nv][V][CR]
     float* r = ar.take<float>(rows * out_f);          // [nv][V][out_f]
-    void* pk = ar.take<char>(ThPacked::bytes(out_f, C));
+    void* pk = ar.take<char>(ThPacked::bytes(out_f, CR));
     float* fold = ar.take<float>((size_t)out_f * 260 + out_f);
     TH_REQUIRE(fold != nullptr, "workspace carve failed");
     // sample the channels-last map at the projected vertices, then the 1x1 conv on those rows only
-    TH_TRY(th_pixgather_launch(map_nhwc, V, C, H, W, verts, nullptr, nullptr, nv, cams, scale, g, C, TH_ROWS_F32, s));
+    TH_TRY(th_pixgather_launch(map_nhwc, V, C, H, W, verts, nullptr, nullptr, nv, cams, scale, g, CR, TH_ROWS_F32, s));
     ThPacked P;
     th_linear red = *reduction;
     if (compact) {
@@ -408,7 +416,7 @@ int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, i
         red.w = fold; red.b = fold + (size_t)out_f * 260; red.in_f = 260;
     }
     TH_TRY(th_pack_linear(red, pk, &P, s));
-    TH_TRY(th_gemm(g, C, (int)rows, P, TH_ACT_NONE, r, out_f, s));
+    TH_TRY(th_gemm(g, CR, (int)rows, P, TH_ACT_NONE, r, out_f, s));
     return th_segmean_masked_launch(r, V, out_f, viz, nv, off, mem, nc, tokens, s);
 }
 
@@ -687,8 +695,8 @@ static int frame_ok(const th_frame* f) {
                    f->centres && f->rot,
                "incomplete th_frame");
     TH_REQUIRE(f->V >= 1 && f->V <= 4, "supported reference-view counts: 1..4");
-    TH_REQUIRE(f->map_channels == TH_MAP_FULL || f->map_channels == TH_MAP_COMPACT,
-               "th_frame.map_channels must be 384 (full pixel_feat_map) or 260 (compact map)");
+    TH_REQUIRE(f->map_channels == TH_MAP_FULL || f->map_channels == TH_MAP_COMPACT || f->map_channels == TH_MAP_SPLIT,
+               "th_frame.map_channels must be 384 (full pixel_feat_map), 260 (compact map) or 256 (compact map, split planes)");
     return 0;
 }
 
@@ -708,7 +716,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
                         float** raw_out, const uint8_t** mask_out, int64_t* stats_host, hipStream_t s, int prepass = 0,
                         int slot = 0, const int32_t** ray_hit_out = nullptr) {
     const int R = ps.R, S = ps.S, V = f->V;
-    const bool compact = f->map_channels == TH_MAP_COMPACT;
+    const bool compact = f->map_channels == TH_MAP_COMPACT || f->map_channels == TH_MAP_SPLIT;
     const int f_ld = compact ? 272 : 384;
     const int fmt = mlp_row_format(c, V);
     TH_REQUIRE(prepass == 1 || !compact || c->mlp.compact_ready,

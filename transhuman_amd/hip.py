@@ -84,6 +84,8 @@ SYMBOLS = {
     "th_upsample_concat_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p]),
+    "th_upsample_concat_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "th_paint_group_nhwc_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "th_paint_group_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ThLinear), C.POINTER(ThLinear),
@@ -478,6 +480,44 @@ def paint_group(holder_map, verts_world, cams, scale_xy, vizmap, off, mem, retur
     return (tokens, painted) if return_painted else tokens
 
 
+class SplitMap:
+    """The compact pixel map in the TH_MAP_SPLIT layout: one buffer holding [V,H,W,256] latents (1 KiB rows: a corner
+    texel is ONE aligned wave load; the interleaved 260-channel rows straddle nine 128-byte lines instead of eight and
+    cost a second load instruction for their 65th float4) followed by [V,H,W,4] (r, g, b, 0)."""
+
+    def __init__(self, buf, V, H, W):
+        self.buf, self.V, self.H, self.W = buf, V, H, W
+        self.shape = (V, H, W, 256)
+        self.device = buf.device
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
+
+    @property
+    def latents(self):
+        return self.buf[: self.V * self.H * self.W * 256].view(self.V, self.H, self.W, 256)
+
+    @property
+    def rgb0(self):
+        return self.buf[self.V * self.H * self.W * 256:].view(self.V, self.H, self.W, 4)
+
+    def interleaved(self):
+        """the same map as one [V,H,W,260] tensor (tests / A-B)"""
+        return torch.cat([self.latents, self.rgb0], dim=-1).contiguous()
+
+
+def upsample_concat_split(images, lat0, lat1, lat2):
+    """th_upsample_concat_split: the compact map (colour lift folded into the consumers) in the split layout."""
+    lib = load_library()
+    img, l0, l1, l2 = _f32(images), _f32(lat0), _f32(lat1), _f32(lat2)
+    V, _, H, W = img.shape
+    assert l0.shape[1] == 64 and l1.shape[1] == 64 and l2.shape[1] == 128
+    dims = (C.c_int32 * 6)(l0.shape[2], l0.shape[3], l1.shape[2], l1.shape[3], l2.shape[2], l2.shape[3])
+    buf = torch.empty(V * H * W * 260, dtype=torch.float32, device=img.device)
+    _check(lib.th_upsample_concat_split(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf), _stream()))
+    return SplitMap(buf, V, H, W)
+
+
 def upsample_concat_nhwc(images, lat0, lat1, lat2, color_w=None, color_b=None):
     """Encoder tail (encoder.py:133-146) -> channels-last pixel_feat_map [V,H,W,384], or with
     color_w=None the compact map [V,H,W,260] (256 latent | r g b | 0; the lift is folded into the consumers)."""
@@ -499,7 +539,7 @@ def paint_group_nhwc(map_nhwc, verts_world, cams, scale_xy, vizmap, red_w, red_b
     """Sample the channels-last map at the projected vertices, apply reduction_layer there, mask, pool.
     A compact (260-channel) map needs the colour lift (color_w, color_b) to fold into the reduction layer."""
     lib = load_library()
-    V, H, W, Cc = map_nhwc.shape
+    V, H, W, Cc = map_nhwc.shape                      # (a SplitMap reports 256 channels: TH_MAP_SPLIT)
     v = _f32(verts_world).reshape(-1, 3)
     nc = off.numel() - 1
     viz = vizmap.to(torch.uint8).contiguous() if vizmap is not None else None
@@ -815,7 +855,8 @@ class Frame:
         self.map = pixel_map_nhwc
         self.tokens, self.centres, self.rot = _f32(tokens), _f32(centres).reshape(-1, 3), _f32(rot).reshape(-1, 9)
         V, H, W, Cc = pixel_map_nhwc.shape
-        assert Cc in (384, 260), "pixel map must be the full (384) or the compact (260) channels-last map"
+        assert Cc in (384, 260) or isinstance(pixel_map_nhwc, SplitMap), \
+            "pixel map must be the full (384) or the compact (260 interleaved / SplitMap) channels-last map"
         self.c = ThFrame(_p(self.verts), self.verts.shape[0], _p(self.Rh), _p(self.Th), _p(self.cams), _p(self.scale),
                          _p(self.map), V, H, W, Cc, _p(self.tokens), _p(self.centres), _p(self.rot),
                          self.tokens.shape[1], hull_thresh, small_frame_rays)

@@ -111,7 +111,8 @@ class Renderer:
         bilinear sampling).  False: the reference's op order through ``net.encoder(images)``.
         compact_map=True (default, only with the fused tail): the last 128 map channels are
         upsample_color(img) = Wc rgb + bc, a linear lift of 3 numbers, so the map keeps r,g,b instead
-        ([V,H,W,260]) and the lift is folded into the four layers that read those channels (alpha_res_0,
+        (split planes [V,H,W,256] + [V,H,W,4], hip.SplitMap; compact_map="interleaved": one [V,H,W,260] tensor)
+        and the lift is folded into the four layers that read those channels (alpha_res_0,
         rgb_res_0, rgb_res_1, reduction_layer: W' = [W_lat | W_col Wc], b' = b + W_col bc) -- a third less
         map/gather/staging traffic and 12 % fewer MLP MACs, same function.
         All forms give the same tokens / pixels to fp32 rounding (tests/test_gpu_parity.py).
@@ -134,8 +135,10 @@ class Renderer:
             V = images.shape[0]
             lat = enc.trunk(images)
             cw, cb = enc.upsample_color.weight, enc.upsample_color.bias
-            if compact_map:
+            if compact_map == "interleaved":            # A/B: one [V,H,W,260] tensor (1040-byte texel rows)
                 map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2])
+            elif compact_map:
+                map_nhwc = hip.upsample_concat_split(images, lat[0], lat[1], lat[2])
             else:
                 map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2], cw, cb)
             scale = hip.feat_scale(enc.feat_scale(H, W), image_shape, dev)
