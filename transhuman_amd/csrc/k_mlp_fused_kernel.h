@@ -74,6 +74,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
     h[0] = (_Float16)x0;
     h[1] = (_Float16)x1;
     hi = *reinterpret_cast<unsigned*>(&h);
+    asm("" : "+v"(hi));          // one packed register from here on (keeps the compiler from re-deriving the halves)
     unsigned l;
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
@@ -322,7 +323,9 @@ __device__ __forceinline__ void gemm_dual_fc3_vfa(const char* __restrict__ mhi, 
     zero_acc<2, 1>(a3);
     zero_acc<1, V>(va);
     FM_SB();
-#pragma unroll 1
+    // (fully unrolled: as a rolled loop the five loop-carried accumulator tiles were copied between AGPR ranges
+    // every iteration -- 413 v_accvgpr_mov in the body -- and the phase ran at half its MFMA rate)
+#pragma unroll
     for (int kb = 0; kb < KB; kb += D) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
@@ -421,8 +424,9 @@ __device__ __forceinline__ void finish_tile_b(f32x16 (&acc)[RT], const BiasT& b,
 // almost never after the first tiles.  The host reads the table per frame (th_range_read) and re-renders on the
 // fp32 MFMA path when a slot reached 6e4 (overflow / NaN) or stayed below 2^-6 (resolution).
 typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+template <bool NONNEG = false>
 __device__ __forceinline__ void range_acc(unsigned& rm, unsigned hi2) {
-    unsigned a = hi2 & 0x7fff7fffu;
+    unsigned a = NONNEG ? hi2 : (hi2 & 0x7fff7fffu);      // relu outputs carry no sign bit: no masking needed
     us2v m = __builtin_elementwise_max(*reinterpret_cast<us2v*>(&rm), *reinterpret_cast<us2v*>(&a));
     rm = *reinterpret_cast<unsigned*>(&m);
 }
@@ -432,7 +436,7 @@ __device__ __forceinline__ void range_commit(unsigned* __restrict__ table, int s
     rm = 0u;
 }
 
-template <int STR>
+template <int STR, bool NONNEG = true>
 __device__ __forceinline__ void store_tile_h(const f32x16& t, int row, int col0, char* __restrict__ hi,
                                              char* __restrict__ lo, int lane, unsigned& rm) {
 #pragma unroll
@@ -441,12 +445,11 @@ __device__ __forceinline__ void store_tile_h(const f32x16& t, int row, int col0,
         uint2 a, b;
         split_pair(t[4 * g], t[4 * g + 1], a.x, b.x);
         split_pair(t[4 * g + 2], t[4 * g + 3], a.y, b.y);
-        range_acc(rm, a.x);
-        range_acc(rm, a.y);
+        range_acc<NONNEG>(rm, a.x);
+        range_acc<NONNEG>(rm, a.y);
         *reinterpret_cast<uint2*>(hi + row * STR + 2 * c) = a;
         *reinterpret_cast<uint2*>(lo + row * STR + 2 * c) = b;
     }
-    FM_SB();   // VALU temporaries must be arch VGPRs (<= 256): do not let the next tile's conversions hoist above
 }
 // same tile as fp32 (key buffers for the cross-view dots)
 __device__ __forceinline__ void store_tile_f(const f32x16& t, int row, int col0, float* __restrict__ dst, int lane) {
@@ -585,12 +588,17 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             finish_tile_b<1>(a1[c], b0[c], P.fc_0pe.inv_scale, false);
 #pragma unroll
             for (int r = 0; r < V; ++r) {
+                // packed adds first, the relus after them: independent consecutive instructions
+                f32x2 u[8];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    acc2[c][r][4 * g + 0] = fmaxf(a1[c][0][4 * g + 0] + st[c][r][g].x, 0.f);
-                    acc2[c][r][4 * g + 1] = fmaxf(a1[c][0][4 * g + 1] + st[c][r][g].y, 0.f);
-                    acc2[c][r][4 * g + 2] = fmaxf(a1[c][0][4 * g + 2] + st[c][r][g].z, 0.f);
-                    acc2[c][r][4 * g + 3] = fmaxf(a1[c][0][4 * g + 3] + st[c][r][g].w, 0.f);
+                    u[2 * g] = (f32x2){a1[c][0][4 * g + 0], a1[c][0][4 * g + 1]} + (f32x2){st[c][r][g].x, st[c][r][g].y};
+                    u[2 * g + 1] = (f32x2){a1[c][0][4 * g + 2], a1[c][0][4 * g + 3]} + (f32x2){st[c][r][g].z, st[c][r][g].w};
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    acc2[c][r][2 * q] = fmaxf(u[q][0], 0.f);
+                    acc2[c][r][2 * q + 1] = fmaxf(u[q][1], 0.f);
                 }
                 store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
             }
@@ -696,22 +704,32 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                     kx[v] = *reinterpret_cast<const float4*>(kpb + (v * 32 + p) * KSTR + 4 * (c8 + 8 * q));
                     sx[v] = *reinterpret_cast<const float4*>(ksb + (v * 32 + p) * KSTR + 4 * (c8 + 8 * q));
                 }
+                // component outermost: the V*V accumulation chains advance together (independent consecutive FMAs)
 #pragma unroll
-                for (int j = 0; j < V; ++j)
+                for (int comp = 0; comp < 4; ++comp)
 #pragma unroll
-                    for (int i = 0; i < V; ++i) {
-                        float s = acc[j * V + i];
-                        s = fmaf(kx[j].x, sx[i].x, s); s = fmaf(kx[j].y, sx[i].y, s);
-                        s = fmaf(kx[j].z, sx[i].z, s); s = fmaf(kx[j].w, sx[i].w, s);
-                        acc[j * V + i] = s;
-                    }
+                    for (int j = 0; j < V; ++j)
+#pragma unroll
+                        for (int i = 0; i < V; ++i) {
+                            const float a = comp == 0 ? kx[j].x : comp == 1 ? kx[j].y : comp == 2 ? kx[j].z : kx[j].w;
+                            const float b = comp == 0 ? sx[i].x : comp == 1 ? sx[i].y : comp == 2 ? sx[i].z : sx[i].w;
+                            acc[j * V + i] = fmaf(a, b, acc[j * V + i]);
+                        }
             }
 #pragma unroll
             for (int ji = 0; ji < V * V; ++ji) {
                 float s = acc[ji];
+#ifdef FM_EXP_SHFL
                 s += __shfl_xor(s, 1);
                 s += __shfl_xor(s, 2);
                 s += __shfl_xor(s, 4);
+#else
+                // sum over the 8 lanes of a sample with DPP moves (VALU, no LDS round trip like ds_bpermute): quad
+                // neighbours, quad halves, then the mirrored lane of the other quad of the 8-lane group
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+                s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));  // row_half_mirror
+#endif
                 if (c8 == 0) probs[ji * 32 + p] = s / 11.313708498984761f;
             }
         }
@@ -738,30 +756,47 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         // The key buffer in ABUF was last read before the two barriers above, so each tile is stored as
         // soon as it is formed.
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c) {
+            // channel pairs outermost: every vp value leaves its accumulator register once and serves the V outputs
+            // (the accumulators live in AGPRs: each use from VALU costs a v_accvgpr_read)
+            f32x16 n[V];
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                f32x16 n;
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = bn[c].g[g];
+                const f32x2 bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
+                // packed fp32 FMAs (two channels per instruction); the 2 x V accumulation chains of a group advance
+                // together, j outermost, so that consecutive instructions are independent (written chain by chain the
+                // compiler emitted one serial dependency chain through a single temporary: 5 k cycles for this block)
+                f32x2 v2[2][V], t[2][V];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 b4 = bn[c].g[g];
-                    const f32x2 bb[2] = {{b4.x, b4.y}, {b4.z, b4.w}};
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 4 * g + 2 * h;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {         // packed fp32 FMAs: two channels per instruction
-                        const int e = 4 * g + 2 * h;
-                        f32x2 t = {vs[c][i][e], vs[c][i][e + 1]};
-                        t = t + bb[h];
+                    for (int j = 0; j < V; ++j) v2[h][j] = (f32x2){vp[c][j][e], vp[c][j][e + 1]};
 #pragma unroll
-                        for (int j = 0; j < V; ++j) {
-                            const f32x2 v2 = {vp[c][j][e], vp[c][j][e + 1]}, a2 = {A[j][i], A[j][i]};
-                            t = __builtin_elementwise_fma(v2, a2, t);
-                        }
-                        n[e] = fmaxf(t[0], 0.f);
-                        n[e + 1] = fmaxf(t[1], 0.f);
-                    }
+                    for (int i = 0; i < V; ++i) t[h][i] = (f32x2){vs[c][i][e], vs[c][i][e + 1]} + bb[h];
                 }
-                store_tile_h<STR256>(n, i * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < V; ++i) {
+                            const f32x2 a2 = {A[j][i], A[j][i]};
+                            t[h][i] = __builtin_elementwise_fma(v2[h][j], a2, t[h][i]);
+                        }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        n[i][4 * g + 2 * h] = fmaxf(t[h][i][0], 0.f);
+                        n[i][4 * g + 2 * h + 1] = fmaxf(t[h][i][1], 0.f);
+                    }
             }
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+                store_tile_h<STR256>(n[i], i * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
+        }
         range_commit(P.range, TH_RANGE_N, seen_n, rmax);
         FM_SYNC();
     }
@@ -911,7 +946,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 for (int r = 1; r < V; ++r) a = a + (acc2[0][r][e] + acc2[1][r][e]);
                 m[e] = a * inv_v;
             }
-            store_tile_h<STR128>(m, myrow, wave * 32, f4_hi, f4_lo, lane, rmax);
+            store_tile_h<STR128, false>(m, myrow, wave * 32, f4_hi, f4_lo, lane, rmax);      // (signed: relu(.) + rgb_res_1)
             range_commit(P.range, TH_RANGE_F4, seen_4, rmax);
         }
         FM_SYNC();
