@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {
   name=$1; shift
   timeout 200 rocprofv3 --pmc "$@" --kernel-include-regex "${KREGEX:-mlp_fused}" --output-format csv -d $out -o pass_$name -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/pass_$name.log 2>&1
+      python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $out/pass_$name.log 2>&1
 }
 if [ -n "$2" ]; then shift; name=$1; shift; run $name "$@"; ls $out; exit 0; fi
 run A SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES

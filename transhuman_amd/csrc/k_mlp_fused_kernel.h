@@ -15,6 +15,8 @@
 #pragma once
 #include <hip/hip_fp16.h>
 
+#include <utility>
+
 #include "th_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -40,15 +42,27 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 // barrier + optional cycle accounting (developer aid: TH_FUSED_DBG=1 prints the average cycles between
 // consecutive barriers over every 16th tile of one launch)
-#define FM_SYNC()                                                                                        \
+#define FM_SYNC_(BARRIER)                                                                                 \
     do {                                                                                                 \
-        __syncthreads();                                                                                 \
+        BARRIER;                                                                                         \
         if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {                                    \
             long long now_ = clock64();                                                                  \
             atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + dbg_i++), (unsigned long long)(now_ - dbg_t)); \
             dbg_t = now_;                                                                                \
         }                                                                                                \
     } while (0)
+// full barrier (waits for every outstanding memory operation: needed behind LDS-DMA staging, whose LDS writes are
+// tracked by vmcnt)
+#define FM_SYNC() FM_SYNC_(__syncthreads())
+// LDS-only barrier: orders LDS traffic (s_waitcnt lgkmcnt(0) + s_barrier) and leaves global loads in flight -- bias /
+// head-row / weight-fragment requests issued in front of it keep travelling while the waves meet
+#define FM_LDS_BARRIER()                                                      \
+    do {                                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");       \
+        __builtin_amdgcn_s_barrier();                                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");       \
+    } while (0)
+#define FM_SYNCL() FM_SYNC_(FM_LDS_BARRIER())
 
 // cycle stamp without a barrier (same accounting as FM_SYNC: wave 0 of every 16th tile)
 #define FM_STAMP()                                                                                       \
@@ -137,14 +151,18 @@ __device__ __forceinline__ void load_xfrag(const char* __restrict__ ahi, const c
 
 // one k-block (16 deep): acc[c][r] += W(c) * X(r)^T as three fp16 products (lo*hi, hi*lo, hi*hi),
 // term-major so consecutive MFMAs hit different accumulators
-template <int RT, int CT>
+// FIRST (bit c = column tile c): those accumulators start from the inline constant 0 (no zero-initialisation pass:
+// 16 v_accvgpr_write per tile)
+template <int RT, int CT, int FIRST = 0>
 __device__ __forceinline__ void mfma_kblock(const uint4 (&w)[CT][2], const h8 (&xh)[RT], const h8 (&xl)[RT],
                                             f32x16 (&acc)[CT][RT]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
         for (int r = 0; r < RT; ++r)
-            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&w[c][1]), xh[r], acc[c][r], 0, 0, 0);
+            acc[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&w[c][1]), xh[r],
+                                                               ((FIRST >> c) & 1) ? zero : acc[c][r], 0, 0, 0);
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
@@ -205,68 +223,118 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[CT][RT]) {
             for (int e = 0; e < 16; ++e) acc[c][r][e] = 0.f;
 }
 
-//  * ZERO: the accumulators are cleared AFTER the first weight / activation fragments have been requested, so the
-//    96..144 accumulator writes run under that (otherwise exposed) L2 / LDS round trip.
-template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, bool ZERO>
-__device__ __forceinline__ void gemm_phase_impl(const char* __restrict__ ahi, const char* __restrict__ alo,
-                                                const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
-    static_assert((D & 1) == 0, "ring depth must be even (activation ping-pong parity)");
-    const uint4* wl = wp + lane;     // this wave's stream: per kb: CT x {hi, lo} x 64 lanes x 16 B
-    const int aoff = (lane & 31) * STR + (lane >> 5) * 16;
-    uint4 w[D][CT][2];
-    h8 xh[2][RT], xl[2][RT];
+struct FmNoStamp { __device__ __forceinline__ void operator()() const {} };
+
+// Weight ring of a GEMM phase.  A wave's dwordx4 load costs the CU's address unit ~16 cycles whatever it hits, so the
+// D-1 blocks a steady-state ring keeps in flight are NOT requested up front (3 x 2*CT loads x 4 waves = 1.1 k cycles
+// of address-unit time in front of the first MFMA at CT = 3): only block 0 is, and the first ring step requests blocks
+// 1 .. D-1 in the shadow of block 0's MFMAs (RAMP).  Block 0 does not depend on the LDS operand: a caller may request
+// it BEFORE the barrier in front of the phase (ring_prefetch0 + PRE) -- the barriers around the GEMM phases order LDS
+// only (FM_SYNCL), so the L2 round trip runs under the barrier.
+template <int CT, int D>
+__device__ __forceinline__ void ring_prefetch0(const uint4* __restrict__ wp, int lane, uint4 (&w)[D][CT][2]) {
+    load_wfrag<CT>(wp + lane, 0, w[0]);
+}
+// (phases shorter than the ring, KB < D: everything up front)
+template <int CT, int D>
+__device__ __forceinline__ void ring_prefetch(const uint4* __restrict__ wp, int KB, int lane, uint4 (&w)[D][CT][2]) {
+    const uint4* wl = wp + lane;
 #pragma unroll
     for (int j = 0; j < D - 1; ++j)
         if (j < KB) load_wfrag<CT>(wl, j, w[j]);
-    load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, 0, xh[0], xl[0]);
-    FM_SB();
-    if (ZERO) {
-        zero_acc<CT, RT>(acc);
-        FM_SB();
-    }
-    int kb = 0;
-#pragma unroll 1
-    for (; kb + D <= KB; kb += D) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-#ifdef FM_NO_INTERLEAVE
-            if (kb + j + D - 1 < KB) load_wfrag<CT>(wl, kb + j + D - 1, w[(j + D - 1) % D]);
-            if (kb + j + 1 < KB) load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j + 1, xh[(j + 1) & 1], xl[(j + 1) & 1]);
-            FM_SB();
-            mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
-            FM_SB();
-#else
-            // branch-free (indices clamped: the last blocks re-request a fragment nobody consumes) so that
-            // the prefetch and the MFMA burst form ONE scheduling region, then ask for one memory
-            // instruction after each of the first MFMAs: the 2*CT global loads + 2*RT ds_reads issue in the
-            // shadow of running MFMAs instead of in front of the burst.
-            const int kw = (kb + j + D - 1 < KB) ? kb + j + D - 1 : KB - 1;
-            const int kx = (kb + j + 1 < KB) ? kb + j + 1 : KB - 1;
+}
+
+// one ring step: request block kb+j+D-1 (weights; RAMP: blocks 1 .. D-1) and kb+j+1 (activations), multiply block kb+j
+template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int FIRST, int J, bool RAMP>
+__device__ __forceinline__ void ring_step(const char* __restrict__ ahi, const char* __restrict__ alo, const uint4* __restrict__ wl,
+                                          int aoff, int kb, int KB, uint4 (&w)[D][CT][2], h8 (&xh)[2][RT], h8 (&xl)[2][RT],
+                                          f32x16 (&acc)[CT][RT]) {
+    constexpr int j = J;
+    // branch-free (indices clamped: the last blocks re-request a fragment nobody consumes) so that
+    // the prefetch and the MFMA burst form ONE scheduling region, then ask for one memory
+    // instruction after each of the first MFMAs: the 2*CT global loads + 2*RT ds_reads issue in the
+    // shadow of running MFMAs instead of in front of the burst.
+    const int kx = (kb + j + 1 < KB) ? kb + j + 1 : KB - 1;
 #ifndef FM_EXP_NOW       // timing experiments only (wrong results): drop the in-loop weight / activation loads
-            load_wfrag<CT>(wl, kw, w[(j + D - 1) % D]);
-#endif
-            if (XPP) {
-#ifndef FM_EXP_NOX
-                load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kx, xh[(j + 1) & 1], xl[(j + 1) & 1]);
-#endif
-                mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
-            } else {   // register-tight phases: one activation set, read right before its burst
-                load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, xh[0], xl[0]);
-                mfma_kblock<RT, CT>(w[j], xh[0], xl[0], acc);
-            }
-            constexpr int NMEM = 2 * CT + 2 * RT, NMF = 3 * CT * RT;
-            constexpr int NPAIR = NMEM < NMF ? NMEM : NMF;
+    if (RAMP) {
 #pragma unroll
-            for (int q = 0; q < NPAIR; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);     // one VMEM read or DS read
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NPAIR, 0);
-            FM_SB();
+        for (int q = 1; q < D; ++q) load_wfrag<CT>(wl, q < KB ? q : KB - 1, w[q]);
+    } else {
+        const int kw = (kb + j + D - 1 < KB) ? kb + j + D - 1 : KB - 1;
+        load_wfrag<CT>(wl, kw, w[(j + D - 1) % D]);
+    }
 #endif
+    if (XPP) {
+#ifndef FM_EXP_NOX
+        load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kx, xh[(j + 1) & 1], xl[(j + 1) & 1]);
+#endif
+        mfma_kblock<RT, CT, FIRST>(w[j], xh[j & 1], xl[j & 1], acc);
+    } else {   // register-tight phases: one activation set, read right before its burst
+        load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, xh[0], xl[0]);
+        mfma_kblock<RT, CT, FIRST>(w[j], xh[0], xl[0], acc);
+    }
+    constexpr int NMEM = 2 * CT * (RAMP ? D - 1 : 1) + 2 * RT, NMF = 3 * CT * RT;
+    if constexpr (NMEM <= NMF) {
+#pragma unroll
+        for (int q = 0; q < NMEM; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);     // one VMEM read or DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - NMEM, 0);
+    } else {        // more memory instructions than MFMAs (ramp-up of a small tile): spread evenly
+        constexpr int BASE = NMEM / NMF, EXTRA = NMEM % NMF;
+#pragma unroll
+        for (int q = 0; q < EXTRA; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x120, BASE + 1, 0);
+        }
+#pragma unroll
+        for (int q = EXTRA; q < NMF; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x120, BASE, 0);
         }
     }
-    // tail (KB % D blocks): their weight fragments were requested by the guarded loads above
+    FM_SB();
+}
+
+template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int FIRST, bool RAMP, int... Js>
+__device__ __forceinline__ void ring_round(std::integer_sequence<int, Js...>, const char* __restrict__ ahi,
+                                           const char* __restrict__ alo, const uint4* __restrict__ wl, int aoff, int kb, int KB,
+                                           uint4 (&w)[D][CT][2], h8 (&xh)[2][RT], h8 (&xl)[2][RT], f32x16 (&acc)[CT][RT]) {
+    (ring_step<RT, CT, STR, ROWSTEP, D, XPP, (Js == 0 ? FIRST : 0), Js, (RAMP && Js == 0)>(ahi, alo, wl, aoff, kb, KB, w, xh, xl, acc), ...);
+}
+
+//  * ZMASK (bit c = column tile c): those tiles are acc = W * A^T, the others accumulate.  The first MFMA of a ZMASK
+//    accumulator takes the inline constant 0 as C (no accumulator clearing pass).
+//  * RAMP (KB >= D): the first ring round is peeled out of the loop: it carries the ZMASK MFMAs and the ring ramp-up.
+//    Without it (KB < D) the phase is the up-front prefetch plus the tail.
+//  * PRE: the caller has already requested block 0 (ring_prefetch0) / the first D-1 blocks (ring_prefetch, !RAMP).
+template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int ZMASK, bool PRE, bool RAMP = true, class ST = FmNoStamp>
+__device__ __forceinline__ void gemm_phase_core(const char* __restrict__ ahi, const char* __restrict__ alo,
+                                                const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT],
+                                                uint4 (&w)[D][CT][2], ST stamp = ST()) {
+    static_assert((D & 1) == 0, "ring depth must be even (activation ping-pong parity)");
+    static_assert(RAMP || ZMASK == 0, "zero-start tiles need the peeled first round");
+    const uint4* wl = wp + lane;     // this wave's stream: per kb: CT x {hi, lo} x 64 lanes x 16 B
+    const int aoff = (lane & 31) * STR + (lane >> 5) * 16;
+    h8 xh[2][RT], xl[2][RT];
+    if (!PRE) {
+        if (RAMP) ring_prefetch0<CT, D>(wp, lane, w);
+        else ring_prefetch<CT, D>(wp, KB, lane, w);
+    }
+    load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, 0, xh[0], xl[0]);
+    FM_SB();
+    stamp();
+    int kb = 0;
+    if (RAMP) {
+        ring_round<RT, CT, STR, ROWSTEP, D, XPP, ZMASK, true>(std::make_integer_sequence<int, D>{}, ahi, alo, wl, aoff, 0, KB, w, xh, xl, acc);
+        kb = D;
+    }
+#pragma unroll 1
+    for (; kb + D <= KB; kb += D)
+        ring_round<RT, CT, STR, ROWSTEP, D, XPP, 0, false>(std::make_integer_sequence<int, D>{}, ahi, alo, wl, aoff, kb, KB, w, xh, xl, acc);
+    stamp();
+    // tail (KB % D blocks): their weight fragments were requested by the clamped loads above
 #pragma unroll
     for (int j = 0; j < D - 1; ++j)
         if (kb + j < KB) {
@@ -280,6 +348,13 @@ __device__ __forceinline__ void gemm_phase_impl(const char* __restrict__ ahi, co
             }
             FM_SB();
         }
+}
+
+template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, bool ZERO, bool RAMP = true>
+__device__ __forceinline__ void gemm_phase_impl(const char* __restrict__ ahi, const char* __restrict__ alo,
+                                                const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT]) {
+    uint4 w[D][CT][2];
+    gemm_phase_core<RT, CT, STR, ROWSTEP, D, XPP, (ZERO ? (1 << CT) - 1 : 0), false, RAMP>(ahi, alo, wp, KB, lane, acc, w);
 }
 
 // acc += W * A^T
@@ -312,18 +387,15 @@ __device__ __forceinline__ void gemm_dual_fc3_vfa(const char* __restrict__ mhi, 
     const int aoff = (lane & 31) * STR256 + (lane >> 5) * 16;
     uint4 r3[D][2][2], ra[D][1][2];
     h8 mh[2][1], ml[2][1], xh[2][V], xl[2][V];
-#pragma unroll
-    for (int j = 0; j < D - 1; ++j) {
-        load_wfrag<2>(w3l, j, r3[j]);
-        load_wfrag<1>(wal, j, ra[j]);
-    }
+    // ring ramp-up as in gemm_phase_core: block 0 up front, blocks 1 .. D-1 under the MFMAs of block 0
+    load_wfrag<2>(w3l, 0, r3[0]);
+    load_wfrag<1>(wal, 0, ra[0]);
     load_xfrag<1, STR256, 0>(mhi, mlo, aoff, 0, mh[0], ml[0]);
     load_xfrag<V, STR256, 32 * STR256>(xhi, xlo, aoff, 0, xh[0], xl[0]);
     FM_SB();
-    zero_acc<2, 1>(a3);
-    zero_acc<1, V>(va);
-    FM_SB();
-    // (fully unrolled: as a rolled loop the five loop-carried accumulator tiles were copied between AGPR ranges
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // (the first MFMA of every accumulator takes the inline constant 0 as C: no clearing pass;
+    // fully unrolled: as a rolled loop the five loop-carried accumulator tiles were copied between AGPR ranges
     // every iteration -- 413 v_accvgpr_mov in the body -- and the phase ran at half its MFMA rate)
 #pragma unroll
     for (int kb = 0; kb < KB; kb += D) {
@@ -331,8 +403,17 @@ __device__ __forceinline__ void gemm_dual_fc3_vfa(const char* __restrict__ mhi, 
         for (int j = 0; j < D; ++j) {
             const int kw = (kb + j + D - 1 < KB) ? kb + j + D - 1 : KB - 1;
             const int kx = (kb + j + 1 < KB) ? kb + j + 1 : KB - 1;
-            load_wfrag<2>(w3l, kw, r3[(j + D - 1) % D]);
-            load_wfrag<1>(wal, kw, ra[(j + D - 1) % D]);
+            const bool ramp = kb == 0 && j == 0;
+            if (ramp) {
+#pragma unroll
+                for (int q = 1; q < D; ++q) {
+                    load_wfrag<2>(w3l, q, r3[q]);
+                    load_wfrag<1>(wal, q, ra[q]);
+                }
+            } else {
+                load_wfrag<2>(w3l, kw, r3[(j + D - 1) % D]);
+                load_wfrag<1>(wal, kw, ra[(j + D - 1) % D]);
+            }
             load_xfrag<1, STR256, 0>(mhi, mlo, aoff, kx, mh[(j + 1) & 1], ml[(j + 1) & 1]);
             load_xfrag<V, STR256, 32 * STR256>(xhi, xlo, aoff, kx, xh[(j + 1) & 1], xl[(j + 1) & 1]);
             // term-major over the 2 + V accumulators (an accumulator recurs every 2 + V MFMAs: the 2-accumulator fc_3
@@ -341,25 +422,42 @@ __device__ __forceinline__ void gemm_dual_fc3_vfa(const char* __restrict__ mhi, 
             for (int t = 0; t < 3; ++t) {
                 const int wp = t == 0 ? 1 : 0;                    // weight plane: lo, hi, hi
                 const bool xlo = t == 1;                           // activation plane: hi, lo, hi
+                const bool first = kb == 0 && j == 0 && t == 0;
                 a3[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&r3[j][0][wp]),
-                                                                  xlo ? ml[j & 1][0] : mh[j & 1][0], a3[0][0], 0, 0, 0);
+                                                                  xlo ? ml[j & 1][0] : mh[j & 1][0], first ? zero : a3[0][0], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < V; ++r) {
                     va[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&ra[j][0][wp]),
-                                                                      xlo ? xl[j & 1][r] : xh[j & 1][r], va[0][r], 0, 0, 0);
+                                                                      xlo ? xl[j & 1][r] : xh[j & 1][r], first ? zero : va[0][r], 0, 0, 0);
                     if (r == 0)
                         a3[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&r3[j][1][wp]),
-                                                                          xlo ? ml[j & 1][0] : mh[j & 1][0], a3[1][0], 0, 0, 0);
+                                                                          xlo ? ml[j & 1][0] : mh[j & 1][0], first ? zero : a3[1][0], 0, 0, 0);
                 }
             }
-            constexpr int NMEM = 6 + 2 + 2 * V, NMF = 6 + 3 * V;
-            constexpr int NPAIR = NMEM < NMF ? NMEM : NMF;
+            constexpr int NMF = 6 + 3 * V;
+            if (ramp) {     // 6 * (D - 1) + 2 + 2 V memory instructions, spread evenly behind the MFMAs
+                constexpr int NMEM = 6 * (D - 1) + 2 + 2 * V;
+                constexpr int BASE = NMEM / NMF, EXTRA = NMEM % NMF;
 #pragma unroll
-            for (int q = 0; q < NPAIR; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
-                __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);     // one VMEM read or DS read
+                for (int q = 0; q < EXTRA; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x120, BASE + 1, 0);
+                }
+#pragma unroll
+                for (int q = EXTRA; q < NMF; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x120, BASE, 0);
+                }
+            } else {
+                constexpr int NMEM = 6 + 2 + 2 * V;
+                constexpr int NPAIR = NMEM < NMF ? NMEM : NMF;
+#pragma unroll
+                for (int q = 0; q < NPAIR; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x120, 1, 0);     // one VMEM read or DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF - NPAIR, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, NMF - NPAIR, 0);
             FM_SB();
         }
     }
@@ -582,7 +680,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 for (int g = 0; g < 4; ++g)
                     st[c][r][g] = *reinterpret_cast<const float4*>(abuf + (r * 32 + myrow) * STOK_STR +
                                                                    4 * (wave * 64 + c * 32 + 8 * g + 4 * (lane >> 5)));
-        FM_SYNC();                                   // every wave has its stok values in registers: ABUF may take s
+        FM_SYNCL();                                   // every wave has its stok values in registers: ABUF may take s
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             finish_tile_b<1>(a1[c], b0[c], P.fc_0pe.inv_scale, false);
@@ -605,13 +703,19 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         }
         range_commit(P.range, TH_RANGE_S, seen_s, rmax);
     }
-    FM_SYNC();
+    // The first weight block of a phase does not depend on the LDS operand: it is requested in FRONT of the barrier
+    // that publishes the operand (the L2 round trip runs under the barrier instead of behind it).
+    uint4 wk3[FM_RING_D][3][2];
+    FM_SB();
+    ring_prefetch0<3, FM_RING_D>(wslice(P.kv1, wave, 3, 0), lane, wk3);
+    FM_SYNCL();
     // kv layers: column tile 0 = key tile `wave` (cols wave*32..), tiles 1,2 = value cols 128 + wave*64 ..
     f32x16 vs[2][V];
     float* ksb = reinterpret_cast<float*>(mbuf);                    // [ROWS][KSTR] fp32 keys of the token branch
     {
         f32x16 acc3[3][V];
-        gemm_phase_z<V, 3, STR256>(abuf, a256_lo, wslice(P.kv1, wave, 3, 0), P.kv1.KB, lane, acc3);
+        gemm_phase_core<V, 3, STR256, 32 * STR256, FM_RING_D, true, 7, true>(abuf, a256_lo, wslice(P.kv1, wave, 3, 0), P.kv1.KB, lane,
+                                                                            acc3, wk3);
 #ifdef FM_STAMPS
         FM_STAMP();
 #endif
@@ -630,25 +734,27 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             vs[1][r] = acc3[2][r];
         }
     }
-    FM_SYNC();
+    FM_SYNCL();
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
     stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
 #ifdef FM_STAMPS
     FM_STAMP();
 #endif
+    uint4 wk2[FM_RING_D2][2][2];
+    ring_prefetch0<2, FM_RING_D2>(wslice(P.ar0, wave, 2, 0), lane, wk2);
     FM_SYNC();
-    gemm_phase_z<V, 2, FL::SA>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2);
+    gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 3, true>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2, wk2);
 #ifdef FM_STAMPS
     FM_STAMP();
 #endif
     const BiasT bp[2] = {load_bias(P.ar0.bias, wave * 64, lane), load_bias(P.ar0.bias, wave * 64 + 32, lane)};
-    FM_SYNC();
+    FM_SYNCL();
     if constexpr (FL::NB > 0) {
         stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
         FM_SYNC();
         gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.ar0, wave, 2, FL::NA), FL::NB, lane, acc2);
-        FM_SYNC();
+        FM_SYNCL();
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -658,11 +764,14 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
     }
     range_commit(P.range, TH_RANGE_P, seen_p, rmax);
-    FM_SYNC();
+    FM_SB();
+    ring_prefetch0<3, FM_RING_D>(wslice(P.kv0, wave, 3, 0), lane, wk3);
+    FM_SYNCL();
     f32x16 vp[2][V];
     {
         f32x16 acc3[3][V];
-        gemm_phase_z<V, 3, STR256>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane, acc3);
+        gemm_phase_core<V, 3, STR256, 32 * STR256, FM_RING_D, true, 7, true>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane,
+                                                                            acc3, wk3);
         {
             const BiasT bk = load_bias(P.kv0.bias, wave * 32, lane), bv0 = load_bias(P.kv0.bias, 128 + wave * 64, lane),
                         bv1 = load_bias(P.kv0.bias, 128 + wave * 64 + 32, lane);
@@ -671,7 +780,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             finish_tile_b<V>(acc3[1], bv0, P.kv0.inv_scale, false);
             finish_tile_b<V>(acc3[2], bv1, P.kv0.inv_scale, false);
         }
-        FM_SYNC();                                                  // every wave is done reading p from ABUF
+        FM_SYNCL();                                                  // every wave is done reading p from ABUF
         float* kpb = reinterpret_cast<float*>(abuf);                // [ROWS][KSTR]
 #pragma unroll
         for (int r = 0; r < V; ++r) {
@@ -680,7 +789,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             vp[1][r] = acc3[2][r];
         }
     }
-    FM_SYNC();
+    FM_SYNCL();
 
     // ================= cross-view attention (cross_transformer.py:128-149) =================
     {
@@ -730,22 +839,24 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));  // row_half_mirror
 #endif
-                if (c8 == 0) probs[ji * 32 + p] = s / 11.313708498984761f;
+                acc[ji] = s / 11.313708498984761f;          // every lane of the 8-lane group holds the full sum
+            }
+            // softmax over j for each (sample, i), computed by every lane of the group (9 exponentials; as its own
+            // phase on 32*V threads it cost a barrier and 1.9 k cycles), written by one
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float m = -3.0e38f;
+#pragma unroll
+                for (int j = 0; j < V; ++j) m = fmaxf(m, acc[j * V + i]);
+                float e[V], se = 0.f;
+#pragma unroll
+                for (int j = 0; j < V; ++j) { e[j] = expf(acc[j * V + i] - m); se = se + e[j]; }
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    if (c8 == 0) probs[(j * V + i) * 32 + p] = e[j] / se;
             }
         }
-        FM_SYNC();
-        for (int t = tid; t < 32 * V; t += 256) {                    // softmax over j for each (sample, i)
-            int p = t & 31, i = t >> 5;
-            float m = -3.0e38f;
-#pragma unroll
-            for (int j = 0; j < V; ++j) m = fmaxf(m, probs[(j * V + i) * 32 + p]);
-            float e[V], se = 0.f;
-#pragma unroll
-            for (int j = 0; j < V; ++j) { e[j] = expf(probs[(j * V + i) * 32 + p] - m); se = se + e[j]; }
-#pragma unroll
-            for (int j = 0; j < V; ++j) probs[(j * V + i) * 32 + p] = e[j] / se;
-        }
-        FM_SYNC();
+        FM_SYNCL();
         float A[V][V];
 #pragma unroll
         for (int j = 0; j < V; ++j)
@@ -753,7 +864,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             for (int i = 0; i < V; ++i) A[j][i] = probs[(j * V + i) * 32 + myrow];
         // vs / vp hold (F V1) s_i and (F V0) p_j  (value_embed folded into fc_1, see k_mlp_fused_host.hip):
         //   fc_1 pre-activation of view i = vs_i + sum_j vp_j A[j][i] + folded bias ; relu ; -> operand of fc_2.
-        // The key buffer in ABUF was last read before the two barriers above, so each tile is stored as
+        // The key buffer in ABUF was last read before the barrier above, so each tile is stored as
         // soon as it is formed.
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -798,27 +909,39 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 store_tile_h<STR256>(n[i], i * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
         }
         range_commit(P.range, TH_RANGE_N, seen_n, rmax);
-        FM_SYNC();
     }
 
     // ================= fc_2 (fc_1 is folded into the value projections) =================
-    gemm_phase_z<V, 2, STR256>(abuf, a256_lo, wslice(P.fc_2, wave, 2, 0), P.fc_2.KB, lane, acc2);
+    FM_SB();
+    ring_prefetch0<2, FM_RING_D2>(wslice(P.fc_2, wave, 2, 0), lane, wk2);
+    FM_SYNCL();
+    gemm_phase_core<V, 2, STR256, 32 * STR256, FM_RING_D2, true, 3, true>(abuf, a256_lo, wslice(P.fc_2, wave, 2, 0), P.fc_2.KB, lane, acc2,
+                                                                         wk2);
 #ifdef FM_STAMPS
     FM_STAMP();
 #endif
     const BiasT bi[2] = {load_bias(P.fc_2.bias, wave * 64, lane), load_bias(P.fc_2.bias, wave * 64 + 32, lane)};
-    FM_SYNC();
+    FM_SYNCL();
     // inter = relu(.) -> ABUF (operand of feature_fc); its view mean -> MBUF (operand of fc_3)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         finish_tile_b<V>(acc2[c], bi[c], P.fc_2.inv_scale, true);
+        // view mean: packed adds, the 8 chains advance together (same order of operations as the scalar form)
         f32x16 m;
+        {
+            f32x2 m2[8];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            float a = acc2[c][0][e];
+            for (int q = 0; q < 8; ++q) m2[q] = (f32x2){acc2[c][0][2 * q], acc2[c][0][2 * q + 1]};
 #pragma unroll
-            for (int r = 1; r < V; ++r) a = a + acc2[c][r][e];
-            m[e] = a * inv_v;
+            for (int r = 1; r < V; ++r)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) m2[q] = m2[q] + (f32x2){acc2[c][r][2 * q], acc2[c][r][2 * q + 1]};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                m2[q] = m2[q] * (f32x2){inv_v, inv_v};
+                m[2 * q] = m2[q][0];
+                m[2 * q + 1] = m2[q][1];
+            }
         }
         store_tile_h<STR256>(m, myrow, wave * 64 + c * 32, mbuf, mbuf + 32 * STR256, lane, rmax);
 #pragma unroll
@@ -826,7 +949,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
     }
     range_commit(P.range, TH_RANGE_INTER, seen_i, rmax);
-    FM_SYNC();
+    FM_SYNCL();
 
     // ================= sigma head: relu(fc_3 m) . alpha_w + b =================
     // (the view-direction values vdv were requested at the top of the tile; they are parked in MBUF once every wave is
@@ -873,10 +996,14 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         }
         s += __shfl_xor(s, 32);
         if (lane < 32) part[(wave * 32 + lane) * 4] = s;
-        FM_SYNC();                                  // every wave is done reading the means (MBUF) and inter (ABUF)
-        if (tid < 32)
-            sig[tid] = part[tid * 4] + part[(32 + tid) * 4] + part[(64 + tid) * 4] + part[(96 + tid) * 4] + P.alpha_b[0];
         if (tid == 0) *flag = 0;
+        FM_SYNCL();                                  // every wave is done reading the means (MBUF) and inter (ABUF)
+        // rgb_all: 0 progressive (sigma > 0 only, :296-305), 1 every sample (MLP_forward_ori), 2 none (sigma grid)
+        if (tid < 32) {
+            const float sg = part[tid * 4] + part[(32 + tid) * 4] + part[(64 + tid) * 4] + part[(96 + tid) * 4] + P.alpha_b[0];
+            sig[tid] = sg;
+            if (tid < npts && P.rgb_all != 2 && (P.rgb_all == 1 || sg > 0.f)) *flag = 1;
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             int i = tid + 256 * q, row = i >> 5, c = i & 31;
@@ -885,10 +1012,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             *reinterpret_cast<_Float16*>(vd_hi + row * STRVD + 2 * c) = a;
             *reinterpret_cast<_Float16*>(vd_lo + row * STRVD + 2 * c) = b;
         }
-        FM_SYNC();
-        // rgb_all: 0 progressive (sigma > 0 only, :296-305), 1 every sample (MLP_forward_ori), 2 none (sigma grid)
-        if (tid < npts && P.rgb_all != 2 && (P.rgb_all == 1 || sig[tid] > 0.f)) *flag = 1;
-        FM_SYNC();
+        FM_SYNCL();
     }
     const bool need_rgb = *flag != 0;
     float rgb_out[3] = {0.f, 0.f, 0.f};
@@ -898,19 +1022,26 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         //   t = relu((Wa F) inter + Wd viewdir + (Wa R0) f + b') ; u = t + rgb_res_1(f) ; mean over views ; fc_4 ; rgb_fc
         // ABUF has been free since the barrier behind the fc_3 / view_fc loop: f is requested first, the two
         // view-direction k-blocks (operand in MBUF) multiply while it arrives.
+        // (vmcnt returns in order: the view-direction weights are requested BEFORE the staging loads, or their GEMM
+        // would wait for the whole filling)
+        uint4 wvd[FM_RING_D2][1][2];
+        ring_prefetch<1, FM_RING_D2>(wslice(P.vfD, wave, 1, 0), 2, lane, wvd);
+        FM_SB();
         stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
-        gemm_phase<V, 1, STRVD, 0>(vd_hi, vd_lo, wslice(P.vfD, wave, 1, 0), 2, lane, vf);
+        ring_prefetch0<2, FM_RING_D2>(wslice(P.rst, wave, 2, 0), lane, wk2);
+        FM_SB();
+        gemm_phase_core<V, 1, STRVD, 0, FM_RING_D2, true, 0, true, false>(vd_hi, vd_lo, wslice(P.vfD, wave, 1, 0), 2, lane, vf, wvd);   // KB < D
 #pragma unroll
         for (int r = 0; r < V; ++r)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc2[1][r][e] = 0.f;
         FM_SYNC();
-        gemm_phase<V, 2, FL::SA>(abuf, fa_lo, wslice(P.rst, wave, 2, 0), FL::NA, lane, acc2);
+        gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 0, true>(abuf, fa_lo, wslice(P.rst, wave, 2, 0), FL::NA, lane, acc2, wk2);
 #ifdef FM_STAMPS
         FM_STAMP();
 #endif
         if constexpr (FL::NB > 0) {
-            FM_SYNC();
+            FM_SYNCL();
             stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
             FM_SYNC();
             gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.rst, wave, 2, FL::NA), FL::NB, lane, acc2);
@@ -939,17 +1070,28 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         char* f4_lo = f4_hi + 32 * STR128;
         {
             f32x16 m;
+            {
+                f32x2 u2[V][8];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float a = acc2[0][0][e] + acc2[1][0][e];
+                for (int r = 0; r < V; ++r)
 #pragma unroll
-                for (int r = 1; r < V; ++r) a = a + (acc2[0][r][e] + acc2[1][r][e]);
-                m[e] = a * inv_v;
+                    for (int q = 0; q < 8; ++q)
+                        u2[r][q] = (f32x2){acc2[0][r][2 * q], acc2[0][r][2 * q + 1]} + (f32x2){acc2[1][r][2 * q], acc2[1][r][2 * q + 1]};
+#pragma unroll
+                for (int r = 1; r < V; ++r)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) u2[0][q] = u2[0][q] + u2[r][q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    u2[0][q] = u2[0][q] * (f32x2){inv_v, inv_v};
+                    m[2 * q] = u2[0][q][0];
+                    m[2 * q + 1] = u2[0][q][1];
+                }
             }
             store_tile_h<STR128, false>(m, myrow, wave * 32, f4_hi, f4_lo, lane, rmax);      // (signed: relu(.) + rgb_res_1)
             range_commit(P.range, TH_RANGE_F4, seen_4, rmax);
         }
-        FM_SYNC();
+        FM_SYNCL();
         f32x16 a4[1][1];
         zero_acc<1, 1>(a4);
         {
@@ -979,7 +1121,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             part[(wave * 32 + lane) * 4 + 1] = s3[1];
             part[(wave * 32 + lane) * 4 + 2] = s3[2];
         }
-        FM_SYNC();
+        FM_SYNCL();
         if (tid < 32) {
 #pragma unroll
             for (int o = 0; o < 3; ++o)
