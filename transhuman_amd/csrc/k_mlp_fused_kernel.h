@@ -619,18 +619,17 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     // (an odd number of 16-byte slots) and read back in the accumulator layout with conflict-free ds_read_b128.
     // (Fetching that layout straight from global memory took 96 loads per lane of 32 B segments from 32 different
     // rows each: the texture path, not the memory latency, bounded the phase at 9 k cycles.)
-    // The view-direction rows of the tile (used by the RGB branch, 27 of 32 columns) are requested here too: two
-    // dependent HBM round trips that used to sit in front of the fc_3 weight stream.
-    float vdv[4];
+    // The view-direction rows of the tile (used by the RGB branch, 27 of 32 columns) sit behind an index (the valid-sample
+    // list): the indices are requested here, in FRONT of the token rows (vmcnt returns in order: behind them they would
+    // arrive last), and the rows themselves in front of the pixel-feature staging -- both HBM round trips then run under
+    // waits that exist anyway (the dependent pair used to sit in front of the first LDS-DMA load: 2 k cycles per tile).
+    int vsel[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        int i = tid + 256 * q, row = i >> 5, c = i & 31;
-        float x = 0.f;
-        if (P.rgb_all != 2 && c < 27 && row < npts) {
-            const long long vr = P.vd_sel ? (long long)(P.vd_sel[pbase + row] / P.vd_div) : (long long)(pbase + row);
-            x = P.vd[vr * 27 + c];
-        }
-        vdv[q] = x;
+        const int i = tid + 256 * q, row = i >> 5, c = i & 31;
+        int x = pbase + row;
+        if (P.vd_sel != nullptr && P.rgb_all != 2 && c < 27 && row < npts) x = P.vd_sel[pbase + row];
+        vsel[q] = x;
     }
     f32x16 acc2[2][V];
     {
@@ -643,12 +642,8 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         const int psrc = min(prow, npts - 1);
         const uint4 pe_h = *reinterpret_cast<const uint4*>(P.pe + (long long)(pbase + psrc) * 128 + 8 * pc);
         const uint4 pe_l = *reinterpret_cast<const uint4*>(P.pe + (long long)(pbase + psrc) * 128 + 64 + 8 * pc);
-        uint4 wq[4][2][2];
-        const uint4* wl = wslice(P.fc_0pe, wave, 2, 0) + lane;
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) load_wfrag<2>(wl, kb, wq[kb]);
-        const BiasT b0[2] = {load_bias(P.fc_0pe.bias, wave * 64, lane), load_bias(P.fc_0pe.bias, wave * 64 + 32, lane)};
-        {
+        FM_SB();
+        {   // the HBM filling first: the (L2-resident) fc_0 weights and bias queue behind it, not in front of it
             const int wv = __builtin_amdgcn_readfirstlane(wave);
             const char* sg = reinterpret_cast<const char*>(P.stok) + lane * 16;
 #pragma unroll 4
@@ -658,6 +653,12 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)(abuf + i * STOK_STR), 16, 0, 0);
             }
         }
+        FM_SB();
+        uint4 wq[4][2][2];
+        const uint4* wl = wslice(P.fc_0pe, wave, 2, 0) + lane;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) load_wfrag<2>(wl, kb, wq[kb]);
+        const BiasT b0[2] = {load_bias(P.fc_0pe.bias, wave * 64, lane), load_bias(P.fc_0pe.bias, wave * 64 + 32, lane)};
         FM_SB();
         *reinterpret_cast<uint4*>(pe_hi + prow * STR64 + 16 * pc) = pe_h;
         *reinterpret_cast<uint4*>(pe_lo + prow * STR64 + 16 * pc) = pe_l;
@@ -737,6 +738,18 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     FM_SYNCL();
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
+    float vdv[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = tid + 256 * q, row = i >> 5, c = i & 31;
+        float x = 0.f;
+        if (P.rgb_all != 2 && c < 27 && row < npts) {
+            const long long vr = P.vd_sel ? (long long)(vsel[q] / P.vd_div) : (long long)(pbase + row);
+            x = P.vd[vr * 27 + c];
+        }
+        vdv[q] = x;
+    }
+    FM_SB();
     stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
 #ifdef FM_STAMPS
     FM_STAMP();
