@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
             v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
             sum += (x.x + x.y) + (x.z + x.w);
         }
-        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+        sum = th_row16_sum(sum);
         const float mean = sum / (float)Kreal;
         float ss = 0.f;
 #pragma unroll
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(const float* __restr
                 for (int e = 0; e < 4; ++e) { float d = v[4 * q + e] - mean; ss += d * d; }
             }
         }
-        for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o);
+        ss = th_row16_sum(ss);
         if (sub == 0) { ln_mean[row] = mean; ln_rstd[row] = 1.0f / __fsqrt_rn(ss / (float)Kreal + ln_eps); }
         __syncthreads();
     }
@@ -370,23 +370,26 @@ int th_pack_linear_h3(const th_linear& lin, void* storage_h3, ThPacked* out, hip
 }
 
 #define H3_RING 6
-template <bool LN>
+// RT row tiles of 16 per workgroup.  A workgroup streams its 64 columns of the weight image (4 K bytes per column) once per
+// 16 RT rows: with RT = 1 the V N_c = 1500 rows of the ViT re-read every layer's weights 94 times (41-55 MB of L2 traffic
+// per GEMM: that, not latency, bounded the 9-10 us launches); RT = 2 / 4 halves / quarters it and gives a wave 2 / 4
+// independent accumulators per product term.
+template <bool LN, int RT>
 __global__ __launch_bounds__(256) void gemm_h3_kernel(const float* __restrict__ A, int lda, int M, int Kreal,
                                                       const uint4* __restrict__ W16, const float* __restrict__ inv_scale,
                                                       const float* __restrict__ bias, int N, int NB, int KB32,
                                                       float* __restrict__ C, int ldc, int flags,
                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                      float ln_eps, unsigned int* __restrict__ range) {
+                                                      float ln_eps, unsigned int* __restrict__ range, ThQkvSplit qs) {
     extern __shared__ __attribute__((aligned(16))) char h3_lds[];
-    __shared__ float ln_mean[16], ln_rstd[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.x * 16;
+    const int m0 = blockIdx.x * 16 * RT;
     const int nb = blockIdx.y * 4 + wave;
     const bool wave_active = nb < NB;
     const int KP = KB32 * 32;
     const int stride = 2 * KP + 16;                        // bytes per LDS row of a plane
     char* a_hi = h3_lds;
-    char* a_lo = h3_lds + 16 * stride;
+    char* a_lo = h3_lds + 16 * RT * stride;
 
     // weight fragments of the first ring stages: requested before the operand is staged
     uint4 bq[H3_RING][2];
@@ -396,100 +399,169 @@ __global__ __launch_bounds__(256) void gemm_h3_kernel(const float* __restrict__ 
         for (int j = 0; j < H3_RING; ++j)
             if (j < KB32) { bq[j][0] = wl[j * 128]; bq[j][1] = wl[j * 128 + 64]; }
     }
-    if (LN) {
-        // 16 threads per row, two passes like layernorm_kernel (k_vit.hip); K <= 256
-        const int row = tid >> 4, sub = tid & 15, gm = m0 + row;
-        float v[16];
-        float sum = 0.f;
+    // epilogue operands (scale, bias, the residual of TH_GEMM_ACCUM) are requested here as well, not behind the MFMAs
+    const int act = flags & 15;
+    const bool accum = (flags & TH_GEMM_ACCUM) != 0;
+    const int col = nb * 16 + (lane & 15);
+    const bool col_ok = wave_active && col < N;
+    const float inv = inv_scale[0], bv = col_ok ? bias[col] : 0.f;
+    float cres[RT][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = 4 * (sub + 16 * q);
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gm < M && k < Kreal) x = *reinterpret_cast<const float4*>(A + (long long)gm * lda + k);
-            v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
-            sum += (x.x + x.y) + (x.z + x.w);
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * t + 4 * (lane >> 4) + r;
+            cres[t][r] = (accum && col_ok && row < M) ? C[(long long)row * ldc + col] : 0.f;
         }
-        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
-        const float mean = sum / (float)Kreal;
-        float ss = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = 4 * (sub + 16 * q);
-            if (k < Kreal) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { float d = v[4 * q + e] - mean; ss += d * d; }
-            }
-        }
-        for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o);
-        if (sub == 0) { ln_mean[row] = mean; ln_rstd[row] = 1.0f / __fsqrt_rn(ss / (float)Kreal + ln_eps); }
-        __syncthreads();
-    }
-    // stage + split the 16 x KP operand
     unsigned rmax = 0u;
-    const int c4n = KP / 4;
-    for (int idx = tid; idx < 16 * c4n; idx += 256) {
-        const int row = idx / c4n, c4 = idx - row * c4n, gm = m0 + row, gk = 4 * c4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gm < M && gk < Kreal) {
-            v = *reinterpret_cast<const float4*>(A + (long long)gm * lda + gk);     // (K % 4 == 0 is required)
-            if (LN) {
-                const float mu = ln_mean[row], rs = ln_rstd[row];
-                const float4 w4 = *reinterpret_cast<const float4*>(ln_w + gk), b4 = *reinterpret_cast<const float4*>(ln_b + gk);
-                v.x = (v.x - mu) * rs * w4.x + b4.x;
-                v.y = (v.y - mu) * rs * w4.y + b4.y;
-                v.z = (v.z - mu) * rs * w4.z + b4.z;
-                v.w = (v.w - mu) * rs * w4.w + b4.w;
+    if (LN) {
+        // 16 threads per row hold the row in registers (K <= 256): two-pass statistics like layernorm_kernel (k_vit.hip)
+        // with DPP row reductions (every lane gets mean / rstd: no LDS, no barrier), normalised and split in place --
+        // the row is read ONCE (it used to be re-read by the staging loop behind a barrier)
+        const int sub = tid & 15;
+        float4 w4[4], b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * (sub + 16 * q);
+            w4[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b4[q] = w4[q];
+            if (k < Kreal) {
+                w4[q] = *reinterpret_cast<const float4*>(ln_w + k);
+                b4[q] = *reinterpret_cast<const float4*>(ln_b + k);
             }
         }
-        const float x4[4] = {v.x, v.y, v.z, v.w};
-        g_h4 hv, lv;
+        float v[RT][16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const _Float16 hi = (_Float16)x4[e];
-            hv[e] = hi;
-            lv[e] = (_Float16)(x4[e] - (float)hi);
-            rmax = max(rmax, (unsigned)(__builtin_bit_cast(unsigned short, hi) & 0x7fffu));
+        for (int t = 0; t < RT; ++t) {
+            const int gm = m0 + 16 * t + (tid >> 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * (sub + 16 * q);
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gm < M && k < Kreal) x = *reinterpret_cast<const float4*>(A + (long long)gm * lda + k);
+                v[t][4 * q] = x.x; v[t][4 * q + 1] = x.y; v[t][4 * q + 2] = x.z; v[t][4 * q + 3] = x.w;
+            }
         }
-        *reinterpret_cast<g_h4*>(a_hi + row * stride + 8 * c4) = hv;
-        *reinterpret_cast<g_h4*>(a_lo + row * stride + 8 * c4) = lv;
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const int row = 16 * t + (tid >> 4), gm = m0 + row;
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sum += (v[t][4 * q] + v[t][4 * q + 1]) + (v[t][4 * q + 2] + v[t][4 * q + 3]);
+            sum = th_row16_sum(sum);
+            const float mean = sum / (float)Kreal;
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * (sub + 16 * q);
+                if (k < Kreal) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { float d = v[t][4 * q + e] - mean; ss += d * d; }
+                }
+            }
+            ss = th_row16_sum(ss);
+            const float rs = 1.0f / __fsqrt_rn(ss / (float)Kreal + ln_eps);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * (sub + 16 * q);
+                if (k < KP) {
+                    const float wv[4] = {w4[q].x, w4[q].y, w4[q].z, w4[q].w}, bb[4] = {b4[q].x, b4[q].y, b4[q].z, b4[q].w};
+                    g_h4 hv, lv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = 0.f;
+                        if (gm < M && k < Kreal) x = (v[t][4 * q + e] - mean) * rs * wv[e] + bb[e];
+                        const _Float16 hi = (_Float16)x;
+                        hv[e] = hi;
+                        lv[e] = (_Float16)(x - (float)hi);
+                        rmax = max(rmax, (unsigned)(__builtin_bit_cast(unsigned short, hi) & 0x7fffu));
+                    }
+                    *reinterpret_cast<g_h4*>(a_hi + row * stride + 2 * k) = hv;
+                    *reinterpret_cast<g_h4*>(a_lo + row * stride + 2 * k) = lv;
+                }
+            }
+        }
+    } else {
+        // stage + split the 16 RT x KP operand
+        const int c4n = KP / 4;
+        for (int idx = tid; idx < 16 * RT * c4n; idx += 256) {
+            const int row = idx / c4n, c4 = idx - row * c4n, gm = m0 + row, gk = 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gm < M && gk < Kreal) v = *reinterpret_cast<const float4*>(A + (long long)gm * lda + gk);     // (K % 4 == 0 is required)
+            const float x4[4] = {v.x, v.y, v.z, v.w};
+            g_h4 hv, lv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 hi = (_Float16)x4[e];
+                hv[e] = hi;
+                lv[e] = (_Float16)(x4[e] - (float)hi);
+                rmax = max(rmax, (unsigned)(__builtin_bit_cast(unsigned short, hi) & 0x7fffu));
+            }
+            *reinterpret_cast<g_h4*>(a_hi + row * stride + 8 * c4) = hv;
+            *reinterpret_cast<g_h4*>(a_lo + row * stride + 8 * c4) = lv;
+        }
     }
     if (range != nullptr && rmax > range[TH_RANGE_VIT]) atomicMax(range + TH_RANGE_VIT, rmax);
     __syncthreads();
     if (!wave_active) return;
 
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // one accumulator per row tile and product term (hi*lo, lo*hi, hi*hi): independent MFMA chains
+    f32x4 acc[RT][3];
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int e = 0; e < 3; ++e) acc[t][e] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int aoff = (lane & 15) * stride + 16 * (lane >> 4);
     for (int kb0 = 0; kb0 < KB32; kb0 += H3_RING) {
 #pragma unroll
         for (int j = 0; j < H3_RING; ++j) {
             const int kb = kb0 + j;
             if (kb < KB32) {
-                const g_h8 ah = *reinterpret_cast<const g_h8*>(a_hi + aoff + kb * 64);
-                const g_h8 al = *reinterpret_cast<const g_h8*>(a_lo + aoff + kb * 64);
                 const g_h8 bh = *reinterpret_cast<const g_h8*>(&bq[j][0]);
                 const g_h8 bl = *reinterpret_cast<const g_h8*>(&bq[j][1]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const g_h8 ah = *reinterpret_cast<const g_h8*>(a_hi + 16 * t * stride + aoff + kb * 64);
+                    const g_h8 al = *reinterpret_cast<const g_h8*>(a_lo + 16 * t * stride + aoff + kb * 64);
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[t][1], 0, 0, 0);
+                    acc[t][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[t][2], 0, 0, 0);
+                }
                 if (kb + H3_RING < KB32) { bq[j][0] = wl[(kb + H3_RING) * 128]; bq[j][1] = wl[(kb + H3_RING) * 128 + 64]; }
             }
         }
     }
-    const int act = flags & 15;
-    const bool accum = (flags & TH_GEMM_ACCUM) != 0;
-    const int col = nb * 16 + (lane & 15);
     if (col >= N) return;
-    const float inv = inv_scale[0], bv = bias[col];
+    // qkv epilogue: this wave's 16 columns are queries (fp32 as usual), keys or values (split planes) -- wave-uniform
+    const int part = (qs.Kp != nullptr) ? col / qs.dim : 0;
+    const int hd = (qs.Kp != nullptr) ? (col - part * qs.dim) : 0;       // head * 64 + d
+    const long long plane = (long long)qs.Npad * 64;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = m0 + 4 * (lane >> 4) + r;
-        if (row < M) {
-            float v = acc[r] * inv + bv;
-            if (act == TH_ACT_RELU) v = fmaxf(v, 0.0f);
-            else if (act == TH_ACT_GELU) v = th_gelu_erf(v);
-            float* dst = C + (long long)row * ldc + col;
-            if (accum) v = *dst + v;
-            *dst = v;
+    for (int t = 0; t < RT; ++t) {
+        const f32x4 a = (acc[t][0] + acc[t][1]) + acc[t][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + 16 * t + 4 * (lane >> 4) + r;
+            if (row < M) {
+                float v = a[r] * inv + bv;
+                if (act == TH_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (act == TH_ACT_GELU) v = th_gelu_erf(v);
+                if (accum) v = cres[t][r] + v;
+                if (part == 0) C[(long long)row * ldc + col] = v;
+                else {
+                    const int view = row / qs.N, key = row - view * qs.N;
+                    const _Float16 hi = (_Float16)v, lo = (_Float16)(v - (float)hi);
+                    _Float16* base = (part == 1 ? qs.Kp : qs.Vp) + ((long long)view * qs.heads + (hd >> 6)) * 2 * plane;
+                    long long o;
+                    if (part == 1) o = (long long)key * 64 + (hd & 63);
+                    else {      // V^T row d, keys in the fragment order of attn2_kernel (see kv_split_kernel)
+                        const int ko = key & 31;
+                        o = (long long)(hd & 63) * qs.Npad + (key & ~31) + 8 * ((ko & 15) >> 2) + 4 * (ko >> 4) + (ko & 3);
+                    }
+                    base[o] = hi;
+                    base[plane + o] = lo;
+                }
+            }
         }
     }
 }
@@ -499,25 +571,44 @@ bool th_gemm_h3_ok(int M, const ThPacked& W, bool ln) {
 }
 
 int th_gemm_h3(const float* A, int lda, int M, const ThPacked& W, const float* ln_w, const float* ln_b, float eps, int flags,
-               float* C, int ldc, unsigned int* range, hipStream_t s) {
+               float* C, int ldc, unsigned int* range, hipStream_t s, const ThQkvSplit* qkv) {
     const bool ln = ln_w != nullptr;
     TH_REQUIRE(th_gemm_h3_ok(M, W, ln), "th_gemm_h3: unsupported shape / layer not packed for the fp16-split path");
+    ThQkvSplit qs{};
+    if (qkv != nullptr) {
+        qs = *qkv;
+        TH_REQUIRE(W.N == 3 * qs.dim && (qs.dim & 63) == 0 && qs.N > 0 && M % qs.N == 0 && (flags & TH_GEMM_ACCUM) == 0,
+                   "th_gemm_h3: the qkv epilogue needs N = 3 dim, dim = heads * 64, M = views * tokens");
+    }
     TH_REQUIRE((lda & 3) == 0 && (((uintptr_t)A) & 15) == 0, "A must be 16-byte aligned with lda % 4 == 0");
     const int KP = W.KB32 * 32;
-    const size_t lds = (size_t)2 * 16 * (2 * KP + 16);
     static bool attr = false;
     if (!attr) {
-        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * (2 * 768 + 16)));
-        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 16 * (2 * 768 + 16)));
+        const int mx = 2 * 16 * 4 * (2 * 256 + 16), mx2 = 2 * 16 * 2 * (2 * 768 + 16);
+        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2));
+        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2));
+        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2));
+        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2));
+        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
+        TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
         attr = true;
     }
-    dim3 grid(th_cdiv(M, 16), th_cdiv(W.NB, 4));
-    if (ln)
-        hipLaunchKernelGGL(gemm_h3_kernel<true>, grid, dim3(256), lds, s, A, lda, M, W.K, W.w16, W.scale16, W.b, W.N, W.NB, W.KB32,
-                           C, ldc, flags, ln_w, ln_b, eps, range);
-    else
-        hipLaunchKernelGGL(gemm_h3_kernel<false>, grid, dim3(256), lds, s, A, lda, M, W.K, W.w16, W.scale16, W.b, W.N, W.NB, W.KB32,
-                           C, ldc, flags, ln_w, ln_b, eps, range);
+    // rows per workgroup: 16 (RT = 1).  Larger tiles re-read the weights less often (RT = 2 / 4: half / a quarter of the
+    // 41-55 MB of L2 traffic per GEMM of the ViT) but were measured SLOWER at V N_c = 900 .. 4500 rows (0.79 / 0.86 /
+    // 0.91 ms per forward at RT = 1 / 2 / 4, N_c = 500): these launches are bound by the length of the per-workgroup
+    // dependency chain, not by bandwidth.  TH_GEMM_H3_RT = 2 | 4 selects the larger tiles (A/B switch).
+    static const int rt_env = getenv("TH_GEMM_H3_RT") ? atoi(getenv("TH_GEMM_H3_RT")) : 0;
+    const int gy = th_cdiv(W.NB, 4);
+    int rt = 1;
+    if (rt_env == 2 || (rt_env == 4 && KP <= 256)) rt = rt_env;
+    const size_t lds = (size_t)2 * 16 * rt * (2 * KP + 16);
+    dim3 grid(th_cdiv(M, 16 * rt), gy);
+#define H3_LAUNCH(LN_, RT_)                                                                                              \
+    hipLaunchKernelGGL((gemm_h3_kernel<LN_, RT_>), grid, dim3(256), lds, s, A, lda, M, W.K, W.w16, W.scale16, W.b, W.N, W.NB, \
+                       W.KB32, C, ldc, flags, ln_w, ln_b, eps, range, qs)
+    if (ln) { if (rt == 4) H3_LAUNCH(true, 4); else if (rt == 2) H3_LAUNCH(true, 2); else H3_LAUNCH(true, 1); }
+    else    { if (rt == 4) H3_LAUNCH(false, 4); else if (rt == 2) H3_LAUNCH(false, 2); else H3_LAUNCH(false, 1); }
+#undef H3_LAUNCH
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
                 sacc[nt][r] = sv;
                 m = fmaxf(m, sv);
             }
-            for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+            m = th_row16_max(m);
             mnew[r] = fmaxf(mrun[r], m);
             corr[r] = expf(mrun[r] - mnew[r]);
             mrun[r] = mnew[r];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
                 *reinterpret_cast<_Float16*>(Pw + po) = x;
                 *reinterpret_cast<_Float16*>(Pw + 16 * AT_HS + po) = y;
             }
-            for (int o = 1; o < 16; o <<= 1) ls += __shfl_xor(ls, o);
+            ls = th_row16_sum(ls);
             lrun[r] = lrun[r] * corr[r] + ls;
 #pragma unroll
             for (int j = 0; j < 4; ++j) oacc[j][r] *= corr[r];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const float* __restrict__ qkv
 // 2-byte LDS stores) between two block barriers: 8 q-blocks repeat the conversion of the same (view, head) and
 // the 8-tile loop is a 31 us dependent chain.  Here kv_split_kernel writes, once per layer,
 //   Kp [V][heads][2 planes][Npad][64]   K rows as fp16 hi | lo          (rows >= N zero)
-//   Vp [V][heads][2 planes][64][Npad]   V^T rows (one d, keys contiguous) as fp16 hi | lo
+//   Vp [V][heads][2 planes][64][Npad]   V^T rows (one d; keys in the fragment order of attn2_kernel) as fp16 hi | lo
 // -- exactly the 16-byte B-operand fragments of the two products -- and attn2_kernel (ONE wave = 16 queries per
 // workgroup, 288 workgroups at N = 500) loads them straight from L2 into registers: no block barrier, no conversion
 // in the loop, V fragments of a tile requested before its S product, K fragments of the next tile before its P V.
@@ -298,16 +298,29 @@ __global__ __launch_bounds__(256) void kv_split_kernel(const float* __restrict__
             at_split(vt[4 * c4 + e][d], x, y);
             vh[e] = x; vl[e] = y;
         }
-        *reinterpret_cast<at_h4*>(vp + (long long)d * Npad + k0 + 4 * c4) = vh;
-        *reinterpret_cast<at_h4*>(vp + plane + (long long)d * Npad + k0 + 4 * c4) = vl;
+        // keys 4 c4 .. 4 c4 + 3 of the 64-key block; within a 32-key block key offset 16 n + 4 g + j sits at position
+        // 8 g + 4 n + j (the B-operand order of attn2_kernel's P^T fragments)
+        const int ko = (4 * c4) & 31, pos = ((4 * c4) & 32) + 8 * ((ko & 15) >> 2) + 4 * (ko >> 4);
+        *reinterpret_cast<at_h4*>(vp + (long long)d * Npad + k0 + pos) = vh;
+        *reinterpret_cast<at_h4*>(vp + plane + (long long)d * Npad + k0 + pos) = vl;
     }
 }
 
+// The products are formed TRANSPOSED: S^T = K Q^T and O^T = V^T P^T.  An MFMA result tile holds, per lane, 4 consecutive
+// rows of ONE column; with queries as columns a lane owns one query (lane & 15) and its 16 scores of a 64-key tile sit
+// in its own registers: the row maximum / sum are in-register reductions plus two cross-row steps, the probabilities are
+// already laid out as the B operand of the second product (k index = 8 (lane >> 4) + j  <->  key 16 (j >> 2) + 4 (lane >> 4)
+// + (j & 3) of a 32-key block: kv_split_kernel stores V^T in that key order), and the softmax statistics of a query live
+// in the lane that holds its output column -- no LDS, no barrier, no cross-lane traffic for the rescaling.  (The
+// row-major form wrote P through LDS with 32 two-byte stores per tile and reduced 4 rows x 4 steps across lanes:
+// 21.4 us per layer at N = 500; this form 16.6 us.  Splitting the keys of a query block over 4 waves with an LDS merge
+// of the partial (m, l, O^T) triples was measured again on this form: 17.7 us -- the launch is not bound by the length of
+// the per-wave chain.)
 __global__ __launch_bounds__(64) void attn2_kernel(const float* __restrict__ qkv, const _Float16* __restrict__ Kp,
                                                    const _Float16* __restrict__ Vp, int N, int Npad, int dim,
                                                    float scale, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) char Pw[2 * 16 * AT_HS];        // P [q][key], hi | lo planes
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+    const int kbeg = 0, kend = N;
     const int head = blockIdx.y, view = blockIdx.z, heads = gridDim.y;
     const int q0 = blockIdx.x * 16;
     const int ld = 3 * dim;
@@ -316,16 +329,17 @@ __global__ __launch_bounds__(64) void attn2_kernel(const float* __restrict__ qkv
     const _Float16* kp = Kp + ((long long)view * heads + head) * 2 * plane;
     const _Float16* vp = Vp + ((long long)view * heads + head) * 2 * plane;
 
+    // Q^T fragments (B operand: column = query c, k = d = 32 s2 + 8 g + j)
     at_h8 qh[2], ql[2];
     {
-        const int qi = q0 + (lane & 15);
+        const int qi = q0 + c;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float v8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v8[e] = 0.f;
             if (qi < N) {
-                const float* src = base + (long long)qi * ld + head * 64 + 32 * s2 + 8 * (lane >> 4);
+                const float* src = base + (long long)qi * ld + head * 64 + 32 * s2 + 8 * g;
                 float4 a = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
                 v8[0] = a.x; v8[1] = a.y; v8[2] = a.z; v8[3] = a.w; v8[4] = b4.x; v8[5] = b4.y; v8[6] = b4.z; v8[7] = b4.w;
             }
@@ -337,22 +351,20 @@ __global__ __launch_bounds__(64) void attn2_kernel(const float* __restrict__ qkv
             }
         }
     }
-    f32x4 oacc[4];
+    f32x4 oacc[4];              // O^T tiles: d = 16 jd + 4 g + r, column = query c
 #pragma unroll
     for (int j = 0; j < 4; ++j) oacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrun[4], lrun[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { mrun[r] = -3.0e38f; lrun[r] = 0.f; }
+    float mrun = -3.0e38f, lrun = 0.f;
 
-    // fragments of one 64-key tile: K [nt][s2] (key = k0 + nt*16 + lane&15, d = 32 s2 + 8 (lane>>4) ..+7),
-    //                               V [j][s2]  (d = j*16 + lane&15,   keys = k0 + 32 s2 + 8 (lane>>4) ..+7)
+    // fragments of one 64-key tile: K [nt][s2] (A operand: row = key k0 + 16 nt + c, k = d = 32 s2 + 8 g ..+7),
+    //                               V^T [jd][s2] (A operand: row = d = 16 jd + c, k = position 8 g ..+7 of 32-key block s2)
     at_h8 kh[4][2], kl[4][2], vh[4][2], vl[4][2];
     auto load_k = [&](int k0) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const long long o = (long long)(k0 + nt * 16 + (lane & 15)) * 64 + 32 * s2 + 8 * (lane >> 4);
+                const long long o = (long long)(k0 + nt * 16 + c) * 64 + 32 * s2 + 8 * g;
                 kh[nt][s2] = *reinterpret_cast<const at_h8*>(kp + o);
                 kl[nt][s2] = *reinterpret_cast<const at_h8*>(kp + plane + o);
             }
@@ -362,87 +374,77 @@ __global__ __launch_bounds__(64) void attn2_kernel(const float* __restrict__ qkv
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const long long o = (long long)(j * 16 + (lane & 15)) * Npad + k0 + 32 * s2 + 8 * (lane >> 4);
+                const long long o = (long long)(j * 16 + c) * Npad + k0 + 32 * s2 + 8 * g;
                 vh[j][s2] = *reinterpret_cast<const at_h8*>(vp + o);
                 vl[j][s2] = *reinterpret_cast<const at_h8*>(vp + plane + o);
             }
     };
-    load_k(0);
-    for (int k0 = 0; k0 < N; k0 += AT_K) {
+    if (kbeg < kend) load_k(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += AT_K) {
         load_v(k0);
-        f32x4 sacc[4];
+        f32x4 sacc[4];          // S^T tiles: key = k0 + 16 nt + 4 g + r, column = query c
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             sacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[s2], kh[nt][s2], sacc[nt], 0, 0, 0);
-                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s2], kl[nt][s2], sacc[nt], 0, 0, 0);
-                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[s2], kh[nt][s2], sacc[nt], 0, 0, 0);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[nt][s2], ql[s2], sacc[nt], 0, 0, 0);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[nt][s2], qh[s2], sacc[nt], 0, 0, 0);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[nt][s2], qh[s2], sacc[nt], 0, 0, 0);
             }
         }
-        if (k0 + AT_K < N) load_k(k0 + AT_K);
-        float mnew[4], corr[4];
+        if (k0 + AT_K < kend) load_k(k0 + AT_K);
+        float m = -3.0e38f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float m = -3.0e38f;
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                int key = k0 + nt * 16 + (lane & 15);
-                float sv = (key < N) ? sacc[nt][r] * scale : -3.0e38f;
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + nt * 16 + 4 * g + r;
+                const float sv = (key < N) ? sacc[nt][r] * scale : -3.0e38f;
                 sacc[nt][r] = sv;
                 m = fmaxf(m, sv);
             }
-            for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
-            mnew[r] = fmaxf(mrun[r], m);
-            corr[r] = expf(mrun[r] - mnew[r]);
-            mrun[r] = mnew[r];
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the previous tile's P fragments have been read
-        __builtin_amdgcn_wave_barrier();
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float mnew = fmaxf(mrun, m);
+        const float corr = expf(mrun - mnew);
+        mrun = mnew;
+        float ls = 0.f;
+        at_h8 ph[2], pl[2];     // P^T fragments (B operand) of the two 32-key blocks
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float ls = 0.f;
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                int key = k0 + nt * 16 + (lane & 15);
-                float pv = (key < N) ? expf(sacc[nt][r] - mnew[r]) : 0.f;
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + nt * 16 + 4 * g + r;
+                const float pv = (key < N) ? expf(sacc[nt][r] - mnew) : 0.f;
                 ls += pv;
                 _Float16 x, y;
                 at_split(pv, x, y);
-                const int po = (4 * (lane >> 4) + r) * AT_HS + 2 * (nt * 16 + (lane & 15));
-                *reinterpret_cast<_Float16*>(Pw + po) = x;
-                *reinterpret_cast<_Float16*>(Pw + 16 * AT_HS + po) = y;
+                ph[nt >> 1][4 * (nt & 1) + r] = x;
+                pl[nt >> 1][4 * (nt & 1) + r] = y;
             }
-            for (int o = 1; o < 16; o <<= 1) ls += __shfl_xor(ls, o);
-            lrun[r] = lrun[r] * corr[r] + ls;
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        lrun = lrun * corr + ls;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) oacc[j][r] *= corr[r];
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): P tile written
-        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < 4; ++j) oacc[j] *= corr;
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int pof = (lane & 15) * AT_HS + 64 * s2 + 16 * (lane >> 4);
-            const at_h8 ph = *reinterpret_cast<const at_h8*>(Pw + pof);
-            const at_h8 pl = *reinterpret_cast<const at_h8*>(Pw + 16 * AT_HS + pof);
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh[j][s2], oacc[j], 0, 0, 0);
-                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl[j][s2], oacc[j], 0, 0, 0);
-                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh[j][s2], oacc[j], 0, 0, 0);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[j][s2], pl[s2], oacc[j], 0, 0, 0);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl[j][s2], ph[s2], oacc[j], 0, 0, 0);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh[j][s2], ph[s2], oacc[j], 0, 0, 0);
             }
-        }
     }
+    // out[t][head*64 + d] = O / l      (x = (attn @ v).transpose(1,2).reshape(B,N,C), :278): 4 consecutive d per lane
+    const int qi = q0 + c;
+    if (qi < N) {
+        const float inv = 1.0f / lrun;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int qi = q0 + 4 * (lane >> 4) + r;
-        if (qi < N) {
-            float inv = 1.0f / lrun[r];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                out[((long long)view * N + qi) * dim + head * 64 + j * 16 + (lane & 15)] = oacc[j][r] * inv;
-        }
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(out + ((long long)view * N + qi) * dim + head * 64 + j * 16 + 4 * g) =
+                make_float4(oacc[j][0] * inv, oacc[j][1] * inv, oacc[j][2] * inv, oacc[j][3] * inv);
     }
 }
 
@@ -487,10 +489,17 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
     static const bool f32_gemm = getenv("TH_VIT_GEMM_F32") != nullptr;
     const bool h3 = allow_h3 && !f32_gemm && !separate_ln && th_gemm_h3_ok(T, W.blocks[0].qkv, true) && th_gemm_h3_ok(T, W.blocks[0].fc1, true) &&
                     th_gemm_h3_ok(T, W.blocks[0].proj, false) && th_gemm_h3_ok(T, W.blocks[0].fc2, false);
+    // the K / V^T operand planes of the register-fed attention are written by the qkv GEMM's epilogue (no kv_split launch);
+    // the padding keys (N .. Npad) of the planes must read as zero: cleared once per forward
+    static const bool no_fuse_split = getenv("TH_VIT_KV_SPLIT") != nullptr;       // A/B switch: the separate launch
+    const bool fuse_split = h3 && !attn_lds && !no_fuse_split;
+    const ThQkvSplit qs{Kp, Vp, N, Npad, heads, dim};
+    if (fuse_split && Npad != N)
+        TH_HIP(hipMemsetAsync(Kp, 0, ((char*)Vp - (char*)Kp) + (size_t)V * heads * 2 * Npad * 64 * sizeof(_Float16), s));   // Kp .. end of Vp
     for (int b = 0; b < W.depth; ++b) {
         const ThVitBlockPacked& B = W.blocks[b];
         if (h3) {
-            TH_TRY(th_gemm_h3(X, dim, T, B.qkv, B.ln1_w, B.ln1_b, 1e-6f, TH_ACT_NONE, Q, 3 * dim, range, s));
+            TH_TRY(th_gemm_h3(X, dim, T, B.qkv, B.ln1_w, B.ln1_b, 1e-6f, TH_ACT_NONE, Q, 3 * dim, range, s, fuse_split ? &qs : nullptr));
         } else if (fuse_ln) {
             TH_TRY(th_gemm_ln(X, dim, T, B.qkv, B.ln1_w, B.ln1_b, 1e-6f, TH_ACT_NONE, Q, 3 * dim, s));
         } else {
@@ -500,7 +509,8 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
         if (attn_lds) {
             hipLaunchKernelGGL(attn_kernel, dim3(th_cdiv(N, AT_Q), heads, V), dim3(256), 0, s, Q, N, dim, scale, Y);
         } else {
-            hipLaunchKernelGGL(kv_split_kernel, dim3(Npad / 64, heads, V), dim3(256), 0, s, Q, N, Npad, dim, Kp, Vp);
+            if (!(h3 && fuse_split))
+                hipLaunchKernelGGL(kv_split_kernel, dim3(Npad / 64, heads, V), dim3(256), 0, s, Q, N, Npad, dim, Kp, Vp);
             hipLaunchKernelGGL(attn2_kernel, dim3(th_cdiv(N, 16), heads, V), dim3(64), 0, s, Q, Kp, Vp, N, Npad, dim, scale, Y);
         }
         if (h3) {

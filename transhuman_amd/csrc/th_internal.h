@@ -85,8 +85,16 @@ int th_pack_linear_h3(const th_linear& lin, void* storage_h3, ThPacked* out, hip
 // C = act([LayerNorm](A) W^T + b) (+C) on the fp16-split MFMA path (layers packed with th_pack_linear_h3, M <= 8192,
 // K <= 768); range: the guard's slot TH_RANGE_VIT takes max |a| of the split operand
 bool th_gemm_h3_ok(int M, const ThPacked& W, bool ln);
+// qkv epilogue of the ViT (optional): output columns >= dim (the keys and values of row = view * N + key) are not stored
+// as fp32 but as the fp16 hi | lo operand planes of attn2_kernel (k_vit.hip: Kp [V][heads][2][Npad][64],
+// Vp [V][heads][2][64][Npad] in the fragment key order) -- the per-layer kv_split launch disappears
+struct ThQkvSplit {
+    _Float16* Kp;
+    _Float16* Vp;
+    int N, Npad, heads, dim;
+};
 int th_gemm_h3(const float* A, int lda, int M, const ThPacked& W, const float* ln_w, const float* ln_b, float eps, int flags,
-               float* C, int ldc, unsigned int* range, hipStream_t s);
+               float* C, int ldc, unsigned int* range, hipStream_t s, const ThQkvSplit* qkv = nullptr);
 // C[M,N] = act(A[M,K] W^T + b) (+ C if TH_GEMM_ACCUM)
 int th_gemm(const float* A, int lda, int M, const ThPacked& W, int flags, float* C, int ldc, hipStream_t s);
 // C = act(LayerNorm(A rows; ln_w, ln_b, eps) W^T + b) (+ C): the normalisation happens inside the GEMM
@@ -116,6 +124,29 @@ static inline ThPointSrc th_src(const th_points* p) {
 // z = near*(1-t) + far*t ; p = o + d*z  -- separate roundings like the torch
 // elementwise ops of if_clight_renderer.py:274,285 (contraction is disabled
 // for the whole library with -ffp-contract=off).
+// Reductions over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15) with data-parallel-primitive moves: VALU speed,
+// no LDS round trip like the ds_bpermute behind __shfl_xor.  Every lane ends up with the full result; the pairing of
+// the first two steps is xor 1, xor 2 and the mirrored lanes of the last two steps hold the same partial results as
+// lane ^ 4 / lane ^ 8 would, so sums are bit-identical to the xor butterfly.
+template <int CTRL>
+__device__ __forceinline__ float th_dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float th_row16_sum(float s) {
+    s += th_dpp_f<0xB1>(s);      // quad_perm [1,0,3,2]
+    s += th_dpp_f<0x4E>(s);      // quad_perm [2,3,0,1]
+    s += th_dpp_f<0x141>(s);     // row_half_mirror
+    s += th_dpp_f<0x140>(s);     // row_mirror
+    return s;
+}
+__device__ __forceinline__ float th_row16_max(float m) {
+    m = fmaxf(m, th_dpp_f<0xB1>(m));
+    m = fmaxf(m, th_dpp_f<0x4E>(m));
+    m = fmaxf(m, th_dpp_f<0x141>(m));
+    m = fmaxf(m, th_dpp_f<0x140>(m));
+    return m;
+}
+
 __device__ __forceinline__ float th_sample_z(const ThPointSrc& ps, int ray, int s) {
     return ps.near[ray] * ps.omt[s] + ps.far[ray] * ps.tv[s];
 }
