@@ -477,7 +477,9 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
     // tile: a quarter of the L2 traffic, which is what bounds the register-fed form from N ~ 1000 on).
     // Measured ViT forward, N_c = 300 / 500 / 1500: 0.80 / 0.99 / 2.15 ms register-fed, 0.86 / 1.07 / 2.06 ms LDS-staged.
     static const char* attn_env = getenv("TH_ATTN_FORM");               // "lds" | "reg": A/B switch
-    const bool attn_lds = attn_env ? attn_env[0] == 'l' : N > 768;
+    // (transposed register-fed form, late round 2: 0.77 / 0.95 / 1.19 / 2.06 ms at N_c = 500 / 800 / 1000 / 1500 against 0.93 / 1.16 /
+    // 1.27 / 1.76 ms LDS-staged)
+    const bool attn_lds = attn_env ? attn_env[0] == 'l' : N > 1100;
     TH_REQUIRE(Q != nullptr, "workspace carve failed");
     long long n = (long long)T * dim;
     hipLaunchKernelGGL(add_kernel, dim3(th_cdiv(n, 256)), dim3(256), 0, s, x, pe, n, X);
