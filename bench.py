@@ -336,6 +336,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # TH_ONE_GPU=1 (developer aid, with TH_DIST_BACKEND=gloo): every rank of a torchrun job uses cuda:0 -- the multi-rank
+    # control flow (ray shards, token exchange, deferred count, image gather) end to end on a one-GPU box; RCCL refuses
+    # two ranks on one device, gloo moves CUDA tensors through the host
+    if os.environ.get("TH_ONE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # TH_FORCE_DIST=1 runs the RCCL code path (process group, all_reduce, all_gather) even with one rank
@@ -345,7 +350,11 @@ def main():
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        backend = os.environ.get("TH_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     from transhuman_amd import hip
     from transhuman_amd.networks.renderer.if_clight_renderer import Renderer
@@ -430,6 +439,9 @@ def main():
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if rank == 0 and os.environ.get("TH_SAVE_IMAGE"):     # developer aid: the last timed frame [R, 5] (rgb, acc, depth)
+        import numpy as _np
+        _np.save(os.environ["TH_SAVE_IMAGE"], img.detach().cpu().numpy())
     prof = hip.profile_read()
     hip.profile_enable(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -46,6 +46,13 @@ def shard_lengths(H, W, world, tile=8):
     return [int(shard_ray_indices(H, W, world, r, tile).numel()) for r in range(world)]
 
 
+def _into_tensor_ok(t, group=None):
+    """all_gather_into_tensor is the RCCL path (device tensors, backend nccl); gloo -- CPU tests, or the one-GPU
+    multi-rank check of bench.py (TH_DIST_BACKEND=gloo) -- gathers a list"""
+    import torch.distributed as dist
+    return t.is_cuda and dist.get_backend(group) == "nccl"
+
+
 def gather_image(local, my_idx, n_rays, world, H=None, W=None, tile=8, group=None):
     """all_gather the per-rank [n_local, C] results into the dense [n_rays, C] image on
     every rank.  Shards may differ in length (ragged tile counts): padded to the max."""
@@ -62,7 +69,7 @@ def gather_image(local, my_idx, n_rays, world, H=None, W=None, tile=8, group=Non
     pad_idx[: my_idx.numel()] = my_idx
     all_val = torch.empty((world * mx, C), dtype=local.dtype, device=local.device)
     all_idx = torch.empty((world * mx,), dtype=torch.int64, device=local.device)
-    if local.is_cuda:
+    if _into_tensor_ok(local, group):
         dist.all_gather_into_tensor(all_val, pad_val, group=group)
         dist.all_gather_into_tensor(all_idx, pad_idx, group=group)
     else:  # gloo (CPU tests)
@@ -106,7 +113,7 @@ class ImageGatherer:
         import torch.distributed as dist
         assert local.shape == (self.n_local, self.C)
         self.pad[: self.n_local] = local
-        if local.is_cuda:
+        if _into_tensor_ok(local, self.group):
             dist.all_gather_into_tensor(self.all_val, self.pad, group=self.group)
             vals = self.all_val
         else:  # gloo (CPU tests)
