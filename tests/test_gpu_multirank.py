@@ -1,0 +1,49 @@
+"""GPU: the N-rank job of bench.py end to end on ONE device -- `torch.distributed.run` with two / three ranks that all use
+cuda:0 over gloo (RCCL refuses two ranks per device; `TH_DIST_BACKEND=gloo TH_ONE_GPU=1`).  Everything but the transport is
+what an 8-GPU node runs: diagonal 8x8 ray-tile shards (ragged at three ranks), TransHE owned by rank j mod N and broadcast
+from the side stream, the deferred whole-frame hit count, the cached-layout image gather.  The gathered frame must be
+bit-identical to the single-rank frame (rays are independent given the per-frame constants: SURVEY.md 8e)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--steps", "2", "--warmup", "1", "--no-extras", "--no-cpu-baseline"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(n, path, res):
+    env = dict(os.environ, TH_SAVE_IMAGE=path, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if n == 1:
+        cmd = [sys.executable, "bench.py", "--res", str(res)] + ARGS
+    else:
+        env.update(TH_DIST_BACKEND="gloo", TH_ONE_GPU="1")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), "--res", str(res)] + ARGS
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res", [128, 96])
+def test_two_and_three_rank_frames_equal_the_single_rank_frame(tmp_path, res):
+    """res 128: ~3200 hit rays (masked branch); res 96: ~1800 <= 2400 -- the reference's small-frame rule fires on the
+    WHOLE-frame count (all-reduced) and every rank re-renders its shard un-masked (if_clight_renderer.py:551)"""
+    one = _run(1, str(tmp_path / "n1.npy"), res)
+    hits = int((one[:, 3] > 0).sum())
+    assert one.shape == (res * res, 5) and ((res == 128 and hits > 2400) or (res == 96 and 500 < hits <= 2400)), hits
+    for n in (2, 3):
+        img = _run(n, str(tmp_path / f"n{n}.npy"), res)
+        assert np.array_equal(one, img), (n, float(np.abs(one - img).max()))
