@@ -620,6 +620,8 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
     if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if rank == 0 and os.environ.get("TH_SAVE_IMAGE"):     # developer aid: the last frame [R, 5] / sigma grid [grid^3]
+        np.save(os.environ["TH_SAVE_IMAGE"], res.detach().cpu().numpy())
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

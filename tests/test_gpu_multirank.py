@@ -23,14 +23,14 @@ def _free_port():
     return p
 
 
-def _run(n, path, res):
+def _run(n, path, res, extra=()):
     env = dict(os.environ, TH_SAVE_IMAGE=path, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if n == 1:
-        cmd = [sys.executable, "bench.py", "--res", str(res)] + ARGS
+        cmd = [sys.executable, "bench.py", "--res", str(res)] + ARGS + list(extra)
     else:
         env.update(TH_DIST_BACKEND="gloo", TH_ONE_GPU="1")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
-               "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), "--res", str(res)] + ARGS
+               "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", str(n), "--res", str(res)] + ARGS + list(extra)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     return np.load(path)
@@ -47,3 +47,15 @@ def test_two_and_three_rank_frames_equal_the_single_rank_frame(tmp_path, res):
     for n in (2, 3):
         img = _run(n, str(tmp_path / f"n{n}.npy"), res)
         assert np.array_equal(one, img), (n, float(np.abs(one - img).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,extra", [("orbit", ()), ("mesh", ("--grid", "48"))])
+def test_secondary_workloads_two_ranks(tmp_path, workload, extra):
+    """C3 (orbit along gen_path_virt, rays generated on device, pixel tiles dealt to the ranks) and C5 (sigma grid, voxel
+    runs dealt to the ranks): the gathered result of a two-rank job equals the single-rank result"""
+    ex = ("--workload", workload) + tuple(extra)
+    one = _run(1, str(tmp_path / "n1.npy"), 192, ex)
+    two = _run(2, str(tmp_path / "n2.npy"), 192, ex)
+    assert one.shape == two.shape and float(np.abs(one).max()) > 0
+    assert np.array_equal(one, two), float(np.abs(one - two).max())
