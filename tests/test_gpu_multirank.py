@@ -1,8 +1,8 @@
 """GPU: the N-rank job of bench.py end to end on ONE device -- `torch.distributed.run` with two / three ranks that all use
 cuda:0 over gloo (RCCL refuses two ranks per device; `TH_DIST_BACKEND=gloo TH_ONE_GPU=1`).  Everything but the transport is
 what an 8-GPU node runs: diagonal 8x8 ray-tile shards (ragged at three ranks), TransHE owned by rank j mod N and broadcast
-from the side stream, the deferred whole-frame hit count, the cached-layout image gather.  The gathered frame must be
-bit-identical to the single-rank frame (rays are independent given the per-frame constants: SURVEY.md 8e)."""
+from the side stream, the deferred whole-frame hit count, the cached-layout image gather.  The gathered frame must equal
+the single-rank frame to fp32 rounding (rays are independent given the per-frame constants: SURVEY.md 8e)."""
 import os
 import socket
 import subprocess
@@ -46,7 +46,10 @@ def test_two_and_three_rank_frames_equal_the_single_rank_frame(tmp_path, res):
     assert one.shape == (res * res, 5) and ((res == 128 and hits > 2400) or (res == 96 and 500 < hits <= 2400)), hits
     for n in (2, 3):
         img = _run(n, str(tmp_path / f"n{n}.npy"), res)
-        assert np.array_equal(one, img), (n, float(np.abs(one - img).max()))
+        # (equal to fp32 rounding: a rank's shard regroups the valid samples into other 32-sample tiles, and the fused kernel's
+        # token blend accumulates over the union of a tile's neighbour centres)
+        assert one.shape == img.shape and float(np.abs(one[:, :4] - img[:, :4]).max()) < 2e-6, (n, float(np.abs(one - img).max()))
+        assert float(np.abs(one[:, 4] - img[:, 4]).max()) < 2e-5 * max(1.0, float(np.abs(one[:, 4]).max()))
 
 
 @pytest.mark.gpu
@@ -58,4 +61,4 @@ def test_secondary_workloads_two_ranks(tmp_path, workload, extra):
     one = _run(1, str(tmp_path / "n1.npy"), 192, ex)
     two = _run(2, str(tmp_path / "n2.npy"), 192, ex)
     assert one.shape == two.shape and float(np.abs(one).max()) > 0
-    assert np.array_equal(one, two), float(np.abs(one - two).max())
+    assert float(np.abs(one - two).max()) <= 2e-5 * max(1.0, float(np.abs(one).max())), float(np.abs(one - two).max())

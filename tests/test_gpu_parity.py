@@ -372,7 +372,10 @@ def test_render_ray_sharding_equals_full(hip, gpu, net):
         for k in ("ray_o", "ray_d", "near", "far"):
             bb[k] = b[k][:, sel]
         parts2[sel] = r.render_fast(bb, frame=frame, small_frame_rays=-1)["rgb_map"][0]
-    assert torch.equal(parts2, full2)
+    # (a shard regroups the valid samples into different 32-sample tiles; the fused kernel blends a tile's token rows on the
+    # matrix pipe over the UNION of the tile's neighbour centres (TH_ROWS_NBR), so the position of a sample's seven
+    # terms in the accumulation depends on its tile mates: equal to fp32 rounding, not bit for bit)
+    assert float((parts2 - full2).abs().max()) < 2e-6
     # the threshold is a property of the CALL, also when the frame constants are handed in: the default
     # 2400 puts the same shard into the reference's un-masked branch
     bb = dict(b)

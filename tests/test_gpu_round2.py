@@ -334,7 +334,7 @@ def test_full_size_frame_nc1500_properties_and_oracle_sample(hip, gpu, net):
     assert float(acc[~hit].abs().max()) == 0.0 and float(rgb[~hit].abs().max()) == 0.0      # misses are exactly zero
     again = r.render_fast(b, is_train=False)
     assert torch.equal(again["rgb_map"], out["rgb_map"]) and torch.equal(again["acc_map"], out["acc_map"])   # run to run
-    # ray-sharded == whole frame, bit for bit (8 ranks' shards)
+    # ray-sharded == whole frame (8 ranks' shards)
     from transhuman_amd.dist import shard_ray_indices
     frame = r.prepare_frame(b)
     idx = shard_ray_indices(512, 512, 8, 5, tile_major=True).to(gpu)
@@ -343,7 +343,8 @@ def test_full_size_frame_nc1500_properties_and_oracle_sample(hip, gpu, net):
         sh[k] = b[k][:, idx].contiguous()
     whole = r.render_fast(b, frame=frame, small_frame_rays=-1)
     part = r.render_fast(sh, frame=frame, small_frame_rays=-1)
-    assert torch.equal(part["rgb_map"][0], whole["rgb_map"][0][idx])
+    # (fp32 rounding, not bit for bit: see test_render_ray_sharding_equals_full)
+    assert float((part["rgb_map"][0] - whole["rgb_map"][0][idx]).abs().max()) < 2e-6
     # oracle on 96 rays (64 of them hits)
     rs = np.random.RandomState(11)
     hits = torch.nonzero(hit).reshape(-1).cpu().numpy()
@@ -385,13 +386,14 @@ def test_full_size_sigma_grid_256_and_mesh(hip, gpu, net):
     m = m.view(-1).cpu()
     assert int(m.sum()) == r.last_stats["valid_samples"] > 200000
     assert float(cube.reshape(-1)[~m].abs().max()) == 0.0
-    # a shard (every 8th run of 4096 voxels, like bench.py deals them) equals the full evaluation bit for bit
+    # a shard (every 8th run of 4096 voxels, like bench.py deals them) equals the full evaluation (to fp32 rounding: the
+    # shard's valid samples form different 32-sample tiles, see test_render_ray_sharding_equals_full)
     frame = r.prepare_frame(b)
     run = torch.arange(256 ** 3, device=gpu) // 4096
     mine = torch.nonzero(run % 8 == 3).reshape(-1)
     part = r.render(b, frame=frame, pts_slice=mine)["sigma"]
     full = r.render(b, frame=frame, pts_slice=torch.arange(256 ** 3, device=gpu))["sigma"]
-    assert torch.equal(part, full[mine])
+    assert float((part - full[mine]).abs().max()) <= 2e-5 * max(1.0, float(full.abs().max()))
     mesh = out["mesh"]
     assert mesh.vertices.shape[0] > 10000 and mesh.is_watertight
     v = mesh.vertices.cpu().numpy()

@@ -215,6 +215,13 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* cen = lds;                                   // [nc*3]
     DpNbr* nb = reinterpret_cast<DpNbr*>(lds + ((nc * 3 + 3) & ~3));
+    // TH_ROWS_NBR: per 32-sample tile of the fused kernel (4 per workgroup) a bitmap over the centre indices and the slot
+    // of every bitmap word's first set bit
+    unsigned* ubm = reinterpret_cast<unsigned*>(nb + DP_SAMPLES);       // [4][128]
+    unsigned* ubw = ubm + 4 * 128;                                       // [4][128]
+    if constexpr (FOLDED && VT < 0) {
+        for (int i = threadIdx.x; i < 4 * 128; i += DP_THREADS) ubm[i] = 0u;
+    }
     for (int i = threadIdx.x; i < nc * 3; i += DP_THREADS) cen[i] = centres[i];
     __syncthreads();
 
@@ -283,6 +290,7 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                 int c = bi[k];
                 o.w[k] = xs[k] / se;
                 o.idx[k] = c;
+                if constexpr (FOLDED && VT < 0) atomicOr(&ubm[(ls >> 5) * 128 + (c >> 5)], 1u << (c & 31));
                 float rx = x - cen[3 * c], ry = y - cen[3 * c + 1], rz = z - cen[3 * c + 2];
                 const float* Rm = rot + 9 * c;
                 o.def[k][0] = fmaf(rz, Rm[6], fmaf(ry, Rm[3], rx * Rm[0]));
@@ -295,6 +303,29 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
 
     // ---- phase 2: wave per sample ----
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar)
+    if constexpr (FOLDED && VT < 0) {
+        // Tile header (512 B behind the records): hdr[0] = U, the size of the union of the tile's neighbour sets, then
+        // the centre of every slot as unsigned short, ascending.  Wave t serves tile t of this workgroup.
+        const long long tile = (long long)blockIdx.x * 4 + wave;
+        if (tile * 32 < P) {
+            unsigned* hdr = reinterpret_cast<unsigned*>(out) + (long long)((P + 31) / 32 * 32) * 16 + tile * 128;
+            unsigned short* scl = reinterpret_cast<unsigned short*>(hdr) + 2;
+            unsigned w0 = ubm[wave * 128 + 2 * lane], w1 = ubm[wave * 128 + 2 * lane + 1];
+            const int c0 = __popc(w0), c1 = __popc(w1);
+            int incl = c0 + c1;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            int base = incl - c0 - c1;
+            ubw[wave * 128 + 2 * lane] = (unsigned)base;
+            ubw[wave * 128 + 2 * lane + 1] = (unsigned)(base + c0);
+            if (lane == 63) hdr[0] = (unsigned)incl;
+            while (w0) { const int bit = __ffs(w0) - 1; scl[base++] = (unsigned short)(64 * lane + bit); w0 &= w0 - 1; }
+            while (w1) { const int bit = __ffs(w1) - 1; scl[base++] = (unsigned short)(64 * lane + 32 + bit); w1 &= w1 - 1; }
+        }
+        __syncthreads();
+    }
     const float PI_F = 3.14159274101257324219f;          // fp32(pi)
     const float HALF_PI_F = 1.57079637050628662109f;     // fp32(pi/2)
     // PE channel `lane` (0..62): 0..2 raw xyz; then per octave f: sin xyz, cos xyz
@@ -330,6 +361,23 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                 float val = (lane < 3) ? xv : dp_sin(fmaf(xv, freq, phase));
                 pe = (k == 0) ? w[k] * val : fmaf(w[k], val, pe);
             }
+        }
+        if constexpr (FOLDED && VT < 0) {
+            // TH_ROWS_NBR: the neighbour record (16 dwords) + the positional-encoding row; no table access
+            if (lane < 16) {
+                unsigned rec = 0u;
+                if (lane < 7) {
+                    const int c = n.idx[lane], t = lp >> 5;
+                    rec = ubw[t * 128 + (c >> 5)] + __popc(ubm[t * 128 + (c >> 5)] & ((1u << (c & 31)) - 1u));   // slot of centre c
+                } else if (lane >= 8 && lane < 15) rec = __builtin_bit_cast(unsigned, n.w[lane - 8]);
+                reinterpret_cast<unsigned*>(out)[(long long)gp * 16 + lane] = rec;
+            }
+            _Float16* ph = reinterpret_cast<_Float16*>(pe_out) + (long long)gp * 128;
+            _Float16 x, y;
+            dp_split((lane < 63) ? pe : 0.f, x, y);
+            ph[lane] = x;
+            ph[64 + lane] = y;
+            continue;
         }
         if constexpr (FOLDED && VT > 0) {
             // all VT * 7 row loads of the sample in flight before the first blend (one exposed round trip per sample
@@ -405,7 +453,7 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
     TH_REQUIRE(nc >= DP_K, "need at least 7 token centres");
     ThPointSrc src;
     if (ps) src = *ps; else { src = ThPointSrc{}; }
-    size_t lds = ((size_t)((nc * 3 + 3) & ~3)) * sizeof(float) + DP_SAMPLES * sizeof(DpNbr);
+    size_t lds = ((size_t)((nc * 3 + 3) & ~3)) * sizeof(float) + DP_SAMPLES * sizeof(DpNbr) + 2 * 4 * 128 * sizeof(unsigned);
     TH_REQUIRE(lds <= 160 * 1024, "too many token centres for LDS staging");
     static bool attr_set = false;
     if (!attr_set) {
@@ -413,7 +461,8 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
         TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    TH_REQUIRE(fmt == TH_ROWS_F32 || (fmt == TH_ROWS_FOLDED && pe_out != nullptr), "K4 writes fp32 rows or the folded form");
+    TH_REQUIRE(fmt == TH_ROWS_F32 || ((fmt == TH_ROWS_FOLDED || fmt == TH_ROWS_NBR) && pe_out != nullptr),
+               "K4 writes fp32 rows, the folded form or neighbour records");
     // optional candidate grid (th_dparf_grid_build into grid_ws): same carve as the builder
     const DpGrid* gi = nullptr;
     const int *cnt = nullptr, *cand = nullptr;
@@ -424,7 +473,15 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
         cand = ar.take<int>((size_t)DPG_MAXCELLS * nc);
     }
     static const bool per_view = getenv("TH_DPARF_PER_VIEW") != nullptr;       // A/B switch
-    if (fmt == TH_ROWS_FOLDED && V == 3 && !per_view) {
+    if (fmt == TH_ROWS_NBR) {
+        static bool attrn = false;
+        if (!attrn) {
+            TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attrn = true;
+        }
+        hipLaunchKernelGGL((dparf_kernel<true, -1>), dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
+                           Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out, gi, cnt, cand);
+    } else if (fmt == TH_ROWS_FOLDED && V == 3 && !per_view) {
         static bool attr3 = false;
         if (!attr3) {
             TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

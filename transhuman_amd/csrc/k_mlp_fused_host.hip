@@ -300,9 +300,51 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
     return 0;
 }
 
+// ---- per-frame token table as split rows (TH_ROWS_NBR path) ---------------------------------------------------
+__global__ __launch_bounds__(256) void tok_split_kernel(float* __restrict__ t, int rows, float* __restrict__ sc,
+                                                        unsigned int* __restrict__ range) {
+    const unsigned bits = reinterpret_cast<const unsigned*>(sc)[1];
+    const int E = (int)((bits >> 23) & 255u);
+    int sl2 = 0;                                           // zero / non-finite table: scale 1
+    if (E == 255) { if (range != nullptr && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(range + TH_RANGE_VIT, 0x7c00u); }
+    else if (bits != 0u) sl2 = min(139 - E, 100);          // max |T'| = m 2^e, m in [0.5, 1): e = E - 126, k = 13 - e
+    const float scale = __builtin_bit_cast(float, (unsigned)(sl2 + 127) << 23);
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc[0] = __builtin_bit_cast(float, (unsigned)(127 - sl2) << 23);
+    const int lane = threadIdx.x & 63;
+    // one wave per row, in place: every lane holds its float4 before the first half is written over the row
+    for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += gridDim.x * 4) {
+        float* row = t + (long long)r * 256;
+        const float4 x = reinterpret_cast<const float4*>(row)[lane];
+        const float v[4] = {x.x * scale, x.y * scale, x.z * scale, x.w * scale};
+        h4 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            _Float16 hi, lo;
+            split_h(v[e], hi, lo);
+            hv[e] = hi;
+            lv[e] = lo;
+        }
+        __builtin_amdgcn_s_waitcnt(0);                    // (the loads of ALL lanes have returned: same instruction)
+        _Float16* rh = reinterpret_cast<_Float16*>(row);
+        *reinterpret_cast<h4*>(rh + 4 * lane) = hv;
+        *reinterpret_cast<h4*>(rh + 256 + 4 * lane) = lv;
+    }
+}
+
+int th_tok_split(float* tprime, int rows, float* sc, unsigned int* range, hipStream_t s) {
+    if (rows <= 0) return 0;
+    unsigned int* amax = reinterpret_cast<unsigned int*>(sc) + 1;
+    TH_HIP(hipMemsetAsync(amax, 0, 4, s));
+    hipLaunchKernelGGL(absmax_kernel, dim3(64), dim3(256), 0, s, tprime, (long long)rows * 256, amax);
+    hipLaunchKernelGGL(tok_split_kernel, dim3(th_cdiv(rows, 4) < 1024 ? th_cdiv(rows, 4) : 1024), dim3(256), 0, s, tprime, rows, sc,
+                       range);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all, float* raw_c,
-                         unsigned int* range, hipStream_t s) {
+                         unsigned int* range, hipStream_t s, const void* tsplit, const float* t_inv, int t_nc) {
     if (P <= 0) return 0;
     TH_REQUIRE(V >= 1 && V <= 3, "fused MLP supports 1..3 reference views");
     TH_REQUIRE(f_ld == 384 || (f_ld == 272 && base.compact_ready),
@@ -311,6 +353,8 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     FusedParams p = base;
     if (cf) { p.ar0 = base.ar0c; p.rst = base.rstc; }
     p.alpha_w = heads.alpha_w; p.alpha_b = heads.alpha_b; p.rgb_w = heads.rgb_w; p.rgb_b = heads.rgb_b;
+    TH_REQUIRE(tsplit == nullptr || (t_inv != nullptr && t_nc >= 7 && t_nc <= 4096), "split token table: scale word and 7 <= N_c <= 4096");
+    p.tsplit = (const _Float16*)tsplit; p.t_inv = t_inv; p.t_nc = t_nc;
     p.stok = stok; p.pe = (const _Float16*)pe; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all; p.range = range;
     static bool attr = false;
     if (!attr) {

@@ -642,6 +642,126 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         const int psrc = min(prow, npts - 1);
         const uint4 pe_h = *reinterpret_cast<const uint4*>(P.pe + (long long)(pbase + psrc) * 128 + 8 * pc);
         const uint4 pe_l = *reinterpret_cast<const uint4*>(P.pe + (long long)(pbase + psrc) * 128 + 64 + 8 * pc);
+        const int aoff = (lane & 31) * STR64 + (lane >> 5) * 16;
+        if (P.tsplit != nullptr) {
+            // ---- TH_ROWS_NBR: the blend of T' rows is formed HERE, on the matrix pipe -------------------------------
+            // K4 hands over, per sample, the 7 nearest token centres and their softmax weights (64 bytes instead of
+            // 3 KB of blended rows through HBM).  The 32 samples of a tile share most of their neighbours: the union U
+            // of their centres (typically 15-25) defines "slots"; stok^T[ch][sample] = sum_slot T'^T[ch][slot] W[slot][sample]
+            // is one more GEMM of the tile with K = U: its "weights" are the U x V rows of the per-frame table T' (split
+            // fp16 hi | lo, 1 KiB per row, L2-resident: 60 KB per tile at the L2 rate instead of 96 KB at the per-CU HBM
+            // rate), its activations the sparse weight matrix W (7 non-zeros per sample).  Passes of 32 slots.
+            // K4 also forms the union per tile (it works on the same 32-sample groups): a 512-byte tile header -- U and the
+            // centre of every slot -- and per sample the SLOTS of its 7 neighbours.  Every wave reads the header into
+            // registers (two dwords per lane) and addresses its share of the row loads through v_readlane: no LDS
+            // bookkeeping and no barrier in front of the LDS-DMA loads.
+            char* wsp_hi = mbuf + 16384;                                     // W [sample][slot] halves, K = 32 per pass
+            char* wsp_lo = wsp_hi + 32 * STRVD;
+            const unsigned* hdr = reinterpret_cast<const unsigned*>(P.stok) + (long long)((P.P + 31) / 32 * 32) * 16 +
+                                  (long long)blockIdx.x * 128;
+            const unsigned h0 = hdr[lane], h1 = hdr[64 + lane];
+            const int ns = tid / 7, nk = tid - 7 * ns;
+            int slot = -1;
+            float nw = 0.f;
+            if (tid < 224) {
+                const unsigned* rec = reinterpret_cast<const unsigned*>(P.stok) + (long long)(pbase + min(ns, npts - 1)) * 16;
+                slot = (int)rec[nk];
+                nw = __builtin_bit_cast(float, rec[8 + nk]);
+            }
+            // (the L2-resident fc_0 weights / bias are requested now: they travel during the header's HBM round trip)
+            const float inv_t = P.t_inv[0];
+            uint4 wq[4][2][2];
+            const uint4* wl = wslice(P.fc_0pe, wave, 2, 0) + lane;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) load_wfrag<2>(wl, kb, wq[kb]);
+            const BiasT b0[2] = {load_bias(P.fc_0pe.bias, wave * 64, lane), load_bias(P.fc_0pe.bias, wave * 64 + 32, lane)};
+            for (int i = tid; i < 2 * 32 * STRVD / 16; i += 256) reinterpret_cast<uint4*>(wsp_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(pe_hi + prow * STR64 + 16 * pc) = pe_h;
+            *reinterpret_cast<uint4*>(pe_lo + prow * STR64 + 16 * pc) = pe_l;
+            const int U = __builtin_amdgcn_readfirstlane((int)h0);          // (hdr[0])
+            auto slot_centre = [&](int u) {                                  // wave-uniform u
+                const int d = (2 + u) >> 1;
+                const unsigned src = d < 64 ? (unsigned)__builtin_amdgcn_readlane((int)h0, d) : (unsigned)__builtin_amdgcn_readlane((int)h1, d - 64);
+                return (int)((src >> (16 * ((2 + u) & 1))) & 0xffffu);
+            };
+            zero_acc<2, V>(acc2);
+            f32x16 a1[2][1];
+            const int wv = __builtin_amdgcn_readfirstlane(wave);
+            const int aoffw = (lane & 31) * STRVD + (lane >> 5) * 16;
+            for (int u0 = 0; u0 < U; u0 += 32) {
+                const int nU = min(32, U - u0), KBu = (nU + 15) >> 4;
+                if (u0 > 0) {
+                    FM_SYNCL();                                      // the previous pass's operands have been read
+                    for (int i = tid; i < 2 * 32 * STRVD / 16; i += 256) reinterpret_cast<uint4*>(wsp_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
+                }
+                // T' rows of the pass (only the nU real ones: the k-padding of the last block re-reads row nU - 1 below)
+                for (int i = wv; i < V * nU; i += 4) {
+                    const int vw = i / nU, u = i - vw * nU;
+                    const int cu = slot_centre(u0 + u);
+                    const char* g = reinterpret_cast<const char*>(P.tsplit) + ((long long)vw * P.t_nc + cu) * 1024 + lane * 16;
+                    __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)(abuf + (vw * 32 + u) * STOK_STR), 16, 0, 0);
+                }
+                FM_SYNCL();                                          // W is cleared (and the pe rows are in place)
+                if (slot >= u0 && slot < u0 + 32) {
+                    _Float16 hi, lo;
+                    split_h(nw, hi, lo);
+                    *reinterpret_cast<_Float16*>(wsp_hi + ns * STRVD + 2 * (slot - u0)) = hi;
+                    *reinterpret_cast<_Float16*>(wsp_lo + ns * STRVD + 2 * (slot - u0)) = lo;
+                }
+                if (u0 == 0) {                                       // W_pe pe under the row loads
+                    zero_acc<2, 1>(a1);
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) {
+                        h8 xh[1], xl[1];
+                        load_xfrag<1, STR64, 0>(pe_hi, pe_lo, aoff, kb, xh, xl);
+                        mfma_kblock<1, 2>(wq[kb], xh, xl, a1);
+                    }
+                }
+                FM_SYNC();                                           // rows (LDS-DMA) and W are in place
+                for (int kb = 0; kb < KBu; ++kb) {
+                    h8 xh[1], xl[1];
+                    load_xfrag<1, STRVD, 0>(wsp_hi, wsp_lo, aoffw, kb, xh, xl);
+                    int roff[8];                                     // slot rows of this lane's 8 k values (padding clamped)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) roff[j] = min(kb * 16 + 8 * (lane >> 5) + j, nU - 1) * STOK_STR;
+#pragma unroll
+                    for (int r = 0; r < V; ++r)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const char* rb = abuf + r * 32 * STOK_STR + 2 * (wave * 64 + c * 32 + (lane & 31));
+                            h8 ah, al;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                ah[j] = *reinterpret_cast<const _Float16*>(rb + roff[j]);
+                                al[j] = *reinterpret_cast<const _Float16*>(rb + roff[j] + 512);
+                            }
+                            acc2[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, xh[0], acc2[c][r], 0, 0, 0);
+                            acc2[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xl[0], acc2[c][r], 0, 0, 0);
+                            acc2[c][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, xh[0], acc2[c][r], 0, 0, 0);
+                        }
+                }
+            }
+            FM_SYNCL();                                   // every wave is done reading the T' rows: ABUF may take s
+            const f32x2 it2 = {inv_t, inv_t};
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                finish_tile_b<1>(a1[c], b0[c], P.fc_0pe.inv_scale, false);
+#pragma unroll
+                for (int r = 0; r < V; ++r) {
+                    f32x2 u[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        u[q] = __builtin_elementwise_fma((f32x2){acc2[c][r][2 * q], acc2[c][r][2 * q + 1]}, it2,
+                                                         (f32x2){a1[c][0][2 * q], a1[c][0][2 * q + 1]});
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        acc2[c][r][2 * q] = fmaxf(u[q][0], 0.f);
+                        acc2[c][r][2 * q + 1] = fmaxf(u[q][1], 0.f);
+                    }
+                    store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
+                }
+            }
+        } else {
         FM_SB();
         {   // the HBM filling first: the (L2-resident) fc_0 weights and bias queue behind it, not in front of it
             const int wv = __builtin_amdgcn_readfirstlane(wave);
@@ -665,7 +785,6 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         FM_SYNC();
         f32x16 a1[2][1];
         zero_acc<2, 1>(a1);
-        const int aoff = (lane & 31) * STR64 + (lane >> 5) * 16;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
             h8 xh[1], xl[1];
@@ -701,6 +820,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 }
                 store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
             }
+        }
         }
         range_commit(P.range, TH_RANGE_S, seen_s, rmax);
     }

@@ -606,13 +606,27 @@ static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
 // which K6 form runs for V views, and therefore which row format the producers must emit into cb.h / cb.f
 static bool mlp_is_fused(const th_ctx* c, int V) { return c->mlp_mode == 1 && c->fused_ready && V <= 3; }
 static int mlp_row_format(const th_ctx* c, int V) { return mlp_is_fused(c, V) ? TH_ROWS_SPLIT : TH_ROWS_F32; }      // K5
-static int dparf_row_format(const th_ctx* c, int V) { return mlp_is_fused(c, V) ? TH_ROWS_FOLDED : TH_ROWS_F32; }   // K4
+static bool tok_gather(const th_ctx* c, int V);
+static int dparf_row_format(const th_ctx* c, int V) {                                                                  // K4
+    return mlp_is_fused(c, V) ? (tok_gather(c, V) ? TH_ROWS_NBR : TH_ROWS_FOLDED) : TH_ROWS_F32;
+}
 // Fused path: per-frame table T' = tokens fc_0[:, :192]^T ([V*N_c, 256] fp32, one small GEMM) that K4 blends instead
 // of the raw tokens (fc_0 is linear; see the token branch of the fused kernel).  Returns the table K4 must read.
+// TH_ROWS_NBR (default on the fused path, TH_TOK_GATHER=0 switches back to TH_ROWS_FOLDED): K4 hands the fused kernel the
+// 7 neighbours + weights of every sample and the kernel blends the rows of T' itself, from the split form of the table
+// (th_tok_split, in place; the scale word sits behind the table: TPRIME_FLOATS).
+#define TH_MAX_CLUSTERS 4096     // T' scratch is sized for this many tokens per view
+#define TPRIME_FLOATS(V) ((size_t)(V) * TH_MAX_CLUSTERS * 256 + 64)
+static bool tok_gather(const th_ctx* c, int V) {
+    static const bool off = getenv("TH_TOK_GATHER") != nullptr && getenv("TH_TOK_GATHER")[0] == '0';
+    return mlp_is_fused(c, V) && !off;
+}
+static float* tprime_scale(float* tprime, int V) { return tprime + (size_t)V * TH_MAX_CLUSTERS * 256; }
 static int token_table(th_ctx* c, const float* tokens, int V, int nc, float* tprime, const float** table, hipStream_t s) {
     *table = tokens;
     if (!mlp_is_fused(c, V)) return 0;
     TH_TRY(th_gemm(tokens, 192, V * nc, c->mlp.fc_0tok, TH_ACT_NONE, tprime, 256, s));
+    if (tok_gather(c, V)) TH_TRY(th_tok_split(tprime, V * nc, tprime_scale(tprime, V), c->range_dev, s));
     *table = tprime;
     return 0;
 }
@@ -621,11 +635,14 @@ static int token_table(th_ctx* c, const float* tokens, int V, int nc, float* tpr
 // addressed as vd_sel[p] / vd_div (vd_sel == nullptr: row p); the fused kernel reads the table in place, the
 // per-layer form wants them gathered into cb.vdc first.
 static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, const float* vd_table,
-                        const int32_t* vd_sel, int vd_div, int rgb_all, hipStream_t s) {
+                        const int32_t* vd_sel, int vd_div, int rgb_all, hipStream_t s, float* tprime = nullptr, int nc = 0) {
     TH_REQUIRE(c->mlp.ready, "MLP weights not set (th_set_mlp_weights)");
-    if (mlp_is_fused(c, V))
+    if (mlp_is_fused(c, V)) {
+        const bool nbr = tok_gather(c, V);
+        TH_REQUIRE(!nbr || tprime != nullptr, "the neighbour-record path needs the split token table");
         return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.pe, cb.f, f_ld, vd_table, vd_sel, vd_div, rgb_all,
-                                    cb.raw_c, c->range_dev, s);
+                                    cb.raw_c, c->range_dev, s, nbr ? tprime : nullptr, nbr ? tprime_scale(tprime, V) : nullptr, nc);
+    }
     const float* vd = vd_table;
     if (vd_sel != nullptr || vd_table != cb.vdc) {
         TH_TRY(th_gather_rows_launch(vd_table, 27, vd_sel, vd_div, m, cb.vdc, s));
@@ -634,11 +651,10 @@ static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, 
     return th_mlp_forward(c->mlp, V, m, cb.h, cb.f, f_ld, vd, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s);
 }
 
-#define TH_MAX_CLUSTERS 4096     // T' scratch of th_network_forward is sized for this many tokens per view
 size_t th_network_workspace_bytes(int V, int P) {
     int CH = P < TH_CHUNK ? (P > 0 ? P : 1) : TH_CHUNK;
     return chunk_bytes(V, CH) + th_align((size_t)P * 4) + th_compact_ws(P) + th_align(64) +
-           th_align((size_t)V * TH_MAX_CLUSTERS * 256 * 4);
+           th_align(TPRIME_FLOATS(V) * 4);
 }
 
 int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir, const float* pts_smpl,
@@ -653,7 +669,7 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
     ChunkBufs cb;
     TH_TRY(chunk_carve(ar, V, CH, &cb));
     TH_REQUIRE(nc <= TH_MAX_CLUSTERS, "too many token clusters");
-    float* tprime = ar.take<float>((size_t)V * TH_MAX_CLUSTERS * 256);
+    float* tprime = ar.take<float>(TPRIME_FLOATS(V));
     TH_REQUIRE(tprime != nullptr, "workspace too small");
     const float* table = nullptr;
     TH_TRY(token_table(c, tokens, V, nc, tprime, &table, s));
@@ -679,8 +695,8 @@ int th_network_forward(th_ctx* c, const float* pixel_feat, const float* viewdir,
                                dparf_row_format(c, V), nullptr, s));
         if (idx) TH_TRY(th_gather_chan_major_launch(pixel_feat, V, 384, P, sel, m, cb.f, fmt, s, c->range_dev));
         else TH_TRY(th_gather_chan_major_launch(pixel_feat + o, V, 384, P, nullptr, m, cb.f, fmt, s, c->range_dev));
-        if (idx) TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir, sel, 1, 0, s));
-        else TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir + 27LL * o, nullptr, 1, 1, s));
+        if (idx) TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir, sel, 1, 0, s, tprime, nc));
+        else TH_TRY(mlp_dispatch(c, V, m, cb, 384, viewdir + 27LL * o, nullptr, 1, 1, s, tprime, nc));
         if (idx) TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, 0, raw_out, s));
         else TH_TRY(th_scatter_raw_launch(cb.raw_c, nullptr, m, 1, raw_out + 4LL * o, s));
     }
@@ -704,7 +720,7 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
     int CH = P < TH_CHUNK ? (int)(P > 0 ? P : 1) : TH_CHUNK;
     return th_align((size_t)P) + th_align((size_t)R * 4) + th_hull_ws(f->n_verts) + th_compact_ws(P) +
            th_align((size_t)P * 4) + th_align(64) + th_align((size_t)R * 27 * 4) + th_align((size_t)P * 16) +
-           th_align((size_t)f->V * TH_MAX_CLUSTERS * 256 * 4) + th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1) +
+           th_align(TPRIME_FLOATS(f->V) * 4) + th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1) +
            chunk_bytes(f->V, CH);
 }
 
@@ -731,7 +747,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     int32_t* info = ar.take<int32_t>(16);
     float* vd_all = ar.take<float>((size_t)R * 27);
     float* raw = ar.take<float>((size_t)P * 4);
-    float* tprime = ar.take<float>((size_t)V * TH_MAX_CLUSTERS * 256);
+    float* tprime = ar.take<float>(TPRIME_FLOATS(V));
     const size_t gws_b = th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1);
     void* gws = ar.take<char>(gws_b);
     int CH = P < TH_CHUNK ? (int)P : TH_CHUNK;
@@ -789,23 +805,25 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     for (int o = 0; o < n; o += CH) {
         int m = (n - o) < CH ? (n - o) : CH;
         const int32_t* sel = idx + o;
-        {
-            ProfScope ps1(pf, TH_PROF_DPARF, s);
-            TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, sel, m, f->centres, f->rot, table, V,
-                                   f->n_clusters, 0.5f, cb.h, cb.pe, dparf_row_format(c, V), use_grid ? gws : nullptr, s));
-        }
+        // (K5 first: K4's small output -- records, tile headers, positional encodings, 0.3 KB per sample -- is then the
+        // last thing written before the fused kernel reads it at the start of every tile: MALL instead of HBM)
         {
             ProfScope ps2(pf, TH_PROF_GATHER, s);
             TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, sel, m, f->cams,
                                        f->scale_xy, cb.f, f_ld, fmt, s, c->range_dev));
         }
         {
+            ProfScope ps1(pf, TH_PROF_DPARF, s);
+            TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, sel, m, f->centres, f->rot, table, V,
+                                   f->n_clusters, 0.5f, cb.h, cb.pe, dparf_row_format(c, V), use_grid ? gws : nullptr, s));
+        }
+        {
             ProfScope ps3(pf, TH_PROF_MLP, s);
             // ray mode: the [R,27] embedding table is indexed sample -> ray (sel / S); mesh mode: zero rows (cb.vdc)
-            if (ray_mode) TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, vd_all, sel, S, unmasked, s));
+            if (ray_mode) TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, vd_all, sel, S, unmasked, s, tprime, f->n_clusters));
             // (the sigma grid never looks at colour: skip the RGB branch, which the reference evaluates and drops,
             // if_mesh_renderer.py:84-99)
-            else TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, cb.vdc, nullptr, 1, 2, s));
+            else TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, cb.vdc, nullptr, 1, 2, s, tprime, f->n_clusters));
         }
         ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));

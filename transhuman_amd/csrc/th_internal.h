@@ -251,7 +251,10 @@ struct FusedParams {
     const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
     // token branch, written by K4 in TH_ROWS_FOLDED form: the neighbour blend of T' = tokens W_tok^T (fp32) and
     // the blended positional encoding (split-f16: 64 hi halves then 64 lo halves per sample)
-    const float* stok;      // [P][V][256]
+    const float* stok;      // [P][V][256]; with tsplit != nullptr (TH_ROWS_NBR): [P][16] neighbour records instead
+    const _Float16* tsplit; // nullptr, or the per-frame table T' as split rows [V][t_nc][256 hi | 256 lo] (th_tok_split)
+    const float* t_inv;     // device word: 1 / (power-of-two scale of tsplit)
+    int t_nc;
     const _Float16* pe;     // [P][2][64]
     // split-f16 rows written by K5 (TH_ROWS_SPLIT): K hi halves then K lo halves per (sample, view)
     const _Float16* f;  // [P][V][2][384] (full) or [P][V][2][272] (compact: 256 latent | r g b | 0...)
@@ -273,9 +276,16 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
 // stok / pe: TH_ROWS_FOLDED output of K4; f: TH_ROWS_SPLIT rows (4 * K bytes per (sample, view))
 // vd rows are addressed through vd_sel / vd_div (the per-RAY embedding table is read in place: sample index / S),
 // or directly by the compacted sample index when vd_sel == nullptr
+// tsplit / t_inv / t_nc: nullptr / nullptr / 0, or the split token table of th_tok_split -- `stok` then holds K4's
+// TH_ROWS_NBR neighbour records
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all,
-                         float* raw_c, unsigned int* range, hipStream_t s);
+                         float* raw_c, unsigned int* range, hipStream_t s, const void* tsplit = nullptr,
+                         const float* t_inv = nullptr, int t_nc = 0);
+// In place: the per-frame table T' [rows][256] fp32 -> [rows][256 hi | 256 lo] fp16 halves of T' * 2^k, k chosen on the
+// device so that max |T'| lands in [2^12, 2^13) (lo halves stay normal numbers); sc[0] = 2^-k, sc[1] scratch (the
+// maximum's bits).  A non-finite table raises the guard's TH_RANGE_VIT slot (its producer is the ViT).
+int th_tok_split(float* tprime, int rows, float* sc, unsigned int* range, hipStream_t s);
 
 struct th_ctx {
     void* fused_store = nullptr;
@@ -348,7 +358,11 @@ int th_nchw_to_nhwc_launch(const float* src, int V, int C, int H, int W, float* 
 //   TH_ROWS_FOLDED (K4 only) the token table handed to K4 is T' = tokens fc_0[:, :192]^T (256 wide): `out` gets the
 //                  fp32 neighbour blend of T' rows [P][V][256], `pe_out` the blended 63-wide positional encoding
 //                  as one split-f16 row of 64 + 64 halves per SAMPLE (fused kernel, see its token branch)
-enum { TH_ROWS_F32 = 0, TH_ROWS_SPLIT = 1, TH_ROWS_FOLDED = 2 };
+//   TH_ROWS_NBR    (K4 only) no rows at all: `out` gets one 64-byte neighbour record per sample -- int idx[7], 0,
+//                  float w[7], 0 (the 7 nearest token centres in (distance, index) order and their softmax weights) --
+//                  and `pe_out` the split-f16 positional encoding like TH_ROWS_FOLDED.  The fused kernel then forms the
+//                  blend of T' rows itself, on the matrix pipe, from the L2-resident table (k_mlp_fused_kernel.h)
+enum { TH_ROWS_F32 = 0, TH_ROWS_SPLIT = 1, TH_ROWS_FOLDED = 2, TH_ROWS_NBR = 3 };
 // k_dparf.hip
 int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh, const float* Th,
                     const int32_t* sel, int P, const float* centres, const float* rot, const float* tokens,
