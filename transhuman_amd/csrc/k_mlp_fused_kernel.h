@@ -695,11 +695,15 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                     for (int i = tid; i < 2 * 32 * STRVD / 16; i += 256) reinterpret_cast<uint4*>(wsp_hi)[i] = make_uint4(0u, 0u, 0u, 0u);
                 }
                 // T' rows of the pass (only the nU real ones: the k-padding of the last block re-reads row nU - 1 below)
-                for (int i = wv; i < V * nU; i += 4) {
-                    const int vw = i / nU, u = i - vw * nU;
+                // (slot-major: the centre of a slot is looked up once and serves its V rows; no division, scalar addresses --
+                // as a flat loop over (view, slot) the address arithmetic bounded this loop, like stage_glds once did)
+                for (int u = wv; u < nU; u += 4) {
                     const int cu = slot_centre(u0 + u);
-                    const char* g = reinterpret_cast<const char*>(P.tsplit) + ((long long)vw * P.t_nc + cu) * 1024 + lane * 16;
-                    __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)(abuf + (vw * 32 + u) * STOK_STR), 16, 0, 0);
+                    const char* g = reinterpret_cast<const char*>(P.tsplit) + (long long)cu * 1024 + lane * 16;
+#pragma unroll
+                    for (int vw = 0; vw < V; ++vw)
+                        __builtin_amdgcn_global_load_lds((fm_gptr)(g + (long long)vw * P.t_nc * 1024),
+                                                         (fm_lptr)(abuf + (vw * 32 + u) * STOK_STR), 16, 0, 0);
                 }
                 FM_SYNCL();                                          // W is cleared (and the pe rows are in place)
                 if (slot >= u0 && slot < u0 + 32) {
