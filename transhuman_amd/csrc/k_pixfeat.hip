@@ -49,7 +49,11 @@ __device__ __forceinline__ void pg_store4(float* __restrict__ orow, int ldo, int
 #ifndef PG_EXP_NOSTORE      // timing experiments only
         *reinterpret_cast<pg_h4*>(oh + 4 * c4) = hv;
 #ifndef PG_EXP_NOLO
+#ifdef PG_EXP_LOSAME     // timing experiment only (wrong results): second store instruction, same bytes
+        *reinterpret_cast<volatile pg_h4*>(oh + 4 * c4) = lv;
+#else
         *reinterpret_cast<pg_h4*>(oh + ldo + 4 * c4) = lv;
+#endif
 #endif
 #else
         if (hv[0] == (_Float16)123.f && lv[1] == (_Float16)77.f) *reinterpret_cast<pg_h4*>(oh) = hv;
