@@ -631,6 +631,19 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         if (P.vd_sel != nullptr && P.rgb_all != 2 && c < 27 && row < npts) x = P.vd_sel[pbase + row];
         vsel[q] = x;
     }
+    float vdv[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_vd = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = tid + 256 * q, row = i >> 5, c = i & 31;
+            float x = 0.f;
+            if (P.rgb_all != 2 && c < 27 && row < npts) {
+                const long long vr = P.vd_sel ? (long long)(vsel[q] / P.vd_div) : (long long)(pbase + row);
+                x = P.vd[vr * 27 + c];
+            }
+            vdv[q] = x;
+        }
+    };
     f32x16 acc2[2][V];
     {
         constexpr int STOK_STR = 1040;
@@ -679,6 +692,10 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             *reinterpret_cast<uint4*>(pe_hi + prow * STR64 + 16 * pc) = pe_h;
             *reinterpret_cast<uint4*>(pe_lo + prow * STR64 + 16 * pc) = pe_l;
             const int U = __builtin_amdgcn_readfirstlane((int)h0);          // (hdr[0])
+            // the view-direction rows (their indices arrived in front of the header): one more HBM round trip that runs
+            // beside the T' rows instead of in front of the pixel-feature staging
+            load_vd();
+            FM_SB();
             auto slot_centre = [&](int u) {                                  // wave-uniform u
                 const int d = (2 + u) >> 1;
                 const unsigned src = d < 64 ? (unsigned)__builtin_amdgcn_readlane((int)h0, d) : (unsigned)__builtin_amdgcn_readlane((int)h1, d - 64);
@@ -862,17 +879,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     FM_SYNCL();
 
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
-    float vdv[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = tid + 256 * q, row = i >> 5, c = i & 31;
-        float x = 0.f;
-        if (P.rgb_all != 2 && c < 27 && row < npts) {
-            const long long vr = P.vd_sel ? (long long)(vsel[q] / P.vd_div) : (long long)(pbase + row);
-            x = P.vd[vr * 27 + c];
-        }
-        vdv[q] = x;
-    }
+    if (P.tsplit == nullptr) load_vd();      // (TH_ROWS_NBR: requested in the token branch, behind the tile header)
     FM_SB();
     stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
 #ifdef FM_STAMPS
