@@ -96,7 +96,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
 }
 
 // ---- global -> LDS staging by LDS-DMA ------------------------------------------------------------------
-// Source rows (one per (sample, view)) hold KROW hi halves followed by KROW lo halves.  Columns
+// Source rows (one per (sample, view)) hold KROW / 8 groups of [8 hi halves | 8 lo halves].  Columns
 // [coff, coff + KC) of both planes are copied into the LDS images hi/lo (row = view*32 + sample, stride STR
 // bytes).  global_load_lds_dwordx4 writes LDS at a wave-uniform base + lane*16, reading a per-lane global
 // address: every wave fills 1 KiB slices of the plane image and each lane derives the (row, column) its
@@ -120,17 +120,19 @@ __device__ __forceinline__ void stage_glds(const _Float16* __restrict__ src, int
     const int wv = __builtin_amdgcn_readfirstlane(wave);
     const int q0 = wv * 64 + lane;
     int row = q0 / SL, slot = q0 - row * SL;
-    const char* gbase = reinterpret_cast<const char*>(src) + 2 * coff;
+    // (source rows are groups of 8 channels, 32 bytes = [8 hi halves | 8 lo halves]: k_pixfeat.hip pg_store8)
+    static_assert(KC % 8 == 0 && KROW % 8 == 0, "rows are made of 8-channel groups");
+    const char* gbase = reinterpret_cast<const char*>(src) + 4 * coff;
 #pragma unroll 1
     for (int c = wv; c < NCH; c += 4) {
         if (c * 64 + lane < NS) {
             int p = row & 31;
             const int vw = row >> 5;
             p = p < npts ? p : npts - 1;
-            const int col = slot < DS ? slot * 16 : 0;
+            const int col = slot < DS ? slot * 32 : 0;
             const char* g = gbase + (long long)((pbase + p) * V + vw) * (4 * KROW) + col;
             __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)(hi + c * 1024), 16, 0, 0);   // (sc0 / nt / sc1 policy bits: no measurable effect)
-            __builtin_amdgcn_global_load_lds((fm_gptr)(g + 2 * KROW), (fm_lptr)(lo + c * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((fm_gptr)(g + 16), (fm_lptr)(lo + c * 1024), 16, 0, 0);
         }
         row += DR;
         slot += DSL;

@@ -13,6 +13,10 @@
 // Bound: L2/HBM gather, 4 * 4C B per (sample, view) in, 4*ldo B out.
 #include "th_internal.h"
 
+#define PG_G 16
+#ifndef PG_B
+#define PG_B 4      // rows per batch: 4 PG_B corner loads in flight per wave
+#endif
 typedef _Float16 pg_h4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void pg_split(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
@@ -31,6 +35,51 @@ __device__ __forceinline__ void pg_range_acc(unsigned& rm, unsigned hi2) {
 __device__ __forceinline__ void pg_range_commit(unsigned* __restrict__ table, unsigned rm) {
     const unsigned m = max(rm & 0xffffu, rm >> 16);
     if (table != nullptr && m > table[TH_RANGE_F]) atomicMax(table + TH_RANGE_F, m);
+}
+
+// SPLIT rows (TH_ROWS_SPLIT): groups of 8 channels, each 32 bytes = [8 hi halves | 8 lo halves].  A 16-byte piece is
+// then one plane's 8 consecutive halves -- what the fused kernel's LDS-DMA staging moves and its MFMA fragments read --
+// and a lane that owns 8 channels writes its 32 bytes with two full-width store instructions per ROW PAIR.  (Two 512-byte
+// plane stores per row were what bounded this kernel: 2.67 ms per frame, 2.03 ms without the second store, see DESIGN.md.)
+template <bool SPLIT>
+__device__ __forceinline__ void pg_store8(float* __restrict__ orow, int g, float4 a, float4 bq, unsigned& rm) {
+    if (!SPLIT) {
+        reinterpret_cast<float4*>(orow)[2 * g] = a;
+        reinterpret_cast<float4*>(orow)[2 * g + 1] = bq;
+    } else {
+        const float v[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
+        typedef _Float16 pg_h8 __attribute__((ext_vector_type(8)));
+        pg_h8 hv, lv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            _Float16 x, y;
+            pg_split(v[e], x, y);
+            hv[e] = x;
+            lv[e] = y;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pg_range_acc(rm, reinterpret_cast<const unsigned*>(&hv)[e]);
+        _Float16* og = reinterpret_cast<_Float16*>(orow) + 16 * g;
+#ifndef PG_EXP_NOSTORE      // timing experiments only
+        *reinterpret_cast<pg_h8*>(og) = hv;
+#ifndef PG_EXP_NOLO
+        *reinterpret_cast<pg_h8*>(og + 8) = lv;
+#endif
+#else
+        if (hv[0] == (_Float16)123.f && lv[1] == (_Float16)77.f) *reinterpret_cast<pg_h8*>(og) = hv;
+#endif
+    }
+}
+// bilinear blend of four corner texels (grid_sample's term order; fused multiply-adds: the reference kernel is
+// compiled with FMA contraction too, and the parity bar for this stage is 2e-5)
+__device__ __forceinline__ float4 pg_blend(float4 a, float4 bb, float4 cc, float4 d, float w00, float w01, float w10,
+                                           float w11) {
+    float4 r;
+    r.x = fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(bb.x, w01, a.x * w00)));
+    r.y = fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(bb.y, w01, a.y * w00)));
+    r.z = fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(bb.z, w01, a.z * w00)));
+    r.w = fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(bb.w, w01, a.w * w00)));
+    return r;
 }
 
 template <bool SPLIT>
@@ -60,33 +109,11 @@ __device__ __forceinline__ void pg_store4(float* __restrict__ orow, int ldo, int
 #endif
     }
 }
-// bilinear blend of four corner texels (grid_sample's term order; fused multiply-adds: the reference kernel is
-// compiled with FMA contraction too, and the parity bar for this stage is 2e-5)
-__device__ __forceinline__ float4 pg_blend(float4 a, float4 bb, float4 cc, float4 d, float w00, float w01, float w10,
-                                           float w11) {
-    float4 r;
-    r.x = fmaf(d.x, w11, fmaf(cc.x, w10, fmaf(bb.x, w01, a.x * w00)));
-    r.y = fmaf(d.y, w11, fmaf(cc.y, w10, fmaf(bb.y, w01, a.y * w00)));
-    r.z = fmaf(d.z, w11, fmaf(cc.z, w10, fmaf(bb.z, w01, a.z * w00)));
-    r.w = fmaf(d.w, w11, fmaf(cc.w, w10, fmaf(bb.w, w01, a.w * w00)));
-    return r;
-}
 
-// One wave = PG_G consecutive samples of ONE view (their projections are neighbours in that view's map).
-//  phase 1: lane i < PG_G projects sample i and derives its four corner indices + weights -- the per-row setup
-//           (two divisions, floor/clamp, ~140 instructions) runs once per PG_G rows instead of once per row in
-//           every lane (PMC: the row-per-wave form spent 78 % of its time in VALU issue, 325 instructions/row);
-//  phase 2: rows in batches of 4: the corner indices / weights come back as wave-uniform scalars
-//           (v_readlane), so the corner addresses are scalar arithmetic and the 16 corner loads of a batch
-//           (4 KiB each row) are all issued before the first blend.  Lanes span channels (float4 per lane:
-//           64 lanes = the 256 latent channels); columns >= 256 (compact map: r g b 0 + zero tail of the row)
-//           are produced for the 4 rows of a batch at once by lanes 0..15.
-#define PG_G 16
-#ifndef PG_B
-#define PG_B 4      // rows per batch: 4 PG_B corner loads in flight per wave
-#endif
+// fp32 rows (TH_ROWS_F32: the per-layer MLP path, paint_neural_human): one row per wave pass, lanes = float4 columns,
+// any row stride that is a multiple of 4
 template <bool SPLIT>
-__global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict__ map, int V, int C, int H, int W,
+__global__ __launch_bounds__(256) void pixgather_f32_kernel(const float* __restrict__ map, int V, int C, int H, int W,
                                                         const float* __restrict__ pts_world, ThPointSrc ps,
                                                         const int32_t* __restrict__ sel, int P,
                                                         const float* __restrict__ cams,
@@ -189,11 +216,130 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
     if (SPLIT) pg_range_commit(range, rm);
 }
 
+
+// One wave = PG_G consecutive samples of ONE view (their projections are neighbours in that view's map).
+//  phase 1: lane i < PG_G projects sample i and derives its four corner indices + weights -- the per-row setup
+//           (two divisions, floor/clamp, ~140 instructions) runs once per PG_G rows instead of once per row in
+//           every lane (PMC: the row-per-wave form spent 78 % of its time in VALU issue, 325 instructions/row);
+//  phase 2: rows in batches of 4: the corner indices / weights come back as wave-uniform scalars
+//           (v_readlane), so the corner addresses are scalar arithmetic and the 16 corner loads of a batch
+//           (4 KiB each row) are all issued before the first blend.  Lanes span channels (float4 per lane:
+//           64 lanes = the 256 latent channels); columns >= 256 (compact map: r g b 0 + zero tail of the row)
+//           are produced for the 4 rows of a batch at once by lanes 0..15.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict__ map, int V, int C, int H, int W,
+                                                        const float* __restrict__ pts_world, ThPointSrc ps,
+                                                        const int32_t* __restrict__ sel, int P,
+                                                        const float* __restrict__ cams,
+                                                        const float* __restrict__ scale, float* __restrict__ out,
+                                                        int ldo, unsigned* __restrict__ range) {
+    const int lane = threadIdx.x & 63;
+    unsigned rm = 0u;
+    // XCD-aware remap (speed only): workgroup b runs on XCD b % 8, each XCD has its own L2: give every XCD a
+    // CONTIGUOUS range of groups: logical block = (b % 8) * ceil(nb / 8) + b / 8 (bijective incl. ragged tails
+    // via the bounds check below).
+    const long long nb8 = ((long long)gridDim.x + 7) / 8;
+    const long long lb = (long long)(blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
+    const long long grp = lb * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (sample group, view): scalar
+    const long long ngrp = (long long)((P + PG_G - 1) / PG_G) * V;
+    if (grp >= ngrp) return;
+    const int v = (int)(grp % V);
+    const int p0 = (int)(grp / V) * PG_G;
+    const int nrow = min(PG_G, P - p0);
+    const float* m = map + (long long)v * H * W * C;
+    // split layout (C == 256): the r, g, b, 0 texels live in a [V,H,W,4] plane behind the latents; they are output
+    // column 64 (float4) of a row exactly like channels 256..259 of the interleaved 260-channel map
+    const float4* rgbp = C == 256 ? reinterpret_cast<const float4*>(map + (long long)V * H * W * 256) + (long long)v * H * W : nullptr;
+    const int C4 = C / 4, L4 = ldo / 4;
+
+    // ---- phase 1 ----
+    Bilin b;
+    {
+        const int p = p0 + min(lane, nrow - 1);
+        long long s = sel ? sel[p] : p;
+        float x, y, z;
+        if (pts_world) { x = pts_world[3 * s]; y = pts_world[3 * s + 1]; z = pts_world[3 * s + 2]; }
+        else th_get_point(ps, s, x, y, z);
+        float uu, vv;
+        th_project(cams + 21 * v, x, y, z, uu, vv);
+        b = th_bilinear_setup(uu, vv, scale[0], scale[1], H, W);
+    }
+    // ---- phase 2 ----
+    // Rows in batches of PG_B = 2 row pairs.  Lanes 0..31 work on the first row of a pair, lanes 32..63 on the second;
+    // lane & 31 = channel group (8 channels = two float4 per corner): the 16 corner loads of a batch are all requested
+    // before the first blend, the corner indices / weights of the two rows come back as scalars (v_readlane) and are
+    // selected per half-wave.
+    const int half = lane >> 5, gl = lane & 31;
+    const int G = ldo / 8, TG = G - 32;                 // 8-channel groups per output row; groups beyond the 256 latents
+    for (int r0 = 0; r0 < nrow; r0 += PG_B) {
+        float4 q[PG_B / 2][4][2];
+        float w[PG_B / 2][4];
+#pragma unroll
+        for (int jj = 0; jj < PG_B / 2; ++jj) {
+            const int iA = min(r0 + 2 * jj, nrow - 1), iB = min(r0 + 2 * jj + 1, nrow - 1);   // ragged tail: duplicate loads, no store
+            const int a00 = __builtin_amdgcn_readlane(b.i00, iA), a01 = __builtin_amdgcn_readlane(b.i01, iA);
+            const int a10 = __builtin_amdgcn_readlane(b.i10, iA), a11 = __builtin_amdgcn_readlane(b.i11, iA);
+            const int b00 = __builtin_amdgcn_readlane(b.i00, iB), b01 = __builtin_amdgcn_readlane(b.i01, iB);
+            const int b10 = __builtin_amdgcn_readlane(b.i10, iB), b11 = __builtin_amdgcn_readlane(b.i11, iB);
+            const float* wsrc[4] = {&b.w00, &b.w01, &b.w10, &b.w11};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float wa = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, *wsrc[c]), iA));
+                const float wb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, *wsrc[c]), iB));
+                w[jj][c] = half ? wb : wa;
+            }
+            const int ic[4] = {half ? b00 : a00, half ? b01 : a01, half ? b10 : a10, half ? b11 : a11};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4* src = reinterpret_cast<const float4*>(m + (long long)ic[c] * C) + 2 * gl;
+                q[jj][c][0] = src[0];
+                q[jj][c][1] = src[1];
+            }
+        }
+        // groups beyond the latents (compact rows: r g b 0 | zeros; full rows: the 128 colour-lift channels) for the rows of
+        // the batch at once: lane = row * TG + group
+        if (TG > 0) {
+            const int j = min(lane / TG, PG_B - 1), t = lane % TG, i = min(r0 + j, nrow - 1);
+            // this lane's row parameters live in lane i (phase 1): fetch them across lanes (every lane takes part: a
+            // ds_bpermute reads nothing useful from a lane that is masked off)
+            const int i00 = __shfl(b.i00, i), i01 = __shfl(b.i01, i), i10 = __shfl(b.i10, i), i11 = __shfl(b.i11, i);
+            const float w00 = __shfl(b.w00, i), w01 = __shfl(b.w01, i), w10 = __shfl(b.w10, i), w11 = __shfl(b.w11, i);
+            if (lane < PG_B * TG) {
+            float4 r2[2];
+#pragma unroll
+            for (int hq = 0; hq < 2; ++hq) {
+                const int c4 = 2 * (32 + t) + hq;
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c4 < C4)
+                    r = pg_blend(reinterpret_cast<const float4*>(m + (long long)i00 * C)[c4],
+                                 reinterpret_cast<const float4*>(m + (long long)i01 * C)[c4],
+                                 reinterpret_cast<const float4*>(m + (long long)i10 * C)[c4],
+                                 reinterpret_cast<const float4*>(m + (long long)i11 * C)[c4], w00, w01, w10, w11);
+                else if (rgbp != nullptr && c4 == 64)
+                    r = pg_blend(rgbp[i00], rgbp[i01], rgbp[i10], rgbp[i11], w00, w01, w10, w11);
+                r2[hq] = r;
+            }
+            if (r0 + j < nrow) pg_store8<SPLIT>(out + ((long long)(p0 + r0 + j) * V + v) * ldo, 32 + t, r2[0], r2[1], rm);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < PG_B / 2; ++jj) {
+            const int i = r0 + 2 * jj + half;
+            const float4 ra = pg_blend(q[jj][0][0], q[jj][1][0], q[jj][2][0], q[jj][3][0], w[jj][0], w[jj][1], w[jj][2], w[jj][3]);
+            const float4 rb = pg_blend(q[jj][0][1], q[jj][1][1], q[jj][2][1], q[jj][3][1], w[jj][0], w[jj][1], w[jj][2], w[jj][3]);
+            if (i < nrow) pg_store8<SPLIT>(out + ((long long)(p0 + i) * V + v) * ldo, gl, ra, rb, rm);
+        }
+    }
+    if (SPLIT) pg_range_commit(range, rm);
+}
+
 int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world, const ThPointSrc* ps,
                         const int32_t* sel, int P, const float* cams, const float* scale, float* out, int ldo,
                         int fmt, hipStream_t s, unsigned int* range) {
     if (P <= 0) return 0;
     TH_REQUIRE((C & 3) == 0 && (ldo & 3) == 0 && ldo >= C, "channel count / row stride must be multiples of 4, ldo >= C");
+    TH_REQUIRE(fmt != TH_ROWS_SPLIT || ((ldo & 7) == 0 && C >= 256 && ldo <= 256 + 8 * (64 / PG_B)),
+               "split rows: >= 256 map channels, row stride a multiple of 8 with at most 16 groups beyond the latents");
     ThPointSrc src = ps ? *ps : ThPointSrc{};
     const long long groups = (long long)th_cdiv(P, PG_G) * V;
     const int nblk = 8 * th_cdiv(th_cdiv(groups, 4), 8);     // multiple of 8 so the XCD remap is onto
@@ -201,7 +347,7 @@ int th_pixgather_launch(const float* map, int V, int C, int H, int W, const floa
         hipLaunchKernelGGL(pixgather_kernel<true>, dim3(nblk), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel, P,
                            cams, scale, out, ldo, range);
     else
-        hipLaunchKernelGGL(pixgather_kernel<false>, dim3(nblk), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel, P,
+        hipLaunchKernelGGL(pixgather_f32_kernel<false>, dim3(nblk), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel, P,
                            cams, scale, out, ldo, nullptr);
     TH_LAUNCH_CHECK();
     return 0;
@@ -235,8 +381,8 @@ __global__ __launch_bounds__(256) void gather_chan_major_kernel(const float* __r
                 _Float16* oh = reinterpret_cast<_Float16*>(out + ((long long)pp * V + v) * C);
                 _Float16 x, y;
                 pg_split(tile[tx][r], x, y);
-                oh[c] = x;
-                oh[C + c] = y;
+                oh[(c >> 3) * 16 + (c & 7)] = x;            // [8 hi | 8 lo] groups (see pg_store8)
+                oh[(c >> 3) * 16 + 8 + (c & 7)] = y;
                 pg_range_acc(rm, (unsigned)__builtin_bit_cast(unsigned short, x));
             }
         }

@@ -256,7 +256,7 @@ struct FusedParams {
     const float* t_inv;     // device word: 1 / (power-of-two scale of tsplit)
     int t_nc;
     const _Float16* pe;     // [P][2][64]
-    // split-f16 rows written by K5 (TH_ROWS_SPLIT): K hi halves then K lo halves per (sample, view)
+    // split-f16 rows written by K5 (TH_ROWS_SPLIT): K / 8 groups of [8 hi | 8 lo] halves per (sample, view)
     const _Float16* f;  // [P][V][2][384] (full) or [P][V][2][272] (compact: 256 latent | r g b | 0...)
     const float* vd;    // view-direction rows [.][27]: row of compacted sample p = vd_sel ? vd_sel[p] / vd_div : p
     const int32_t* vd_sel;
@@ -353,8 +353,9 @@ int th_nchw_to_nhwc_launch(const float* src, int V, int C, int H, int W, float* 
 
 // Row format of the per-(sample, view) operand rows h / f handed from the producer kernels to the MLP stage:
 //   TH_ROWS_F32    K fp32 values (layer-by-layer fp32 MFMA path, public th_dparf_encode / th_pixel_gather)
-//   TH_ROWS_SPLIT  K fp16 "hi" halves followed by K fp16 "lo" halves, x = hi + lo to 2^-22 (fused kernel: the
-//                  operand is copied to LDS by LDS-DMA with no conversion pass); same 4K bytes per row
+//   TH_ROWS_SPLIT  K / 8 groups of [8 fp16 "hi" halves | 8 fp16 "lo" halves], x = hi + lo to 2^-22 (fused kernel: the
+//                  operand is copied to LDS by LDS-DMA, 16-byte pieces = one plane's 8 consecutive halves, with no
+//                  conversion pass); same 4K bytes per row
 //   TH_ROWS_FOLDED (K4 only) the token table handed to K4 is T' = tokens fc_0[:, :192]^T (256 wide): `out` gets the
 //                  fp32 neighbour blend of T' rows [P][V][256], `pe_out` the blended 63-wide positional encoding
 //                  as one split-f16 row of 64 + 64 halves per SAMPLE (fused kernel, see its token branch)
