@@ -356,6 +356,8 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
+    if os.environ.get("TH_MAIN_PRIORITY"):       # A/B switch: the shading stream as a high-priority stream (-1)
+        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=int(os.environ["TH_MAIN_PRIORITY"])))
     from transhuman_amd import hip
     from transhuman_amd.networks.renderer.if_clight_renderer import Renderer
     hip.set_mlp_mode(args.mlp_mode)

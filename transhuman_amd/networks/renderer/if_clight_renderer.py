@@ -296,7 +296,8 @@ class Renderer:
         dev = first["ray_o"].device
         side = self._dev.get(("side_stream", str(dev)))
         if side is None:
-            side = self._dev[("side_stream", str(dev))] = torch.cuda.Stream(dev)
+            # TH_SIDE_PRIORITY=-1: high-priority side stream (A/B switch; measured: see DESIGN.md 6)
+            side = self._dev[("side_stream", str(dev))] = torch.cuda.Stream(dev, priority=int(os.environ.get("TH_SIDE_PRIORITY", "0")))
         side.wait_stream(torch.cuda.current_stream(dev))
         queue = collections.deque([front(first, 0, side)])
         queued, more = 1, True
