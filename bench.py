@@ -77,10 +77,10 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
         kernel = "per-point MLP stage (gemm_f32_mfma_kernel x14 + glue kernels), rank 0"
     # HBM bytes per full launch (524288 samples) from the committed PMC passes (profiles/r01_i_pmc_hbm.txt:
     # 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction applied); algorithmic = 524288 * (3 views * (1024 B stok + 2 * 1088 B f) + 256 B pe)
-    traffic = 4.22e9 if mlp_mode == 1 else None
+    traffic = 4.20e9 if mlp_mode == 1 else None
     return {"bound": "mfma", "kernel": kernel, "achieved": achieved / 1e12, "peak": peak / 1e12,
             "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "traffic_note": "HBM bytes per 524288-sample launch, rocprofv3 PMC (profiles/r02_k_pmc_hbm.txt); "
+            "traffic_note": "HBM bytes per 524288-sample launch, rocprofv3 PMC (profiles/r02_m_pmc_hbm.txt); "
                             "algorithmic 3.6e9 (pixel-feature rows twice, positional encodings, neighbour records)",
             "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK,
             "algorithmic_flop_per_step": flops_step, "kernel_ms_per_step": stage_ms,
