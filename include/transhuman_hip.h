@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 3
+#define TH_ABI_VERSION 4
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -91,6 +91,13 @@ int th_set_mlp_weights(th_ctx* ctx, const th_mlp_weights* w, th_stream stream);
  * v_mfma_f32_32x32x16_f16 with fp16 hi/lo operand splitting (3 products, fp32 accumulate: fp32-class
  * accuracy); 0 = one fp32-MFMA GEMM launch per layer (exact fp32 products; also the path for V = 4). */
 int th_set_mlp_mode(th_ctx* ctx, int mode);
+/* K4 -> K6 hand-over of the token branch on the fused path (Network.get_human_representation, cross_transformer.py:151-205,
+ * feeding fc_0, :291-295): 1 (default) = K4 writes, per sample, its 7 nearest token centres (as slots of the per-tile
+ * union) and their softmax weights, and the fused kernel blends the rows of the per-frame table tokens fc_0[:, :192]^T on
+ * the matrix pipe (0.34 KB per sample through HBM); 0 = K4 blends the rows in fp32 and hands them over (3.3 KB per
+ * sample; a ray shard then equals the whole frame bit for bit instead of to fp32 rounding).  Env TH_TOK_GATHER=0 makes
+ * 0 the default of new contexts. */
+int th_set_tok_gather(th_ctx* ctx, int on);
 
 /* Range guard of the fp16 hi/lo split arithmetic (fused MLP kernel, its producer K5, the ResNet-stem convolutions).
  * The reference computes this path in fp32 (cross_transformer.py:291-353 has no autocast); the fused kernel is

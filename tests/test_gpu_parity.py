@@ -376,6 +376,22 @@ def test_render_ray_sharding_equals_full(hip, gpu, net):
     # matrix pipe over the UNION of the tile's neighbour centres (TH_ROWS_NBR), so the position of a sample's seven
     # terms in the accumulation depends on its tile mates: equal to fp32 rounding, not bit for bit)
     assert float((parts2 - full2).abs().max()) < 2e-6
+    # with K4 blending the rows in fp32 (th_set_tok_gather(ctx, 0)) the shards ARE the frame, bit for bit -- and the two
+    # hand-over forms agree to fp32 rounding
+    hip.set_tok_gather(False)
+    try:
+        full3 = r.render_fast(b, frame=frame, small_frame_rays=-1)["rgb_map"][0]
+        parts3 = torch.zeros_like(full3)
+        for rank in range(2):
+            sel = idx[rank::2]
+            bb = dict(b)
+            for k in ("ray_o", "ray_d", "near", "far"):
+                bb[k] = b[k][:, sel]
+            parts3[sel] = r.render_fast(bb, frame=frame, small_frame_rays=-1)["rgb_map"][0]
+    finally:
+        hip.set_tok_gather(True)
+    assert torch.equal(parts3, full3)
+    assert float((full3 - full2).abs().max()) < 2e-6
     # the threshold is a property of the CALL, also when the frame constants are handed in: the default
     # 2400 puts the same shard into the reference's un-masked branch
     bb = dict(b)

@@ -61,6 +61,7 @@ int th_ctx_create(int device, th_ctx** out) {
     th_ctx* c = new th_ctx();
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
+    if (const char* e = getenv("TH_TOK_GATHER")) c->tok_gather = e[0] == '0' ? 0 : 1;
     TH_HIP(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(int32_t), hipHostMallocDefault));
     TH_HIP(hipMalloc((void**)&c->range_dev, TH_RANGE_SLOTS * sizeof(unsigned int)));
     TH_HIP(hipMemset(c->range_dev, 0, TH_RANGE_SLOTS * sizeof(unsigned int)));
@@ -257,6 +258,12 @@ int th_range_last_slot(th_ctx* c) { return c ? c->range_last : -1; }
 int th_set_vit_mode(th_ctx* c, int mode) {
     TH_REQUIRE(c && (mode == 0 || mode == 1), "mode must be 0 (fp32 MFMA GEMMs) or 1 (fp16-split MFMA GEMMs)");
     c->vit_mode = mode;
+    return 0;
+}
+
+int th_set_tok_gather(th_ctx* c, int on) {
+    TH_REQUIRE(c && (on == 0 || on == 1), "th_set_tok_gather: 0 (blended rows from K4) or 1 (neighbour records, blend in the fused kernel)");
+    c->tok_gather = on;
     return 0;
 }
 
@@ -617,10 +624,7 @@ static int dparf_row_format(const th_ctx* c, int V) {                           
 // (th_tok_split, in place; the scale word sits behind the table: TPRIME_FLOATS).
 #define TH_MAX_CLUSTERS 4096     // T' scratch is sized for this many tokens per view
 #define TPRIME_FLOATS(V) ((size_t)(V) * TH_MAX_CLUSTERS * 256 + 64)
-static bool tok_gather(const th_ctx* c, int V) {
-    static const bool off = getenv("TH_TOK_GATHER") != nullptr && getenv("TH_TOK_GATHER")[0] == '0';
-    return mlp_is_fused(c, V) && !off;
-}
+static bool tok_gather(const th_ctx* c, int V) { return mlp_is_fused(c, V) && c->tok_gather == 1; }
 static float* tprime_scale(float* tprime, int V) { return tprime + (size_t)V * TH_MAX_CLUSTERS * 256; }
 static int token_table(th_ctx* c, const float* tokens, int V, int nc, float* tprime, const float** table, hipStream_t s) {
     *table = tokens;

@@ -293,6 +293,7 @@ struct th_ctx {
     bool fused_ready = false;
     int mlp_mode = 1;                 // 1: fused fp16x3-split MFMA kernel, 0: layer-by-layer fp32 MFMA
     int vit_mode = 1;                 // 1: TransHE dense layers on the fp16-split MFMA path (th_gemm_h3), 0: fp32 MFMA
+    int tok_gather = 1;               // 1: TH_ROWS_NBR hand-over (token blend inside the fused kernel), 0: TH_ROWS_FOLDED
     int device = 0;
     void* mlp_store = nullptr;
     void* vit_store = nullptr;

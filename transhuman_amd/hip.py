@@ -62,6 +62,7 @@ SYMBOLS = {
     "th_set_mlp_weights": (C.c_int, [C.c_void_p, C.POINTER(ThMlpWeights), C.c_void_p]),
     "th_set_mlp_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_vit_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "th_set_tok_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "th_range_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_range_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "th_range_last_slot": (C.c_int, [C.c_void_p]),
@@ -164,7 +165,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 3:
+    if lib.th_abi_version() != 4:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -961,6 +962,13 @@ def eval_sigma_grid(net, frame, pts):
         if (conv_fallback or vit_fallback) and getattr(frame, "rebuild", None) is not None:
             frame = frame.rebuild()
     return out, dict(valid_samples=stats[1])
+
+
+def set_tok_gather(on, device=None):
+    """Token-branch hand-over K4 -> K6 on the fused path: True (default) = neighbour records, the fused kernel blends the
+    rows of the per-frame token table on the matrix pipe; False = K4 blends them in fp32 (3.3 KB per sample through HBM;
+    a ray shard then equals the whole frame bit for bit instead of to fp32 rounding)."""
+    _check(load_library().th_set_tok_gather(ctx(device), 1 if on else 0))
 
 
 def set_mlp_mode(mode, device=None):
