@@ -466,3 +466,31 @@ def test_split_map_equals_interleaved_map(hip, gpu, net):
     rows_s = hip.pixel_gather(f_split.map, pts, cams, f_split.scale, row_floats=272)
     rows_i = hip.pixel_gather(f_int.map, pts, cams, f_int.scale, row_floats=272)
     assert torch.equal(rows_s, rows_i) and float(rows_s[..., 260:].abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nc,V,P", [(7, 3, 1000), (64, 1, 2077), (500, 2, 4099), (4096, 3, 3001)])
+def test_token_blend_on_the_matrix_pipe_equals_the_fp32_blend(hip, gpu, net, nc, V, P):
+    """TH_ROWS_NBR (K4 hands over neighbour slots + per-tile unions, the fused kernel blends the rows of the token table with
+    MFMAs) against TH_ROWS_FOLDED (K4 blends them in fp32) on random inputs: scattered points and random centres make the
+    unions of a 32-sample tile as large as they get (nc = 4096: ~200 of 224 distinct centres, seven passes of 32 slots),
+    nc = 7 is the smallest table, P is never a multiple of the tile / K4 workgroup size, every view count of the fused path."""
+    rs = np.random.RandomState(nc + P)
+    centres = torch.from_numpy(rs.uniform(-0.8, 0.8, (nc, 3)).astype(np.float32))
+    q, _ = np.linalg.qr(rs.normal(size=(nc, 3, 3)))
+    rot = torch.from_numpy(q.astype(np.float32).reshape(nc, 9))
+    tok = torch.from_numpy(rs.normal(size=(V, nc, 192)).astype(np.float32))
+    pts = torch.from_numpy(rs.uniform(-0.9, 0.9, (P, 3)).astype(np.float32))
+    pf = torch.from_numpy(rs.normal(size=(V, 384, P)).astype(np.float32))
+    vd = O.view_embed(torch.from_numpy(rs.normal(size=(P, 3)).astype(np.float32)))
+    mask = torch.from_numpy(rs.uniform(size=P) < 0.85)
+    args = (net, pf.to(gpu), vd.to(gpu), pts.to(gpu), centres.to(gpu), rot.to(gpu), tok.to(gpu), mask.to(gpu))
+    raw_nbr = hip.network_forward(*args).cpu()
+    hip.set_tok_gather(False)
+    try:
+        raw_rows = hip.network_forward(*args).cpu()
+    finally:
+        hip.set_tok_gather(True)
+    assert torch.isfinite(raw_nbr).all() and torch.equal(hip.network_forward(*args).cpu(), raw_nbr)
+    scale = max(1.0, float(raw_rows.abs().max()))
+    assert float((raw_nbr - raw_rows).abs().max()) < 1e-5 * scale, (nc, V, P, float((raw_nbr - raw_rows).abs().max()), scale)
