@@ -396,6 +396,16 @@ int th_render_rays(th_ctx* ctx, const th_frame* f, const th_points* rays, float*
  * consumes the one queued for ITS workspace.  Results are identical with or without it. */
 int th_render_prepass(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
                       size_t workspace_bytes, th_stream stream);
+/* Optional second ahead-of-time stage, behind a th_render_prepass of the same workspace / ray arrays: the pixel-aligned
+ * feature rows (get_pixel_aligned_feature, :210-269) and the 7-neighbour records of the human representation
+ * (cross_transformer.py:151-205) of the first chunks of valid samples.  Neither needs the TransHE tokens on the
+ * th_set_tok_gather(ctx, 1) path: `f` must be complete EXCEPT f->tokens, so a caller can run TransHE on another stream
+ * beside this (texture-path-bound) stage instead of in front of it; the following th_render_rays (same workspace, same
+ * map / token centres, complete frame) then only runs the fused MLP for those chunks.  Waits for the prepass's sample
+ * count on the host.  A no-op (return 0) without a matching prepass or off the fused neighbour-record path; results are
+ * identical with or without it. */
+int th_render_pregather(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
+                        size_t workspace_bytes, th_stream stream);
 /* Drops a pending prepass (a caller that abandons the frame it was queued for must not let a later
  * th_render_rays that happens to reuse the same buffers pick it up). */
 int th_render_prepass_cancel(th_ctx* ctx);                          /* all pending prepasses */

@@ -617,6 +617,25 @@ static bool tok_gather(const th_ctx* c, int V);
 static int dparf_row_format(const th_ctx* c, int V) {                                                                  // K4
     return mlp_is_fused(c, V) ? (tok_gather(c, V) ? TH_ROWS_NBR : TH_ROWS_FOLDED) : TH_ROWS_F32;
 }
+// Pre-gather sets (th_render_pregather): K5's rows and K4's records of the first TH_PRE_SETS chunks of a frame, written
+// BEFORE the frame's tokens exist -- neither kernel needs them on the TH_ROWS_NBR path -- so that a caller can run TransHE
+// beside them; th_render_rays then only runs the fused kernel for those chunks.
+#define TH_PRE_SETS 5
+struct PreSet { float *f, *h, *pe; };
+static size_t pre_set_bytes(int V, int CH) {
+    return th_align((size_t)V * CH * 384 * 4) + th_align((size_t)CH * 16 * 4 + ((size_t)CH / 32 + 2) * 128 * 4) +
+           th_align((size_t)CH * 64 * 4);
+}
+static int pre_carve(ThArena& ar, int V, int CH, PreSet* p) {
+    for (int k = 0; k < TH_PRE_SETS; ++k) {
+        p[k].f = ar.take<float>((size_t)V * CH * 384);
+        p[k].h = (float*)ar.take<char>((size_t)CH * 16 * 4 + ((size_t)CH / 32 + 2) * 128 * 4);
+        p[k].pe = ar.take<float>((size_t)CH * 64);
+        TH_REQUIRE(p[k].pe != nullptr, "workspace too small");
+    }
+    return 0;
+}
+
 // Fused path: per-frame table T' = tokens fc_0[:, :192]^T ([V*N_c, 256] fp32, one small GEMM) that K4 blends instead
 // of the raw tokens (fc_0 is linear; see the token branch of the fused kernel).  Returns the table K4 must read.
 // TH_ROWS_NBR (default on the fused path, TH_TOK_GATHER=0 switches back to TH_ROWS_FOLDED): K4 hands the fused kernel the
@@ -725,7 +744,7 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
     return th_align((size_t)P) + th_align((size_t)R * 4) + th_hull_ws(f->n_verts) + th_compact_ws(P) +
            th_align((size_t)P * 4) + th_align(64) + th_align((size_t)R * 27 * 4) + th_align((size_t)P * 16) +
            th_align(TPRIME_FLOATS(f->V) * 4) + th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1) +
-           chunk_bytes(f->V, CH);
+           chunk_bytes(f->V, CH) + TH_PRE_SETS * pre_set_bytes(f->V, CH);
 }
 
 // hull mask -> (small-frame rule) -> compaction -> chunked DPaRF + gather + MLP -> dense raw[P,4]
@@ -758,10 +777,12 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     ChunkBufs cb;
     TH_REQUIRE(raw != nullptr && tprime != nullptr && gws != nullptr, "workspace too small");
     TH_TRY(chunk_carve(ar, V, CH, &cb));
+    PreSet pre[TH_PRE_SETS];
+    TH_TRY(pre_carve(ar, V, CH, pre));
 
     ThProf* pf = prof_of(c);
     int32_t* hp = c->host_pinned;
-    if (prepass == 2) {
+    if (prepass == 2 || prepass == 3) {
         hp = c->host_pinned + 16 + 4 * slot;
         TH_HIP(hipStreamWaitEvent(s, c->prepass[slot].ev, 0));      // the prepass may have run on another stream
         TH_HIP(hipEventSynchronize(c->prepass[slot].ev));
@@ -799,6 +820,42 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     }
     const int hit_rays = hp[0], unmasked = hp[1], n = hp[2];
     if (stats_host) { stats_host[0] = hit_rays; stats_host[1] = n; stats_host[2] = -1; stats_host[3] = unmasked; }
+    const bool can_pre = ray_mode && tok_gather(c, V) && fmt == TH_ROWS_SPLIT;
+    if (prepass == 3) {
+        // pre-gather stage: K5 + K4 of the first chunks (needs the map, the cameras, the token centres -- not the tokens)
+        th_ctx::Prepass& t = c->prepass[slot];
+        t.npre = 0;
+        if (!can_pre || n <= 0) return 0;
+        const bool grid = getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
+        if (grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s));
+        int k = 0;
+        for (int o = 0; o < n && k < TH_PRE_SETS; o += CH, ++k) {
+            const int m = (n - o) < CH ? (n - o) : CH;
+            {
+                ProfScope ps2(pf, TH_PROF_GATHER, s);
+                TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx + o, m, f->cams,
+                                           f->scale_xy, pre[k].f, f_ld, fmt, s, c->range_dev));
+            }
+            ProfScope ps1(pf, TH_PROF_DPARF, s);
+            TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, idx + o, m, f->centres, f->rot, nullptr, V, f->n_clusters, 0.5f,
+                                   pre[k].h, pre[k].pe, TH_ROWS_NBR, grid ? gws : nullptr, s));
+        }
+        if (!t.ev2) TH_HIP(hipEventCreateWithFlags(&t.ev2, hipEventDisableTiming));
+        TH_HIP(hipEventRecord(t.ev2, s));
+        t.npre = k;
+        t.pre_map = f->pixel_map_nhwc;
+        t.pre_centres = f->centres;
+        return 0;
+    }
+    int npre = 0;
+    if (prepass == 2) {
+        th_ctx::Prepass& t = c->prepass[slot];
+        if (t.npre > 0 && can_pre && t.pre_map == f->pixel_map_nhwc && t.pre_centres == f->centres) {
+            npre = t.npre;
+            TH_HIP(hipStreamWaitEvent(s, t.ev2, 0));
+        }
+        t.npre = 0;
+    }
     if (!ray_mode) TH_HIP(hipMemsetAsync(cb.vdc, 0, (size_t)CH * 27 * 4, s));   // zero view dirs, if_mesh_renderer.py:62
     TH_REQUIRE(f->n_clusters <= TH_MAX_CLUSTERS, "too many token clusters");
     const float* table = nullptr;
@@ -806,9 +863,20 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     // exact candidate grid for the 7-NN scan of K4 (TH_DPARF_NOGRID=1: full scan, same result)
     const bool use_grid = n > 0 && prepass != 1 && getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
     if (use_grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s));
-    for (int o = 0; o < n; o += CH) {
+    for (int o = 0, kc = 0; o < n; o += CH, ++kc) {
         int m = (n - o) < CH ? (n - o) : CH;
         const int32_t* sel = idx + o;
+        if (kc < npre) {        // rows and records of this chunk were written by th_render_pregather
+            ChunkBufs pc = cb;
+            pc.f = pre[kc].f; pc.h = pre[kc].h; pc.pe = pre[kc].pe;
+            {
+                ProfScope ps3(pf, TH_PROF_MLP, s);
+                TH_TRY(mlp_dispatch(c, V, m, pc, f_ld, vd_all, sel, S, unmasked, s, tprime, f->n_clusters));
+            }
+            ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
+            TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));
+            continue;
+        }
         // (K5 first: K4's small output -- records, tile headers, positional encodings, 0.3 KB per sample -- is then the
         // last thing written before the fused kernel reads it at the start of every tile: MALL instead of HBM)
         {
@@ -906,6 +974,29 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     t.ws = ws; t.rays = rays->ray_o; t.R = R; t.S = S;
     t.valid = true;
     return 0;
+}
+
+int th_render_pregather(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, th_stream stream) {
+    TH_REQUIRE(c && f && rays && ws, "null argument");
+    TH_REQUIRE(f->verts_world && f->Rh && f->Th && f->cams && f->scale_xy && f->pixel_map_nhwc && f->centres && f->rot &&
+                   f->n_clusters >= 7 && f->V >= 1 && f->V <= 4,
+               "th_render_pregather needs every th_frame field except the tokens");
+    TH_REQUIRE(f->map_channels == TH_MAP_FULL || f->map_channels == TH_MAP_COMPACT || f->map_channels == TH_MAP_SPLIT,
+               "th_frame.map_channels must be 384, 260 or 256");
+    int slot = -1;
+    for (int k = 0; k < th_ctx::kPrepassSlots; ++k) {
+        th_ctx::Prepass& t = c->prepass[k];
+        if (t.valid && t.ws == ws && t.rays == (const void*)rays->ray_o && t.R == rays->R && t.S == rays->S) slot = k;
+    }
+    if (slot < 0) return 0;                      // no matching th_render_prepass: nothing to do (th_render_rays runs everything)
+    const int R = rays->R, S = rays->S;
+    long long P = (long long)R * S;
+    TH_REQUIRE(ws_bytes >= shade_ws_bytes(f, P, R), "workspace too small");
+    ThArena ar(ws, ws_bytes);
+    ThPointSrc ps = th_src(rays);
+    float* raw = nullptr;
+    const uint8_t* mask = nullptr;
+    return shade_points(c, f, ps, P, true, ar, &raw, &mask, nullptr, (hipStream_t)stream, 3, slot);
 }
 
 int th_render_prepass_cancel(th_ctx* c) {

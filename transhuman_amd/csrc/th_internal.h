@@ -309,6 +309,12 @@ struct th_ctx {
         const void* rays = nullptr;
         int R = 0, S = 0;
         bool valid = false;
+        // th_render_pregather: the first `npre` chunks' pixel rows (K5) and neighbour records (K4) are already in the
+        // workspace's pre-gather sets, written for this map / these token centres; ev2 marks their completion
+        hipEvent_t ev2 = nullptr;
+        int npre = 0;
+        const void* pre_map = nullptr;
+        const void* pre_centres = nullptr;
     };
     static constexpr int kPrepassSlots = 4;
     Prepass prepass[kPrepassSlots];

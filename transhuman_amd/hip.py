@@ -126,6 +126,8 @@ SYMBOLS = {
                                  C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
     "th_render_prepass": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
                                     C.c_void_p]),
+    "th_render_pregather": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
+                                      C.c_void_p]),
     "th_conv_pack_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "th_conv_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                C.POINTER(C.c_float), C.c_void_p]),
@@ -854,13 +856,20 @@ class Frame:
         self.Rh, self.Th = _f32(Rh).reshape(9), _f32(Th).reshape(3)
         self.cams, self.scale = cams, scale_xy
         self.map = pixel_map_nhwc
-        self.tokens, self.centres, self.rot = _f32(tokens), _f32(centres).reshape(-1, 3), _f32(rot).reshape(-1, 9)
+        self.centres, self.rot = _f32(centres).reshape(-1, 3), _f32(rot).reshape(-1, 9)
+        self.tokens = _f32(tokens) if tokens is not None else None       # None: set_tokens() before the frame is rendered
         V, H, W, Cc = pixel_map_nhwc.shape
         assert Cc in (384, 260) or isinstance(pixel_map_nhwc, SplitMap), \
             "pixel map must be the full (384) or the compact (260 interleaved / SplitMap) channels-last map"
         self.c = ThFrame(_p(self.verts), self.verts.shape[0], _p(self.Rh), _p(self.Th), _p(self.cams), _p(self.scale),
                          _p(self.map), V, H, W, Cc, _p(self.tokens), _p(self.centres), _p(self.rot),
-                         self.tokens.shape[1], hull_thresh, small_frame_rays)
+                         self.centres.shape[0], hull_thresh, small_frame_rays)
+
+    def set_tokens(self, tokens):
+        """TransHE output [V, N_c, 192] of a frame that was built without it (render_pregather runs beside TransHE)"""
+        self.tokens = _f32(tokens)
+        assert self.tokens.shape[1] == self.centres.shape[0]
+        self.c.tokens = self.tokens.data_ptr()
 
 
 _ws_cache = {}
@@ -893,6 +902,19 @@ def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=240
     points._prepass_keep = (v, ws)
     _check(lib.th_render_prepass(ctx(dev), C.byref(f), C.byref(points.c), _p(ws), ws.numel(), _stream()))
     points._prepass_pending = True          # only THIS Points object (it keeps the ray tensors alive) may consume it
+
+
+def render_pregather(net, frame, points, slot=0):
+    """th_render_pregather: behind a render_prepass of the same ``points`` / workspace ``slot``, queue the pixel-feature
+    gather and the neighbour records of the first chunks -- ``frame`` may still lack its tokens (Frame(tokens=None)),
+    so TransHE can run on another stream meanwhile."""
+    if not getattr(points, "_prepass_pending", False):
+        return
+    lib = load_library()
+    _sync_weights(net, "mlp")
+    dev = frame.verts.device
+    _, ws = points._prepass_keep
+    _check(lib.th_render_pregather(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(ws), ws.numel(), _stream()))
 
 
 def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_frame_rays=None):

@@ -101,7 +101,8 @@ class Renderer:
         return self._dev[key]
 
     # ---- per-frame constants ---------------------------------------------------------
-    def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True, token_exchange=None):
+    def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True, token_exchange=None,
+                      pregather=None):
         """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
 
         fused_encoder_tail=True (default): the ResNet stem runs through SpatialEncoder.trunk (K12 / K11), its tail
@@ -117,7 +118,10 @@ class Renderer:
         map/gather/staging traffic and 12 % fewer MLP MACs, same function.
         All forms give the same tokens / pixels to fp32 rounding (tests/test_gpu_parity.py).
         token_exchange (multi-GPU, transhuman_amd.dist.TokenExchange): callable(compute, shape, device) that either
-        runs ``compute`` (paint -> group -> TransHE) here or receives the tokens from the rank that did."""
+        runs ``compute`` (paint -> group -> TransHE) here or receives the tokens from the rank that did.
+        pregather=(points, slot) (render_fast, behind its hull prepass): the pixel-feature gather and the neighbour
+        records of the frame's first chunks (hip.render_pregather: they need the map and the token centres, not the
+        tokens) are queued on the current stream and TransHE runs BESIDE them on a second stream instead of in front."""
         cfg = get_cfg()
         assert cfg.time_steps == 1                                                  # :412
         t = 0
@@ -162,16 +166,34 @@ class Renderer:
             self.last_grouped = group()
             return self.net.ViT(self.last_grouped, self._pe_norm(V, dev), mask=None)    # :538
 
-        if token_exchange is None:
-            tokens = make_tokens()
-        else:
-            tokens = token_exchange(make_tokens, (V, self.num_clusters, get_cfg().embed_size), dev)
         centres = hip.segment_mean(batch["tar_smpl_vertice_smplcoord"][0], off, mem)   # :543
         rot = hip.segment_mean_rot(batch["blend_mtx"][0], off, mem)                 # :544 + cross_transformer.py:185
-        frame = hip.Frame(batch["tar_smpl_vertice"][0], batch["Rh"][0], batch["Th"][0], cams, pix_scale, map_nhwc,
-                          tokens, centres, rot,
-                          hull_thresh=cfg_hull() if hull_thresh is None else hull_thresh,
-                          small_frame_rays=2400)
+        mk_frame = lambda tok: hip.Frame(batch["tar_smpl_vertice"][0], batch["Rh"][0], batch["Th"][0], cams, pix_scale,
+                                         map_nhwc, tok, centres, rot,
+                                         hull_thresh=cfg_hull() if hull_thresh is None else hull_thresh,
+                                         small_frame_rays=2400)
+        if token_exchange is not None:
+            frame = mk_frame(token_exchange(make_tokens, (V, self.num_clusters, get_cfg().embed_size), dev))
+        elif pregather is None or os.environ.get("TH_PREGATHER") == "0":
+            frame = mk_frame(make_tokens())
+        else:
+            pts_pg, slot_pg = pregather
+            cur = torch.cuda.current_stream(dev)
+            self.last_grouped = grouped = group()
+            grouped_ready = torch.cuda.Event()
+            grouped_ready.record(cur)
+            frame = mk_frame(None)
+            hip.render_pregather(self.net, frame, pts_pg, slot_pg)                  # K5 + K4 of the first chunks ...
+            vs = self._dev.get(("vit_stream", str(dev)))
+            if vs is None:
+                vs = self._dev[("vit_stream", str(dev))] = torch.cuda.Stream(dev)
+            with torch.cuda.stream(vs):                                            # ... TransHE beside them
+                vs.wait_event(grouped_ready)
+                tokens = self.net.ViT(grouped, self._pe_norm(V, dev), mask=None)    # :538
+            grouped.record_stream(vs)
+            tokens.record_stream(cur)
+            cur.wait_stream(vs)
+            frame.set_tokens(tokens)
         # (range guard, hip.render_rays: the same constants again -- through the stock convolutions -- if the stem's
         # input left the fp16 range)
         # (a rebuilt frame computes its own tokens: the exchange's frame counter must not advance twice)
@@ -208,7 +230,9 @@ class Renderer:
                                        n_clusters=len(self.csr_offsets) - 1)
                 for t in (pts.ray_o, pts.ray_d, pts.near, pts.far):
                     t.record_stream(side)
-            frame = self.prepare_frame(batch)
+                frame = self.prepare_frame(batch, pregather=(pts, 0))
+            else:
+                frame = self.prepare_frame(batch)
         # (the threshold applies to THIS call whether or not the frame constants were handed in)
         rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
                                                  small_frame_rays=small_frame_rays)
