@@ -366,6 +366,12 @@ class Renderer:
             fence = torch.cuda.Event()
             fence.record(main)
             epoch = hip.range_epoch(dev)
+            # two-phase shading: the texture-path-bound producers (pixel gather, neighbour records) of ALL chunks first,
+            # then the fused MLP of all chunks.  The side stream's front of the next frame starts with this frame's
+            # shading: its ~130 small launches share the chip with the producers (which leave LDS / registers / the
+            # matrix pipe free) instead of time-slicing with MLP tiles that own whole CUs.
+            if os.environ.get("TH_PREGATHER") != "0":
+                hip.render_pregather(self.net, frame, pts)
             rgb, acc, depth, stats, check = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
                                                             defer_guard=True, small_frame_rays=small_frame_rays)
             side.wait_event(fence)
