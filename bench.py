@@ -268,7 +268,9 @@ def run_extras(dev, net, args, H, W, V):
                          "hit_rays": int(r.last_stats["hit_rays"]), "gpu_vs_oracle": oracle_rays_check(bc2, assign, args.samples, idx, img)}
     seq.close()
 
-    # C5: sigma grid + marching cubes
+    # C5: sigma grid + marching cubes (its own 16.7 M-point workspace: give the frame workspaces back first)
+    hip.drop_workspaces(dev)
+    torch.cuda.empty_cache()
     g = args.grid
     mr = MeshRenderer(net, vertex_can=body.astype(np.float64) * 1.02 + 0.001, pc2voxel_ind=assign)
     mb = dict(bc)
@@ -277,9 +279,9 @@ def run_extras(dev, net, args, H, W, V):
     old_th = cfg.mesh_th
     cfg.mesh_th = 0.5                      # sigma_raw of the synthetic weights is O(1) (the reference's 20 fits trained weights)
     try:
-        ms, out = time_steps(lambda: mr.render(mbd), 2, warmup=1)
+        ms, out = time_steps(lambda: mr.render(mbd), 4, warmup=2)
         flat = mbd["pts"].reshape(-1, 3)
-        sig_ms, _ = time_steps(lambda: hip.eval_sigma_grid(net, mr.prepare_frame(mbd), flat), 2, warmup=0)
+        sig_ms, _ = time_steps(lambda: hip.eval_sigma_grid(net, mr.prepare_frame(mbd), flat), 4, warmup=1)
         cube = out["cube"][10:-10, 10:-10, 10:-10]
         # oracle on a sample of voxels near the surface + a few anywhere
         nz = np.flatnonzero(cube.reshape(-1) != 0)

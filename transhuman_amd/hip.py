@@ -887,6 +887,19 @@ def _cached_ws(nbytes, device, slot=0):
     return cur
 
 
+def drop_workspaces(device=None):
+    """Forget the cached render workspaces (tens of GB each at full frame size) -- e.g. between unrelated workloads of
+    one process; pending prepasses of those workspaces are cancelled."""
+    lib = load_library()
+    for (dev, _slot) in list(_ws_cache.keys()):
+        if device is None or str(device) == dev:
+            _ws_cache.pop((dev, _slot), None)
+    try:
+        _check(lib.th_render_prepass_cancel(ctx(device)))
+    except HipError:
+        pass
+
+
 def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=2400, n_clusters=0, slot=0):
     """th_render_prepass: queue the ray-only front of render_rays (hull mask, compaction, ...) before the
     per-frame constants exist.  The following render_rays on the same `points` picks it up (and shades in the
