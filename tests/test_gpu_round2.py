@@ -494,3 +494,32 @@ def test_token_blend_on_the_matrix_pipe_equals_the_fp32_blend(hip, gpu, net, nc,
     assert torch.isfinite(raw_nbr).all() and torch.equal(hip.network_forward(*args).cpu(), raw_nbr)
     scale = max(1.0, float(raw_rows.abs().max()))
     assert float((raw_nbr - raw_rows).abs().max()) < 1e-5 * scale, (nc, V, P, float((raw_nbr - raw_rows).abs().max()), scale)
+
+
+@pytest.mark.gpu
+def test_pregather_and_two_phase_shading_change_nothing(hip, gpu, net, monkeypatch):
+    """th_render_pregather (pixel rows + neighbour records of all chunks queued before TransHE has finished, on the
+    current stream; TransHE beside them) and the two-phase shading of render_sequence are pure re-orderings: the frame is
+    bit-identical with and without them, in the masked and in the un-masked (R' <= 2400) branch, also with several chunks"""
+    from transhuman_amd.networks.renderer import if_clight_renderer
+    from transhuman_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.N_samples, cfg.num_class = 32, 300
+    r = if_clight_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=synth_assign(300))
+    hip.set_chunk_samples(4096)                       # ~25 k valid samples -> 7 chunks: 5 pre-gathered + 2 interleaved
+    try:
+        for res, focal in ((64, 210.0), (32, 105.0)):
+            b = synth.batch_to(synth.make_batch(res, res, 3, seed=0, focal=focal), gpu)
+            monkeypatch.setenv("TH_PREGATHER", "0")
+            ref = r.render_fast(b, is_train=False)
+            st_ref = dict(r.last_stats)
+            seq_ref = [o["rgb_map"].clone() for o in r.render_sequence(iter([b, b]))]
+            monkeypatch.delenv("TH_PREGATHER")
+            out = r.render_fast(b, is_train=False)
+            assert dict(r.last_stats) == st_ref
+            for k in ("rgb_map", "acc_map", "depth_map"):
+                assert torch.equal(out[k], ref[k]), (res, k)
+            seq = [o["rgb_map"].clone() for o in r.render_sequence(iter([b, b]))]
+            assert all(torch.equal(a, c) for a, c in zip(seq, seq_ref)) and torch.equal(seq[0], ref["rgb_map"])
+    finally:
+        hip.set_chunk_samples(524288)
