@@ -1,5 +1,8 @@
+#!/usr/bin/env python
+"""Where the 256^3 mesh workload (if_mesh_renderer.Renderer.render) spends its time on the GPU box: whole render, sigma
+grid alone, frame constants, marching cubes:  python tools/mesh_time.py"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from transhuman_amd import hip, synth
 from transhuman_amd.config import get_cfg
