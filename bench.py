@@ -11,10 +11,15 @@ encoder (hand-written HIP too: K12 convolutions, K11 BatchNorm, K8 upsample/conc
 DPaRF tables -> [sample placement, hull mask, compaction, DPaRF, pixel gather,
 per-point MLP, compositing] -> image.  All inputs are resident in HBM before
 the timed region.  With N>1 GPUs the frame's rays are dealt to ranks in
-interleaved 8x8-pixel tiles, per-frame constants are recomputed on every rank
-(cheaper than shipping the 1.2 GB feature map) and the image is assembled with
-one RCCL all_gather -- "strong" scaling: total work fixed, value = rays of the
-frame / max-over-ranks time.
+diagonal 8x8-pixel tiles, the encoder's constants are recomputed on every rank
+(cheaper than shipping the 0.82 GB feature map), TransHE of frame j runs on rank
+j mod N and its tokens are broadcast, and the image is assembled with one RCCL
+all_gather -- "strong" scaling: total work fixed, value = rays of the frame /
+max-over-ranks time.  The timed loop runs Renderer.render_sequence (the frame
+constants of frame i+1 on a second stream under the shading of frame i); the
+reference's own call pattern, render_fast per frame, is timed after it and
+reported as render_fast_ms_per_step, followed by the `extra` block (the other
+configurations of BASELINE.json, each with an oracle spot check).
 
 Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (the fused per-point MLP: fp32-class arithmetic
 as three fp16 MFMA products per MAC), measured live with HIP events on the launch stream;
