@@ -962,6 +962,7 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     if (slot < 0) slot = c->prepass_rr = (c->prepass_rr + 1) % th_ctx::kPrepassSlots;
     th_ctx::Prepass& t = c->prepass[slot];
     t.valid = false;
+    t.npre = 0;                                   // (a pre-gather of an abandoned frame must not outlive its prepass)
     if (R <= 0) return 0;
     long long P = (long long)R * S;
     TH_REQUIRE(P < (1LL << 31), "R*S must fit in int32");
