@@ -102,7 +102,7 @@ class Renderer:
 
     # ---- per-frame constants ---------------------------------------------------------
     def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True, token_exchange=None,
-                      pregather=None):
+                      pregather=None, defer_tokens=False):
         """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
 
         fused_encoder_tail=True (default): the ResNet stem runs through SpatialEncoder.trunk (K12 / K11), its tail
@@ -121,7 +121,9 @@ class Renderer:
         runs ``compute`` (paint -> group -> TransHE) here or receives the tokens from the rank that did.
         pregather=(points, slot) (render_fast, behind its hull prepass): the pixel-feature gather and the neighbour
         records of the frame's first chunks (hip.render_pregather: they need the map and the token centres, not the
-        tokens) are queued on the current stream and TransHE runs BESIDE them on a second stream instead of in front."""
+        tokens) are queued on the current stream and TransHE runs BESIDE them on a second stream instead of in front.
+        defer_tokens=True (render_sequence): everything up to the grouped vertex features; ``frame.finish_tokens()`` runs
+        TransHE later (the frame pipeline issues it at the start of the next shading window, see render_sequence)."""
         cfg = get_cfg()
         assert cfg.time_steps == 1                                                  # :412
         t = 0
@@ -174,6 +176,11 @@ class Renderer:
                                          small_frame_rays=2400)
         if token_exchange is not None:
             frame = mk_frame(token_exchange(make_tokens, (V, self.num_clusters, get_cfg().embed_size), dev))
+        elif defer_tokens:
+            self.last_grouped = grouped = group()
+            pe_norm = self._pe_norm(V, dev)
+            frame = mk_frame(None)
+            frame.finish_tokens = lambda: frame.set_tokens(self.net.ViT(grouped, pe_norm, mask=None))   # :538
         elif pregather is None or os.environ.get("TH_PREGATHER") == "0":
             frame = mk_frame(make_tokens())
         else:
@@ -297,6 +304,13 @@ class Renderer:
         sl = slice(None) if ray_slice is None else ray_slice
         it = iter(batches)
         lookahead = max(1, min(int(lookahead), 3))           # (th_render_prepass keeps at most 4 tokens)
+        # split front (single rank, TH_SPLIT_FRONT=0 switches it off): the front of a frame is issued in two pieces -- A =
+        # hull stage, encoder, paint, group (chip-filling kernels) and B = TransHE (63 small dependent launches).  In the
+        # shading window of frame i the side stream runs B(i+1) FIRST and then A(i+2): the latency-bound launches of
+        # TransHE find free CUs beside the producers of frame i instead of queueing, one by one, behind MLP tiles.
+        split = token_exchange is None and os.environ.get("TH_SPLIT_FRONT", "1") != "0"
+        if split:
+            lookahead = max(lookahead, 2)
         nslots = lookahead + 1
 
         def front(b, j, side):
@@ -309,10 +323,21 @@ class Renderer:
                 if V <= 4 and pts.R > 0:
                     hip.render_prepass(pts, b["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
                                        n_clusters=len(self.csr_offsets) - 1, slot=1 + j % nslots)
-                frame = self.prepare_frame(b, token_exchange=token_exchange)
+                frame = self.prepare_frame(b, token_exchange=token_exchange, defer_tokens=split)
                 ready = torch.cuda.Event()
                 ready.record(side)
-            return b, pts, frame, ready
+            return [b, pts, frame, ready]
+
+        def tokens(ent, side):
+            """side stream: piece B of an entry whose piece A has been issued"""
+            fin = getattr(ent[2], "finish_tokens", None)
+            if fin is None:
+                return
+            with torch.cuda.stream(side):
+                fin()
+                ent[2].finish_tokens = None
+                ent[3] = torch.cuda.Event()
+                ent[3].record(side)
 
         first = next(it, None)
         if first is None:
@@ -324,6 +349,7 @@ class Renderer:
             side = self._dev[("side_stream", str(dev))] = torch.cuda.Stream(dev, priority=int(os.environ.get("TH_SIDE_PRIORITY", "0")))
         side.wait_stream(torch.cuda.current_stream(dev))
         queue = collections.deque([front(first, 0, side)])
+        tokens(queue[0], side)
         queued, more = 1, True
 
         def pull():
@@ -375,7 +401,9 @@ class Renderer:
             rgb, acc, depth, stats, check = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
                                                             defer_guard=True, small_frame_rays=small_frame_rays)
             side.wait_event(fence)
-            pull()
+            if queue:
+                tokens(queue[0], side)        # B(i+1) first ...
+            pull()                            # ... then A(i+lookahead)
             shaded.append((rgb, acc, depth, stats, frame, cur, pts, check, epoch))
             if len(shaded) > 1:
                 yield finish(shaded.popleft())
