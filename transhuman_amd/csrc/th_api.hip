@@ -623,13 +623,14 @@ static int dparf_row_format(const th_ctx* c, int V) {                           
 #define TH_PRE_SETS 5
 struct PreSet { float *f, *h, *pe; };
 static size_t pre_set_bytes(int V, int CH) {
-    return th_align((size_t)V * CH * 384 * 4) + th_align((size_t)CH * 16 * 4 + ((size_t)CH / 32 + 2) * 128 * 4) +
+    // (records of the chunk rounded up to whole tiles, then one 512-byte header per tile)
+    return th_align((size_t)V * CH * 384 * 4) + th_align(((size_t)CH + 32) * 16 * 4 + ((size_t)CH / 32 + 2) * 128 * 4) +
            th_align((size_t)CH * 64 * 4);
 }
 static int pre_carve(ThArena& ar, int V, int CH, PreSet* p) {
     for (int k = 0; k < TH_PRE_SETS; ++k) {
         p[k].f = ar.take<float>((size_t)V * CH * 384);
-        p[k].h = (float*)ar.take<char>((size_t)CH * 16 * 4 + ((size_t)CH / 32 + 2) * 128 * 4);
+        p[k].h = (float*)ar.take<char>(((size_t)CH + 32) * 16 * 4 + ((size_t)CH / 32 + 2) * 128 * 4);
         p[k].pe = ar.take<float>((size_t)CH * 64);
         TH_REQUIRE(p[k].pe != nullptr, "workspace too small");
     }
