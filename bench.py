@@ -530,6 +530,9 @@ def finish(dist_on, res):
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    if res is not None and os.environ.get("TH_BENCH_MEM") == "1":      # developer aid: peak device memory of the job
+        print(f"[bench] peak device memory: allocated {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB, "
+              f"reserved {torch.cuda.max_memory_reserved() / 2**30:.1f} GiB", file=sys.stderr)
     if res is not None:
         sys.stdout.flush()
         print(json.dumps(res), flush=True)
