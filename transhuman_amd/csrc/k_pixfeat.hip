@@ -70,6 +70,52 @@ __device__ __forceinline__ void pg_store8(float* __restrict__ orow, int g, float
 #endif
     }
 }
+// Contiguous form of pg_store8 for the latents of a split row: lane gl of a half-wave holds channels 4 gl .. 4 gl + 3 (a) and
+// 128 + 4 gl .. + 3 (b).  Neighbouring lanes (2k, 2k+1) trade halves with one DPP swap of four dwords, after which lane 2k holds
+// the 8 hi halves and lane 2k+1 the 8 lo halves of channel group k (a) and of group 16 + k (b): piece gl of the row's first 512
+// bytes and piece gl of its second -- two store instructions that each write 512 contiguous bytes per half-wave.
+// Every lane of the wave must call this (DPP reads the neighbour); `live` masks the stores.
+#ifndef PG_CONTIG
+#define PG_CONTIG 1
+#endif
+__device__ __forceinline__ unsigned pg_swap1(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ void pg_store_pair(float* __restrict__ orow, int gl, float4 a, float4 bq, unsigned& rm, bool live) {
+    typedef _Float16 pg_h2 __attribute__((ext_vector_type(2)));
+    const float va[4] = {a.x, a.y, a.z, a.w}, vb[4] = {bq.x, bq.y, bq.z, bq.w};
+    unsigned ha[2], la[2], hb[2], lb[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        _Float16 x0, y0, x1, y1;
+        pg_h2 t;
+        pg_split(va[2 * e], x0, y0); pg_split(va[2 * e + 1], x1, y1);
+        t[0] = x0; t[1] = x1; ha[e] = __builtin_bit_cast(unsigned, t);
+        t[0] = y0; t[1] = y1; la[e] = __builtin_bit_cast(unsigned, t);
+        pg_split(vb[2 * e], x0, y0); pg_split(vb[2 * e + 1], x1, y1);
+        t[0] = x0; t[1] = x1; hb[e] = __builtin_bit_cast(unsigned, t);
+        t[0] = y0; t[1] = y1; lb[e] = __builtin_bit_cast(unsigned, t);
+        pg_range_acc(rm, ha[e]);
+        pg_range_acc(rm, hb[e]);
+    }
+    const bool odd = gl & 1;
+    // even lanes send their lo halves and receive the neighbour's hi halves; odd lanes the other way round
+    unsigned ra[2], rb[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        ra[e] = pg_swap1(odd ? ha[e] : la[e]);
+        rb[e] = pg_swap1(odd ? hb[e] : lb[e]);
+    }
+    uint4 s0, s1;
+    s0.x = odd ? ra[0] : ha[0]; s0.y = odd ? ra[1] : ha[1]; s0.z = odd ? la[0] : ra[0]; s0.w = odd ? la[1] : ra[1];
+    s1.x = odd ? rb[0] : hb[0]; s1.y = odd ? rb[1] : hb[1]; s1.z = odd ? lb[0] : rb[0]; s1.w = odd ? lb[1] : rb[1];
+    if (live) {
+        uint4* o = reinterpret_cast<uint4*>(orow);
+        o[gl] = s0;
+        o[32 + gl] = s1;
+    }
+}
+
 // bilinear blend of four corner texels (grid_sample's term order; fused multiply-adds: the reference kernel is
 // compiled with FMA contraction too, and the parity bar for this stage is 2e-5)
 __device__ __forceinline__ float4 pg_blend(float4 a, float4 bb, float4 cc, float4 d, float w00, float w01, float w10,
@@ -291,9 +337,17 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
             const int ic[4] = {half ? b00 : a00, half ? b01 : a01, half ? b10 : a10, half ? b11 : a11};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+#if PG_CONTIG
+                // each half-wave reads 512 contiguous bytes per instruction (channels 4 gl.. and 128 + 4 gl..): 8 L1
+                // lines per wave load instead of 16 half-used ones
+                const float4* src = reinterpret_cast<const float4*>(m + (long long)ic[c] * C) + gl;
+                q[jj][c][0] = src[0];
+                q[jj][c][1] = src[32];
+#else
                 const float4* src = reinterpret_cast<const float4*>(m + (long long)ic[c] * C) + 2 * gl;
                 q[jj][c][0] = src[0];
                 q[jj][c][1] = src[1];
+#endif
             }
         }
         // groups beyond the latents (compact rows: r g b 0 | zeros; full rows: the 128 colour-lift channels) for the rows of
@@ -327,7 +381,11 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
             const int i = r0 + 2 * jj + half;
             const float4 ra = pg_blend(q[jj][0][0], q[jj][1][0], q[jj][2][0], q[jj][3][0], w[jj][0], w[jj][1], w[jj][2], w[jj][3]);
             const float4 rb = pg_blend(q[jj][0][1], q[jj][1][1], q[jj][2][1], q[jj][3][1], w[jj][0], w[jj][1], w[jj][2], w[jj][3]);
+#if PG_CONTIG
+            pg_store_pair(out + ((long long)(p0 + min(i, nrow - 1)) * V + v) * ldo, gl, ra, rb, rm, i < nrow);
+#else
             if (i < nrow) pg_store8<SPLIT>(out + ((long long)(p0 + i) * V + v) * ldo, gl, ra, rb, rm);
+#endif
         }
     }
     if (SPLIT) pg_range_commit(range, rm);
