@@ -62,3 +62,21 @@ def test_secondary_workloads_two_ranks(tmp_path, workload, extra):
     two = _run(2, str(tmp_path / "n2.npy"), 192, ex)
     assert one.shape == two.shape and float(np.abs(one).max()) > 0
     assert float(np.abs(one - two).max()) <= 2e-5 * max(1.0, float(np.abs(one).max())), float(np.abs(one - two).max())
+
+
+@pytest.mark.gpu
+def test_one_rank_job_over_rccl_equals_the_plain_frame(tmp_path):
+    """the transport the gloo runs above replace: `TH_FORCE_DIST=1` makes bench.py take its N-rank path with world size 1
+    on the real backend ("nccl" = RCCL): init_process_group on the device, the deferred hit-count all_reduce on its own
+    communicator and stream, the token broadcast from the side stream, all_gather_into_tensor of the image.  One rank owns
+    every ray tile in ascending order, so the gathered frame is the plain frame bit for bit."""
+    one = _run(1, str(tmp_path / "n1.npy"), 128)
+    env = dict(os.environ, TH_SAVE_IMAGE=str(tmp_path / "rccl.npy"), TH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TH_DIST_BACKEND", "TH_ONE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--res", "128"] + ARGS, cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    img = np.load(str(tmp_path / "rccl.npy"))
+    assert img.shape == one.shape and np.array_equal(img, one), float(np.abs(img - one).max())
