@@ -7,7 +7,8 @@
 // corner) and masks afterwards (cross_transformer.py:235); here the map is
 // channels-last (th_nchw_to_nhwc, once per frame) so each corner is one
 // contiguous 1.5 KB read, and only hull-valid samples are gathered.
-// One wave per 16 consecutive samples of one view; lanes span channels (float4 per lane).
+// One wave per 16 consecutive samples of one view; split rows: a half-wave per row, two float4 per lane and corner
+// (pixgather_kernel); fp32 rows: a wave per row, one float4 per lane and corner (pixgather_f32_kernel).
 // The map has C channels per pixel (384 full / 260 compact, see k_encoder.hip); output rows are ldo floats
 // wide (>= C; the tail is zero-filled so the row can feed a K-padded GEMM directly: compact rows are 272).
 // Bound: L2/HBM gather, 4 * 4C B per (sample, view) in, 4*ldo B out.
@@ -311,10 +312,11 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
         b = th_bilinear_setup(uu, vv, scale[0], scale[1], H, W);
     }
     // ---- phase 2 ----
-    // Rows in batches of PG_B = 2 row pairs.  Lanes 0..31 work on the first row of a pair, lanes 32..63 on the second;
-    // lane & 31 = channel group (8 channels = two float4 per corner): the 16 corner loads of a batch are all requested
-    // before the first blend, the corner indices / weights of the two rows come back as scalars (v_readlane) and are
-    // selected per half-wave.
+    // Rows in batches of PG_B / 2 row pairs.  Lanes 0..31 work on the first row of a pair, lanes 32..63 on the second;
+    // gl = lane & 31 owns two float4 per corner (channels 4 gl .. and 128 + 4 gl ..: every load instruction reads 512
+    // contiguous bytes per half-wave; pg_store_pair regroups them into the [8 hi | 8 lo] groups of a split row): the corner
+    // loads of a batch are all requested before the first blend, the corner indices / weights of the two rows come back as
+    // scalars (v_readlane) and are selected per half-wave.
     const int half = lane >> 5, gl = lane & 31;
     const int G = ldo / 8, TG = G - 32;                 // 8-channel groups per output row; groups beyond the 256 latents
     for (int r0 = 0; r0 < nrow; r0 += PG_B) {
