@@ -69,30 +69,54 @@ def executed_mlp_flops(V, n_valid, n_pos):
 MFMA_F16_PEAK = 2500e12         # dense fp16/bf16 MFMA peak (AMD's 5 PF figure is 2:1 sparse)
 
 
+def hbm_traffic():
+    """HBM bytes per full launch of the three per-sample kernels from the committed PMC passes: profiles/hbm_traffic.json
+    is written by `tools/pmc_hbm_summary.py DIR --json` from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_hbm.sh (2 *
+    FETCH_SIZE + WRITE_SIZE: the gfx950 correction of MI355X_MICROARCH.md) and names the summary it came from."""
+    p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
 def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_step=None):
     """Dominant kernel = the per-point MLP.  `achieved` counts ALGORITHMIC fp32 FLOPs (the reference's
-    layer shapes).  mode 1 (default): mlp_fused_kernel evaluates every fp32 MAC as three fp16 MFMA MACs
+    layer shapes).  mode 1 (default): the fused kernel evaluates every fp32 MAC as three fp16 MFMA MACs
     (hi*hi + hi*lo + lo*hi, fp32 accumulate), so the pipe it is bound by is the fp16 MFMA pipe at one third
     of its 2.5 PFLOP/s dense peak; mode 0: fp32 MFMA GEMM launches, peak 157.3 TFLOP/s."""
     if mlp_mode == 1:
         peak = MFMA_F16_PEAK / 3.0
-        kernel = "mlp_fused_kernel<3,1> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0"
+        kernel = "mlp_fused2_kernel<3,1> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0"
     else:
         peak = MFMA_F32_PEAK
         kernel = "per-point MLP stage (gemm_f32_mfma_kernel x14 + glue kernels), rank 0"
-    # HBM bytes per full launch (524288 samples) from the committed PMC passes (profiles/r01_i_pmc_hbm.txt:
-    # 2*FETCH_SIZE + WRITE_SIZE, gfx950 correction applied); algorithmic = 524288 * (3 views * (1024 B stok + 2 * 1088 B f) + 256 B pe)
-    traffic = 4.20e9 if mlp_mode == 1 else None
+    t = hbm_traffic() if mlp_mode == 1 else None
+    traffic = t["mlp_fused_bytes_per_launch"] if t else None
     return {"bound": "mfma", "kernel": kernel, "achieved": achieved / 1e12, "peak": peak / 1e12,
             "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "traffic_note": "HBM bytes per 524288-sample launch, rocprofv3 PMC (profiles/r02_m_pmc_hbm.txt); "
-                            "algorithmic 3.6e9 (pixel-feature rows twice, positional encodings, neighbour records)",
+            "traffic_note": ("HBM bytes per 524288-sample launch, rocprofv3 PMC (" + t["source"] + "); algorithmic " +
+                             f"{t['mlp_fused_algorithmic_bytes_per_launch']:.3g} (" + t["algorithmic_note"] + ")") if t else
+                            "no committed PMC pass (profiles/hbm_traffic.json absent)",
             "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK,
             "algorithmic_flop_per_step": flops_step, "kernel_ms_per_step": stage_ms,
             "launches_per_step": launches,
             # what the matrix pipes really did (after the algebraic folds): executed FLOPs / time / peak
             "executed_flop_per_step": executed_step,
             "frac_executed": (executed_step / max(stage_ms * 1e-3, 1e-12) / peak) if (executed_step and mlp_mode == 1) else None}
+
+
+def gather_block(V, n_valid, gather_ms, n_cu=256, clock_hz=2.4e9):
+    """K5 (pixgather_kernel) against its own ceiling: bytes through the texture path per (sample, view) row = 4 corner
+    texels of 1040 B (1 KiB of latents + 16 B colour) + one 1088-byte split row written; tools/ubench/load_rate.hip
+    reaches ~50 B/clk/CU for 1 KiB row gathers out of L2."""
+    rows = float(n_valid) * V
+    byts = rows * (4 * 1040 + 1088)
+    sec = max(gather_ms * 1e-3, 1e-12)
+    return {"kernel": "pixgather_kernel<true>", "bytes_per_step": byts, "ms_per_step": gather_ms, "TB_per_s": byts / sec / 1e12,
+            "B_per_clk_per_CU": byts / sec / clock_hz / n_cu, "ubench_ceiling_B_per_clk_per_CU": 50.0,
+            "note": f"at the nominal {clock_hz / 1e9:.1f} GHz, {n_cu} CUs; runs beside K4 (neighbour records) on a second stream"}
 
 
 def load_assign(k, body):
@@ -234,6 +258,37 @@ def run_extras(dev, net, args, H, W, V):
     frame_case("S_dense", args.nc, True)
     frame_case("C4_nc1500", 1500, False)
     cfg.num_class = args.nc
+
+    # SURVEY 8d's S-dense regime proper: a long lens on the torso + a per-ray slab hugging the surface -> (nearly) every one
+    # of the R x S = 16.8 M samples is valid (32 full passes of the per-sample stage, ~77 TFLOP of algorithmic MLP work):
+    # launch tails, the hull stage and the frame constants are negligible, the fused kernel's number stands alone
+    bc = synth.make_batch(H, W, V, seed=0, all_rays=True, dense=True, focal=6000.0 * W / 512, dilate=64)
+    body = bc["tar_smpl_vertice_smplcoord"][0].numpy()
+    assign = load_assign(args.nc, body)
+    r = Renderer(net, vertex_can=body.astype(np.float64) * 1.02 + 0.001, pc2voxel_ind=assign)
+    b = synth.batch_to(bc, dev)
+    seq = r.render_sequence(itertools.repeat(b))
+    next(seq); next(seq)
+    hip.profile_enable(True)
+    hip.profile_read()
+    ms, out = time_steps(lambda: next(seq), 3, warmup=0)
+    prof = hip.profile_read()
+    hip.profile_enable(False)
+    n_valid = int(r.last_stats["valid_samples"])
+    img = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
+    pts = hip.Points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], args.samples)
+    n_pos = count_sigma_positive(hip, net, r.last_frame, pts)
+    flops = algorithmic_mlp_flops(V, n_valid, n_pos)
+    mlp_ms = prof["mlp"][0] / 3.0
+    idx = np.sort(rs.choice(H * W, 48, replace=False))
+    extra["S_dense_full"] = {"ms_per_frame": ms, "rays_per_s": H * W / ms * 1e3, "valid_samples": n_valid,
+                             "sigma_pos_samples": n_pos, "algorithmic_mlp_flop": flops, "mlp_ms_per_frame": mlp_ms,
+                             "mlp_TFLOP_per_s": flops / max(mlp_ms * 1e-3, 1e-12) / 1e12,
+                             "roofline_frac": flops / max(mlp_ms * 1e-3, 1e-12) / (MFMA_F16_PEAK / 3.0),
+                             "gpu_vs_oracle": oracle_rays_check(bc, assign, args.samples, idx, img)}
+    seq.close()
+    hip.drop_workspaces(dev)
+    torch.cuda.empty_cache()
 
     # C3: orbit (the reference's virtual camera path, rays on device)
     bc = synth.make_batch(H, W, V, seed=0, all_rays=True)
@@ -493,6 +548,12 @@ def main():
             },
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
                                        mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos)),
+            "gather": gather_block(V, n_valid, prof["gather"][0] / max(args.steps, 1)),
+            # what the range guard of the fp16 hi/lo split has switched on this device (every entry false = the fast paths
+            # ran; a tripped MLP guard means per-layer fp32 launches, ~7x slower frames) + the last table read (fp16 bit
+            # patterns of max |x| per split tensor: f, s, p, n, inter, fc4_in; fp32 bits: conv_in; fp16: vit_in)
+            "range_guard": dict(hip.guard_state(dev), fallback=bool(hip.guard_state(dev)["mlp_fp32_fallback"]),
+                                slots=[int(x) for x in (hip.last_range or [])]),
             "stage_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
             "stage_note": "HIP-event spans per stage; with the frame pipeline hull / vit run on the side stream under the "
                           "other stages (their spans are stretched by the overlap and do not add to the frame time)",

@@ -104,8 +104,10 @@ int th_set_tok_gather(th_ctx* ctx, int on);
  * fp32-class only while every split value satisfies |x| < 65504 (fp16 range) and the tensor it belongs to is not
  * uniformly tiny (below 2^-14 the halves are subnormal: absolute resolution 2^-25).  The kernels keep launch-wide
  * maxima of |x| per split tensor in a device table; th_range_snapshot queues a copy of the table (and clears it)
- * behind the work issued so far on `stream` and returns a slot id (>= 0; 4 slots rotate), th_range_read waits for that
- * copy and returns the TH_RANGE_SLOTS words: slots 0..5 = fp16 bit pattern of max |hi half| of
+ * behind the work issued so far on `stream` and returns a snapshot id (>= 0, monotonic; 8 pinned buffers rotate),
+ * th_range_read waits for that copy and returns the TH_RANGE_SLOTS words (return value 2: the id is older than the 8
+ * most recent snapshots and its buffer has been reused -- the caller must treat the frame as unchecked and render it
+ * again): slots 0..5 = fp16 bit pattern of max |hi half| of
  * {f rows (K5), s, p, n, inter, fc_4 operand}; slot 6 = fp32 bit pattern of max |input| of the stem convolutions;
  * inf / NaN show up as values >= 0x7C00 (fp16 slots) / 0x7F800000 (fp32 slot).  th_render_rays,
  * th_eval_sigma_grid and th_network_forward take a snapshot at their end (th_range_last_slot).  A caller that finds
@@ -116,7 +118,7 @@ int th_set_tok_gather(th_ctx* ctx, int on);
 #define TH_RANGE_FP16_FLOOR 0x2400u     /* 2^-6  */
 /* slot 7: fp16 bit pattern of max |a| of the operands of TransHE's dense layers (th_gemm_h3).  Slots 6 and 7 are
  * written by the stream that computes a frame's constants and are sticky (not cleared by a snapshot; slot 7 is cleared by
- * th_set_vit_weights).  th_set_vit_mode(ctx, 0) moves TransHE's dense layers back to the fp32 MFMA GEMMs. */
+ * th_set_vit_weights, slot 6 by th_set_mlp_weights).  th_set_vit_mode(ctx, 0) moves TransHE's dense layers back to the fp32 MFMA GEMMs. */
 int th_set_vit_mode(th_ctx* ctx, int mode);
 int th_range_snapshot(th_ctx* ctx, th_stream stream);
 int th_range_read(th_ctx* ctx, int slot, uint32_t* out /* [TH_RANGE_SLOTS] */);
@@ -125,6 +127,13 @@ int th_range_last_slot(th_ctx* ctx);
  * batchify_rays chunk is 32768, if_clight_renderer.py:575).  Results do not depend on it; workspace
  * sizes do, so call it before the *_workspace_bytes() queries. */
 int th_set_chunk_samples(int n);
+/* Generation of the fused per-point MLP kernel (process-wide; same inputs, outputs and arithmetic):
+ * 2 = mlp_fused2_kernel -- the pixel-feature rows are read once per tile (the RGB branch's products over them
+ * are formed in the pixel branch), keys stay in registers, the rows' LDS staging runs under the key/value GEMMs;
+ * 1 = mlp_fused_kernel of rounds 1-2.  The two are each other's in-GPU cross-check; the default is the faster one on the
+ * headline frame, env TH_FUSED_GEN=1|2 overrides it.  th_get_fused_gen returns the current value. */
+int th_set_fused_gen(int gen);
+int th_get_fused_gen(void);
 int th_set_vit_weights(th_ctx* ctx, int depth, int dim, int heads, const th_vit_block* blocks,
                        const float* norm_w, const float* norm_b, th_stream stream);
 

@@ -1,0 +1,178 @@
+"""GPU tests added in round 3: the CPU oracle on the BASELINE configs[1] frame at its own size and on the S-dense
+frame (every sample valid), the range guard across a frame pipeline (stem-convolution overflow seen one frame early),
+the snapshot ring, and the training entry.  Everything goes through the C ABI (transhuman_amd.hip)."""
+import itertools
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import th_oracle as O
+from transhuman_amd import synth
+from util import make_sd, make_net, synth_assign, csr, can_centres64, can64, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(gpu):
+    from transhuman_amd import hip as H
+    H.load_library()
+    return H
+
+
+@pytest.fixture(scope="module")
+def net(gpu, hip):
+    return make_net(12).to(gpu)
+
+
+def _renderer(net, nc, samples=64):
+    from transhuman_amd.config import get_cfg
+    from transhuman_amd.networks.renderer import if_clight_renderer
+    cfg = get_cfg()
+    cfg.N_samples, cfg.num_class = samples, nc
+    return if_clight_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=synth_assign(nc))
+
+
+def _oracle_on(bc, pick, assign, samples=64):
+    sd = make_sd()
+    off, mem = csr(assign)
+    sub = dict(bc)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        sub[k] = bc[k][:, pick]
+    with torch.no_grad():
+        hol, pix = O.encoder_forward(sd, bc["input_imgs"][0][0])
+        ref, _ = O.render_fast(sd, sub, hol, pix, off, mem, can_centres64(assign), n_samples=samples, small_frame_rays=-1)
+    return ref
+
+
+def test_headline_frame_oracle_sample(hip, gpu, net):
+    """BASELINE.json configs[1] at its own size (512 x 512 rays x 64 samples, V = 3, N_c = 500: the frame bench.py
+    times): the CPU oracle on 96 of its rays (64 of them hits), rgb / acc within 1e-4, through render_fast AND through
+    the frame pipeline bench.py's timed loop uses."""
+    r = _renderer(net, 500)
+    bc = synth.make_batch(512, 512, 3, seed=0, all_rays=True)
+    b = synth.batch_to(bc, gpu)
+    out = r.render_fast(b, is_train=False)
+    st = dict(r.last_stats)
+    rgb, acc = out["rgb_map"][0], out["acc_map"][0]
+    assert st["hit_rays"] > 30000 and st["valid_samples"] > 1500000 and st["unmasked"] == 0
+    seq = r.render_sequence(itertools.repeat(b))
+    next(seq)
+    piped = next(seq)
+    seq.close()
+    assert torch.equal(piped["rgb_map"], out["rgb_map"]) and torch.equal(piped["acc_map"], out["acc_map"])
+    rs = np.random.RandomState(5)
+    hits = torch.nonzero(acc > 0).reshape(-1).cpu().numpy()
+    pick = np.sort(np.concatenate([rs.choice(hits, 64, replace=False), rs.choice(512 * 512, 32, replace=False)]))
+    ref = _oracle_on(bc, pick, synth_assign(500))
+    assert maxdiff(rgb[pick].cpu(), ref["rgb_map"][0]) < 1e-4 and maxdiff(acc[pick].cpu(), ref["acc_map"][0]) < 1e-4
+    assert float(ref["acc_map"].max()) > 0.05
+    assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")
+
+
+def test_s_dense_full_frame_oracle_sample(hip, gpu, net):
+    """SURVEY 8d's S-dense regime: a long lens on the torso and a per-ray slab hugging the surface make (nearly) every
+    one of the 512 x 512 x 64 = 16.8 M samples valid -- 32 full passes of the per-sample stage.  Properties over the
+    frame + the oracle on 40 rays."""
+    r = _renderer(net, 500)
+    bc = synth.make_batch(512, 512, 3, seed=0, all_rays=True, dense=True, focal=6000.0, dilate=64)
+    b = synth.batch_to(bc, gpu)
+    out = r.render_fast(b, is_train=False)
+    st = dict(r.last_stats)
+    rgb, acc = out["rgb_map"][0], out["acc_map"][0]
+    assert st["hit_rays"] == 512 * 512 and st["valid_samples"] > 0.99 * 512 * 512 * 64 and st["unmasked"] == 0
+    assert torch.isfinite(rgb).all() and float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
+    rs = np.random.RandomState(6)
+    pick = np.sort(rs.choice(512 * 512, 40, replace=False))
+    ref = _oracle_on(bc, pick, synth_assign(500))
+    assert maxdiff(rgb[pick].cpu(), ref["rgb_map"][0]) < 1e-4 and maxdiff(acc[pick].cpu(), ref["acc_map"][0]) < 1e-4
+    hip.drop_workspaces(gpu)
+
+
+def test_pipeline_rebuilds_frames_built_before_a_conv_fallback(hip, gpu):
+    """Range guard across render_sequence: the stem convolutions' range slot is sticky and written by the side stream
+    one or two frames AHEAD, so the overflow of a coming frame is first seen in the snapshot of an earlier one.  Every
+    frame whose constants were built before the switch to the stock convolutions must be rebuilt (epoch of its front),
+    not only the one whose snapshot showed it: the pipeline's frames equal render_fast's on the fallen-back context."""
+    net2 = make_net(12).to(gpu)                       # its own module: the fallback is tied to the uploaded weights
+    r = _renderer(net2, 300, samples=32)
+    bc = synth.make_batch(64, 64, 3, seed=0, focal=210.0)
+    big = dict(bc)
+    big["input_imgs"] = [t * 1.0e5 for t in bc["input_imgs"]]   # |x| > 65504 in front of conv1: inf in the fp16 hi planes
+    b = synth.batch_to(big, gpu)
+    assert not hip.conv_fallback(gpu)
+    e0 = hip.range_epoch(gpu)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        seq = r.render_sequence(itertools.repeat(b))
+        frames = [next(seq) for _ in range(4)]
+        seq.close()
+    assert hip.conv_fallback(gpu) and hip.range_epoch(gpu) > e0
+    assert any("convolution" in str(x.message) for x in w)
+    ref = r.render_fast(b, is_train=False)             # stock convolutions now
+    assert torch.isfinite(ref["rgb_map"]).all()
+    for f in frames:
+        assert torch.equal(f["rgb_map"], ref["rgb_map"]) and torch.equal(f["acc_map"], ref["acc_map"])
+    # new weights bring the HIP convolutions back (and clear the sticky slot)
+    with torch.no_grad():
+        net2.alpha_fc.bias.add_(0.0)
+    small = synth.batch_to(bc, gpu)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        out = r.render_fast(small, is_train=False)
+    assert not hip.conv_fallback(gpu) and torch.isfinite(out["rgb_map"]).all()
+    assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")
+
+
+def test_stale_range_snapshot_is_reported(hip, gpu, net):
+    """The snapshot ring holds the 8 most recent snapshots: an id held across more guarded calls than that is reported
+    as overwritten (range_read -> None, the guard answers 'render again') instead of returning another call's maxima."""
+    r = _renderer(net, 300, samples=32)
+    b = synth.batch_to(synth.make_batch(32, 32, 3, seed=0), gpu)
+    frame = r.prepare_frame(b)
+    pts = hip.Points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], n_samples=32)
+    rgb, acc, dep, st, check = hip.render_rays(net, frame, pts, defer_guard=True)
+    assert check() is True
+    rgb, acc, dep, st, check = hip.render_rays(net, frame, pts, defer_guard=True)
+    for _ in range(9):
+        hip.render_rays(net, frame, pts)
+    assert check() is False                            # overwritten: unchecked -> the caller renders again
+    assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")   # ... without switching any path
+
+
+def test_training_entry_refuses_autograd(hip, gpu, net):
+    """Renderer.render is the reference trainer's entry (if_nerf_clight.py:45): with gradients enabled it raises
+    instead of handing back graph-less tensors; under no_grad it renders."""
+    r = _renderer(net, 300, samples=32)
+    b = synth.batch_to(synth.make_batch(16, 16, 3, seed=0), gpu)
+    assert any(p.requires_grad for p in net.parameters())
+    with pytest.raises(RuntimeError, match="inference-only"):
+        r.render(b)
+    with torch.no_grad():
+        out = r.render(b)
+    assert out["rgb_map"].shape == (1, 256, 3) and torch.isfinite(out["rgb_map"]).all()
+
+
+@pytest.mark.parametrize("V,compact", [(3, True), (3, False), (1, True), (2, False)])
+def test_fused_kernel_generations_agree(hip, gpu, V, compact):
+    """mlp_fused2_kernel (f read once, keys in registers, staging under the GEMMs) against mlp_fused_kernel on the same
+    frame: same arithmetic, different summation order in the cross-view dots only -> raw-level agreement far inside the
+    1e-4 bar, for the compact (272) and the full (384) row forms and 1 / 2 / 3 views, masked and un-masked modes."""
+    net2 = make_net(12).to(gpu)
+    r = _renderer(net2, 300, samples=32)
+    b = synth.batch_to(synth.make_batch(48, 40, V, seed=0, focal=160.0), gpu)
+    outs = {}
+    for gen in (1, 2):
+        default_gen = hip.set_fused_gen(gen)
+        try:
+            frame = r.prepare_frame(b, compact_map=compact)
+            o = r.render_fast(b, frame=frame, small_frame_rays=-1)
+            u = r.render_fast(b, frame=frame, small_frame_rays=1 << 30)
+        finally:
+            hip.set_fused_gen(default_gen)
+        outs[gen] = (o["rgb_map"][0].clone(), o["acc_map"][0].clone(), u["rgb_map"][0].clone(), u["acc_map"][0].clone())
+    for a, c in zip(outs[1], outs[2]):
+        assert torch.isfinite(c).all() and maxdiff(a.cpu(), c.cpu()) < 5e-6
+    assert float(outs[2][1].max()) > 0.05

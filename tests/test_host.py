@@ -160,3 +160,36 @@ def test_evaluator_psnr_images_and_files(tmp_path):
         assert (p2[~mask[5:17, 8:20]] == 1.0).all()
     finally:
         cfg.white_bkgd = old
+
+
+def test_training_entry_is_refused_before_any_device_work():
+    """Renderer.render with gradients enabled (the reference trainer's call, if_nerf_clight.py:45) raises an explicit
+    inference-only error -- on any host, before a HIP call is made."""
+    import pytest
+    from transhuman_amd.config import get_cfg
+    from transhuman_amd.networks.renderer.if_clight_renderer import Renderer
+    from util import can64
+    get_cfg().num_class = 300
+    r = Renderer(make_net(2), vertex_can=can64().numpy(), pc2voxel_ind=synth_assign(300))
+    with pytest.raises(RuntimeError, match="inference-only"):
+        r.render(synth.make_batch(8, 8, 1, seed=0))
+
+
+def test_synthetic_rays_match_the_oracle_restatement_of_the_loader():
+    """synth.pixel_rays / box_interval (the generator's own ray set-up) give the numbers of the oracle's restatement of
+    the reference data loader (oracle/th_oracle.py, pinned to the reference by g14_rays): the committed goldens were
+    made from batches built on exactly these values."""
+    from oracle import th_oracle as O
+    cams = synth.make_cameras(48, 40, 3, center=(0.03, 0.10, 3.0))
+    K, R, T = cams["in_K"][1], cams["in_R"][1], cams["in_T"][1]
+    bounds = np.array([[-0.4, -0.8, 2.6], [0.45, 0.95, 3.4]], np.float32)
+    K, R, T = K.astype(np.float32), R.astype(np.float32), T.astype(np.float32)
+    ref = O.gen_rays(48, 40, K, R, T, bounds)
+    o, d = synth.pixel_rays(48, 40, K, R, T)
+    o = o.reshape(-1, 3).astype(np.float32)
+    d = d.reshape(-1, 3).astype(np.float32)
+    near, far, m = synth.box_interval(bounds, o, d)
+    assert m.sum() > 100 and np.array_equal(m, ref["mask_at_box"])
+    assert np.array_equal(near.astype(np.float32), ref["near"][m]) and np.array_equal(far.astype(np.float32), ref["far"][m])
+    assert np.array_equal(o, ref["ray_o"])
+    assert np.array_equal(np.where(np.abs(d) < 1e-5, np.float32(1e-5), d), ref["ray_d"])

@@ -21,6 +21,7 @@ def load(path, name):
 
 def main():
     d = sys.argv[1]
+    as_json = "--json" in sys.argv
     f = load(f"{d}/pmc_FETCH_SIZE_counter_collection.csv", "FETCH_SIZE")
     w = load(f"{d}/pmc_WRITE_SIZE_counter_collection.csv", "WRITE_SIZE")
     print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1")
@@ -31,6 +32,22 @@ def main():
         fk = max(f[k])
         wk = max(w.get(k, [0.0]))
         rows.append((2 * fk + wk, k, len(f[k]), fk, wk))
+    if as_json:
+        # profiles/hbm_traffic.json (read by bench.py): bytes per full launch of the three per-sample kernels
+        import json
+
+        def of(sub):
+            m = [r for r in rows if sub in r[1]]
+            return max(m)[0] * 1024 if m else None
+        src = sys.argv[sys.argv.index("--json") + 1] if len(sys.argv) > sys.argv.index("--json") + 1 else d
+        ch, V = 524288, 3
+        print(json.dumps({"source": src, "launch_samples": ch,
+                          "mlp_fused_bytes_per_launch": of("mlp_fused"), "pixgather_bytes_per_launch": of("pixgather_kernel<true>"),
+                          "dparf_bytes_per_launch": of("dparf_kernel"),
+                          "mlp_fused_algorithmic_bytes_per_launch": ch * (V * 1088 + 256 + 64) + ch // 32 * 512,
+                          "algorithmic_note": "pixel-feature rows once (3 x 1088 B), positional encoding 256 B, neighbour record "
+                                              "64 B per sample + a 512 B header per 32-sample tile"}, indent=1))
+        return
     for hbm, k, n, fk, wk in sorted(rows, reverse=True)[:16]:
         print(f"{k[:62]:62s} {n:8d} {fk:12.0f} {wk:12.0f} {hbm * 1024 / 1e9:13.3f}")
 

@@ -80,6 +80,9 @@ void th_ctx_destroy(th_ctx* c) {
     if (c->host_pinned) (void)hipHostFree(c->host_pinned);
     if (c->range_dev) (void)hipFree(c->range_dev);
     if (c->range_host) (void)hipHostFree(c->range_host);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
+    if (c->aux_join) (void)hipEventDestroy(c->aux_join);
     for (auto& e : c->range_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& t : c->prepass)
@@ -218,6 +221,9 @@ int th_set_mlp_weights(th_ctx* c, const th_mlp_weights* w, th_stream stream) {
         }
         M.compact_ready = true;
     }
+    // new weights: the sticky maximum of the stem convolutions' input starts over (the encoder belongs to the same
+    // parameter set; hip.py re-enables the HIP convolutions at the same moment)
+    TH_HIP(hipMemsetAsync(c->range_dev + TH_RANGE_CONV, 0, sizeof(unsigned int), s));
     TH_HIP(hipStreamSynchronize(s));
     M.ready = true;
     // fused-kernel image (fp16 hi/lo split, per-wave fragment order)
@@ -229,11 +235,16 @@ int th_set_mlp_weights(th_ctx* c, const th_mlp_weights* w, th_stream stream) {
     return 0;
 }
 
+// Snapshots rotate through kRangeSnaps pinned buffers.  The id handed out is a GENERATION (monotonic; buffer = id %
+// kRangeSnaps): a caller that holds an id across more than kRangeSnaps - 1 later snapshots (a frame pipeline whose
+// consumer issues other guarded calls between two frames) is told so (th_range_read returns 2) instead of silently
+// reading another call's maxima.
 int th_range_snapshot(th_ctx* c, th_stream stream) {
     TH_REQUIRE(c, "null ctx");
     hipStream_t s = (hipStream_t)stream;
-    const int slot = c->range_rr;
-    c->range_rr = (c->range_rr + 1) % th_ctx::kRangeSnaps;
+    const int gen = c->range_gen_next;
+    const int slot = gen % th_ctx::kRangeSnaps;
+    c->range_gen_next = gen == 0x3fffffff ? 0 : gen + 1;
     if (!c->range_ev[slot]) TH_HIP(hipEventCreateWithFlags(&c->range_ev[slot], hipEventDisableTiming));
     TH_HIP(hipMemcpyAsync(c->range_host + slot * TH_RANGE_SLOTS, c->range_dev, TH_RANGE_SLOTS * sizeof(unsigned int),
                           hipMemcpyDeviceToHost, s));
@@ -241,13 +252,20 @@ int th_range_snapshot(th_ctx* c, th_stream stream) {
     // frame's constants (clearing them here could erase that frame's maxima) -- they are sticky until new weights arrive
     TH_HIP(hipMemsetAsync(c->range_dev, 0, TH_RANGE_CONV * sizeof(unsigned int), s));
     TH_HIP(hipEventRecord(c->range_ev[slot], s));
-    c->range_last = slot;
-    return slot;
+    c->range_gen[slot] = gen;
+    c->range_last = gen;
+    return gen;
 }
 
-int th_range_read(th_ctx* c, int slot, uint32_t* out) {
+int th_range_read(th_ctx* c, int id, uint32_t* out) {
     TH_REQUIRE(c && out, "null argument");
-    TH_REQUIRE(slot >= 0 && slot < th_ctx::kRangeSnaps && c->range_ev[slot], "no such range snapshot");
+    TH_REQUIRE(id >= 0, "no such range snapshot");
+    const int slot = id % th_ctx::kRangeSnaps;
+    TH_REQUIRE(c->range_ev[slot], "no such range snapshot");
+    if (c->range_gen[slot] != id) {
+        th_set_error("th_range_read: snapshot " + std::to_string(id) + " has been overwritten by later snapshots");
+        return 2;
+    }
     TH_HIP(hipEventSynchronize(c->range_ev[slot]));
     memcpy(out, c->range_host + slot * TH_RANGE_SLOTS, TH_RANGE_SLOTS * sizeof(unsigned int));
     return 0;
@@ -829,17 +847,47 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         if (!can_pre || n <= 0) return 0;
         const bool grid = getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
         if (grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s));
-        int k = 0;
-        for (int o = 0; o < n && k < TH_PRE_SETS; o += CH, ++k) {
-            const int m = (n - o) < CH ? (n - o) : CH;
-            {
-                ProfScope ps2(pf, TH_PROF_GATHER, s);
-                TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx + o, m, f->cams,
-                                           f->scale_xy, pre[k].f, f_ld, fmt, s, c->range_dev));
+        // K4 of every chunk on the context's second stream, K5 of every chunk on `s`: the two producers share nothing but
+        // the sample list -- K5 sits on the texture path (TA busy 80-90 %, VALU 43 %), K4 since TH_ROWS_NBR is a 7-NN scan
+        // out of LDS (no row gather) -- so their waves co-reside on the CUs instead of running back to back
+        // (TH_K4_SIDE=0: one stream, K5 then K4 per chunk).
+        static const bool k4_side = !(getenv("TH_K4_SIDE") && getenv("TH_K4_SIDE")[0] == '0');
+        hipStream_t s4 = s;
+        if (k4_side) {
+            if (!c->aux) {
+                TH_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+                TH_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
+                TH_HIP(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
             }
-            ProfScope ps1(pf, TH_PROF_DPARF, s);
-            TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, idx + o, m, f->centres, f->rot, nullptr, V, f->n_clusters, 0.5f,
-                                   pre[k].h, pre[k].pe, TH_ROWS_NBR, grid ? gws : nullptr, s));
+            TH_HIP(hipEventRecord(c->aux_fork, s));          // sample list, candidate grid and every earlier user of the sets
+            TH_HIP(hipStreamWaitEvent(c->aux, c->aux_fork, 0));
+            s4 = c->aux;
+        }
+        int k = 0;
+        {
+            ProfScope ps1(pf, TH_PROF_DPARF, s4);
+            for (int o = 0; o < n && k < TH_PRE_SETS; o += CH, ++k) {
+                const int m = (n - o) < CH ? (n - o) : CH;
+                TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, idx + o, m, f->centres, f->rot, nullptr, V, f->n_clusters, 0.5f,
+                                       pre[k].h, pre[k].pe, TH_ROWS_NBR, grid ? gws : nullptr, s4));
+                if (!k4_side) {
+                    ProfScope ps2(pf, TH_PROF_GATHER, s);
+                    TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx + o, m, f->cams,
+                                               f->scale_xy, pre[k].f, f_ld, fmt, s, c->range_dev));
+                }
+            }
+        }
+        if (k4_side) {
+            ProfScope ps2(pf, TH_PROF_GATHER, s);
+            int k5 = 0;
+            for (int o = 0; o < n && k5 < TH_PRE_SETS; o += CH, ++k5) {
+                const int m = (n - o) < CH ? (n - o) : CH;
+                TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx + o, m, f->cams,
+                                           f->scale_xy, pre[k5].f, f_ld, fmt, s, c->range_dev));
+            }
+            ps2.close();
+            TH_HIP(hipEventRecord(c->aux_join, c->aux));
+            TH_HIP(hipStreamWaitEvent(s, c->aux_join, 0));
         }
         if (!t.ev2) TH_HIP(hipEventCreateWithFlags(&t.ev2, hipEventDisableTiming));
         TH_HIP(hipEventRecord(t.ev2, s));

@@ -247,6 +247,7 @@ struct FusedParams {
     // stacked along out_f (K 384, on f): column tile 0 accumulates onto vfA / vfD, tile 1 is rgb_res_1
     FusedLayer vfA, vfD, rst;
     FusedLayer ar0c, rstc;         // colour-folded (K = 272) forms; the launcher copies them over ar0 / rst
+    FusedLayer k0, v0;             // kv0's key tile (CT 1) and value tiles (CT 2) as separate images (mlp_fused2_kernel: two passes)
     bool compact_ready;
     const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
     // token branch, written by K4 in TH_ROWS_FOLDED form: the neighbour blend of T' = tokens W_tok^T (fp32) and
@@ -320,13 +321,18 @@ struct th_ctx {
     Prepass prepass[kPrepassSlots];
     int prepass_rr = 0;
     int n_cu = 256;
+    // second stream of the pre-gather stage: K4 (neighbour records: VALU / LDS work, no row gather since TH_ROWS_NBR)
+    // runs beside K5 (pixel-feature gather: texture-path bound) instead of behind it
+    hipStream_t aux = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
     void* prof = nullptr;             // ThProf (th_api.hip)
     // range guard (th_range_*): device table the kernels merge their maxima into, pinned snapshots + events
     unsigned int* range_dev = nullptr;
     unsigned int* range_host = nullptr;            // [kRangeSnaps][TH_RANGE_SLOTS]
-    static constexpr int kRangeSnaps = 4;
+    static constexpr int kRangeSnaps = 8;
     hipEvent_t range_ev[kRangeSnaps] = {};
-    int range_rr = 0, range_last = -1;
+    int range_gen[kRangeSnaps] = {-1, -1, -1, -1, -1, -1, -1, -1};   // generation each pinned buffer holds
+    int range_gen_next = 0, range_last = -1;
 };
 
 // ---- launchers (one group per .hip file) -------------------------------------------

@@ -67,6 +67,8 @@ SYMBOLS = {
     "th_range_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "th_range_last_slot": (C.c_int, [C.c_void_p]),
     "th_set_chunk_samples": (C.c_int, [C.c_int]),
+    "th_set_fused_gen": (C.c_int, [C.c_int]),
+    "th_get_fused_gen": (C.c_int, []),
     "th_set_vit_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(ThVitBlock), C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "th_linear_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -291,9 +293,15 @@ def _sync_weights(mod, kind):
     if own is None or own[0]() is not mod or own[1] != ver:
         (set_mlp_weights if kind == "mlp" else set_vit_weights)(mod)
         _ctx_owner[key] = (weakref.ref(mod), ver)
-        if kind == "mlp" and _range_fallback.pop(key[0], None):
-            # new weights: back to the mode the caller asked for (the guard re-checks them)
-            _check(load_library().th_set_mlp_mode(ctx(dev), _user_mode.get(key[0], 1)))
+        # new weights: back to the modes the caller asked for (the guard re-checks them).  The Network's parameter set
+        # includes the encoder, so the stem convolutions return to the HIP kernels with it (th_set_mlp_weights clears
+        # their sticky range slot, th_set_vit_weights TransHE's).
+        if kind == "mlp":
+            if _range_fallback.pop(key[0], None):
+                _check(load_library().th_set_mlp_mode(ctx(dev), _user_mode.get(key[0], 1)))
+            _conv_fallback.pop(key[0], None)
+        elif _vit_fallback.pop(key[0], None):
+            _check(load_library().th_set_vit_mode(ctx(dev), 1))
 
 
 # ---------------------------------------------------------------------------
@@ -306,8 +314,8 @@ RANGE_FP32_LIMIT = 0x476A6000      # 6.0e4 as an fp32 bit pattern (slot conv_in)
 _user_mode = {}                    # device index -> mode requested through set_mlp_mode (default 1)
 _range_fallback = {}               # device index -> True while the guard forces mode 0 on this context
 _range_epoch = {}                  # device index -> number of fallbacks so far (frames queued earlier are re-rendered)
-conv_fallback = False              # set when the stem convolutions' input left the fp16 range: stock convolutions from now on
-vit_fallback = False               # set when an operand of TransHE's fp16-split GEMMs left the fp16 range: fp32 MFMA GEMMs
+_conv_fallback = {}                # device index -> True once the stem convolutions' input left the fp16 range: stock convolutions
+_vit_fallback = {}                 # device index -> True once an operand of TransHE's fp16-split GEMMs left the fp16 range: fp32 MFMA GEMMs
 last_range = None                  # the last table read (debugging / tests)
 
 
@@ -316,11 +324,33 @@ def _dev_index(device):
         else torch.cuda.current_device()
 
 
+def conv_fallback(device=None):
+    """True while the stem convolutions of this device run through the stock modules (range guard)."""
+    return bool(_conv_fallback.get(_dev_index(device)))
+
+
+def vit_fallback(device=None):
+    """True while TransHE's dense layers of this device run on the fp32 MFMA GEMMs (range guard)."""
+    return bool(_vit_fallback.get(_dev_index(device)))
+
+
+def guard_state(device=None):
+    """What the range guard has switched on this device: every entry False = the fast paths are in use (a tripped MLP
+    guard means per-layer fp32 MFMA launches, ~7x slower frames)."""
+    d = _dev_index(device)
+    return {"mlp_fp32_fallback": bool(_range_fallback.get(d)), "conv_fallback": bool(_conv_fallback.get(d)),
+            "vit_fp32_fallback": bool(_vit_fallback.get(d)), "epoch": _range_epoch.get(d, 0)}
+
+
 def range_read(slot, device=None):
-    """The launch-wide maxima of snapshot ``slot`` (th_range_read; waits for the work in front of the snapshot)."""
+    """The launch-wide maxima of snapshot ``slot`` (th_range_read; waits for the work in front of the snapshot).
+    None when the snapshot has been overwritten by later ones (the ring holds the 8 most recent)."""
     global last_range
     out = (C.c_uint32 * 8)()
-    _check(load_library().th_range_read(ctx(device), int(slot), out))
+    rc = load_library().th_range_read(ctx(device), int(slot), out)
+    if rc == 2:
+        return None
+    _check(rc)
     last_range = list(out)
     return last_range
 
@@ -358,27 +388,34 @@ def range_epoch(device=None):
 
 def _guard(device, slot):
     """True when the snapshot is clean.  Otherwise the context has been switched to the fp32 path (and / or the
-    stem convolutions to the stock modules): the caller re-runs its work."""
-    global conv_fallback, vit_fallback
+    stem convolutions to the stock modules, TransHE to the fp32 GEMMs): the caller re-runs its work.  Every switch
+    bumps the device's epoch: the conv / TransHE slots are sticky and written by the stream that computes the NEXT
+    frames' constants, so an overflow of frame j+1 usually shows up in the snapshot of frame j -- frames whose
+    constants were built before the switch are recognised by their older epoch and rebuilt (render_sequence)."""
     if slot is None or slot < 0:
         return True
     vals = range_read(slot, device)
+    if vals is None:             # overwritten snapshot: the frame is unchecked -> render it again (its own snapshot is read at once)
+        return False
+    d = _dev_index(device)
     ok = True
-    if vals[7] >= RANGE_FP16_LIMIT and not vit_fallback:
+    if vals[7] >= RANGE_FP16_LIMIT and not _vit_fallback.get(d):
         import warnings
         warnings.warn("transhuman_amd: an operand of TransHE's dense layers left the fp16 range; using the fp32 MFMA "
-                      "GEMMs from now on", RuntimeWarning)
+                      "GEMMs until new weights are uploaded", RuntimeWarning)
         _check(load_library().th_set_vit_mode(ctx(device), 0))
-        vit_fallback = True
+        _vit_fallback[d] = True
+        _range_epoch[d] = _range_epoch.get(d, 0) + 1
         ok = False
-    if _conv_range_bad(vals) and not conv_fallback:
+    if _conv_range_bad(vals) and not _conv_fallback.get(d):
         import warnings
         warnings.warn("transhuman_amd: the ResNet-stem convolution input left the fp16 range; using the stock "
-                      "convolutions from now on", RuntimeWarning)
-        conv_fallback = True
+                      "convolutions until new weights are uploaded", RuntimeWarning)
+        _conv_fallback[d] = True
+        _range_epoch[d] = _range_epoch.get(d, 0) + 1
         ok = False
     why = range_verdict(vals)
-    if why is not None and not _range_fallback.get(_dev_index(device)):
+    if why is not None and not _range_fallback.get(d):
         _enter_fallback(device, why)
         ok = False
     return ok
@@ -562,7 +599,7 @@ _conv_cache = {}
 def conv2d_supported(conv):
     """True for the nn.Conv2d shapes th_conv2d is built for (the bias-free convolutions of the ResNet18 stem)."""
     ks, st, pd = conv.kernel_size, conv.stride, conv.padding
-    return (not conv_fallback and conv.bias is None and ks[0] == ks[1] and st[0] == st[1] and pd[0] == pd[1] == ks[0] // 2 and
+    return (not conv_fallback(conv.weight.device) and conv.bias is None and ks[0] == ks[1] and st[0] == st[1] and pd[0] == pd[1] == ks[0] // 2 and
             conv.groups == 1 and conv.dilation == (1, 1) and
             bool(load_library().th_conv2d_supported(conv.in_channels, conv.out_channels, ks[0], st[0])))
 
@@ -967,7 +1004,7 @@ def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_f
     if defer_guard:
         return rgb, acc, dep, st, (lambda: _guard(dev, slot))
     if not _guard(dev, slot):
-        if (conv_fallback or vit_fallback) and getattr(frame, "rebuild", None) is not None:
+        if (conv_fallback(dev) or vit_fallback(dev)) and getattr(frame, "rebuild", None) is not None:
             frame = frame.rebuild()                  # frame constants again, through the stock convolutions
             keep_sfr = fc.small_frame_rays
             fc = ThFrame.from_buffer_copy(frame.c)
@@ -994,7 +1031,7 @@ def eval_sigma_grid(net, frame, pts):
                                       _stream()))
         if _guard(p.device, int(stats[2])):
             break
-        if (conv_fallback or vit_fallback) and getattr(frame, "rebuild", None) is not None:
+        if (conv_fallback(p.device) or vit_fallback(p.device)) and getattr(frame, "rebuild", None) is not None:
             frame = frame.rebuild()
     return out, dict(valid_samples=stats[1])
 
@@ -1020,6 +1057,14 @@ def set_chunk_samples(n):
 
 
 PROF_PHASES = ("hull", "dparf", "gather", "mlp", "composite", "vit", "_6", "_7")
+
+
+def set_fused_gen(gen):
+    """th_set_fused_gen: 2 = mlp_fused2_kernel, 1 = the first-generation fused kernel; -> the previous value."""
+    lib = load_library()
+    old = int(lib.th_get_fused_gen())
+    _check(lib.th_set_fused_gen(int(gen)))
+    return old
 
 
 def profile_enable(on=True, device=None):

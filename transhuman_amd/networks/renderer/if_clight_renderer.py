@@ -190,13 +190,15 @@ class Renderer:
             grouped_ready = torch.cuda.Event()
             grouped_ready.record(cur)
             frame = mk_frame(None)
-            hip.render_pregather(self.net, frame, pts_pg, slot_pg)                  # K5 + K4 of the first chunks ...
             vs = self._dev.get(("vit_stream", str(dev)))
             if vs is None:
                 vs = self._dev[("vit_stream", str(dev))] = torch.cuda.Stream(dev)
-            with torch.cuda.stream(vs):                                            # ... TransHE beside them
+            # TransHE is ISSUED first (render_pregather waits on the host for the hull stage's sample count: the 63
+            # launches must not queue behind that wait); on the device it runs beside K5 + K4 of the first chunks
+            with torch.cuda.stream(vs):
                 vs.wait_event(grouped_ready)
                 tokens = self.net.ViT(grouped, self._pe_norm(V, dev), mask=None)    # :538
+            hip.render_pregather(self.net, frame, pts_pg, slot_pg)
             grouped.record_stream(vs)
             tokens.record_stream(cur)
             cur.wait_stream(vs)
@@ -316,6 +318,9 @@ class Renderer:
         def front(b, j, side):
             """side stream: hull stage of b's rays into workspace 1 + j % nslots (0 is render_fast's), then b's frame
             constants"""
+            # the range-guard epoch these constants are built under: a frame whose front was issued before the guard
+            # switched a path (fp32 MLP, stock convolutions, fp32 TransHE GEMMs) is rebuilt before it is handed out
+            ep = hip.range_epoch(b["ray_o"].device)
             with torch.cuda.stream(side):
                 pts = hip.Points(b["ray_o"][0][sl], b["ray_d"][0][sl], b["near"][0][sl], b["far"][0][sl],
                                  n_samples=cfg.N_samples)
@@ -326,7 +331,7 @@ class Renderer:
                 frame = self.prepare_frame(b, token_exchange=token_exchange, defer_tokens=split)
                 ready = torch.cuda.Event()
                 ready.record(side)
-            return [b, pts, frame, ready]
+            return [b, pts, frame, ready, ep]
 
         def tokens(ent, side):
             """side stream: piece B of an entry whose piece A has been issued"""
@@ -375,15 +380,15 @@ class Renderer:
         def finish(ent):
             rgb, acc, depth, stats, frame, cur, pts, check, epoch = ent
             if not check() or epoch != hip.range_epoch(dev):
-                if hip.conv_fallback or hip.vit_fallback:
-                    frame = frame.rebuild()
+                if hip.conv_fallback(dev) or hip.vit_fallback(dev):
+                    frame = frame.rebuild()                 # constants again, through the paths the guard switched to
                 rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
                                                          small_frame_rays=small_frame_rays)
             self.last_stats, self.last_frame, self.last_batch = stats, frame, cur
             return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
 
         while queue:
-            cur, pts, frame, ready = queue.popleft()
+            cur, pts, frame, ready, epoch = queue.popleft()
             main = torch.cuda.current_stream(dev)
             main.wait_event(ready)
             # everything queued so far (inputs of coming batches, the shading of the previous frame -- the last user
@@ -391,9 +396,10 @@ class Renderer:
             # this frame's shading is not
             fence = torch.cuda.Event()
             fence.record(main)
-            epoch = hip.range_epoch(dev)
-            # two-phase shading: the texture-path-bound producers (pixel gather, neighbour records) of ALL chunks first,
-            # then the fused MLP of all chunks.  The side stream's front of the next frame starts with this frame's
+            # two-phase shading: the texture-path-bound producers (pixel gather, neighbour records) of the frame's first
+            # TH_PRE_SETS = 5 chunks (2.6 M samples: the whole frame at the default sizes; each set costs V * 1536 B of
+            # workspace per sample of a chunk) first, then the fused MLP of all chunks (later chunks: producers and MLP
+            # alternate as in render_fast).  The side stream's front of the next frame starts with this frame's
             # shading: its ~130 small launches share the chip with the producers (which leave LDS / registers / the
             # matrix pipe free) instead of time-slicing with MLP tiles that own whole CUs.
             if os.environ.get("TH_PREGATHER") != "0":
@@ -412,7 +418,13 @@ class Renderer:
 
     def render(self, batch, is_train=True):
         """:486-498 -- no hull mask, every sample shaded, RGB everywhere.
-        Forward only (the HIP kernels carry no autograd)."""
+        Forward only: the HIP kernels carry no autograd.  The reference's trainer calls this entry with gradients
+        enabled and back-propagates through it (lib/train/trainers/if_nerf_clight.py:45, trainer.py:79-86); that use
+        is refused here instead of returning graph-less tensors whose loss.backward() dies with a generic message."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
+            raise RuntimeError("inference-only: transhuman_amd's Renderer.render runs hand-written HIP kernels without "
+                               "autograd -- wrap the call in torch.no_grad() (evaluation), or train with the reference "
+                               "renderer and load the checkpoint here (state_dict keys are identical)")
         cfg = get_cfg()
         self._check_sampling_options(cfg)
         frame = self.prepare_frame(batch, hull_thresh=-1.0)

@@ -233,40 +233,52 @@ def make_cameras(H, W, V=3, center=(0.0, 0.0, 3.0), dist=3.0, focal=None):
                 in_K=np.stack([K] * V), in_R=np.stack(Rs), in_T=np.stack(Ts))
 
 
-def get_rays(H, W, K, R, T):
-    """Restatement of /root/reference/lib/utils/if_nerf/if_nerf_data_utils.py:11-30."""
-    rays_o = -np.dot(R.T, T).ravel()
-    i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy")
-    xy1 = np.stack([i, j, np.ones_like(i)], axis=2)
-    pixel_camera = np.dot(xy1, np.linalg.inv(K).T)
-    pixel_world = np.dot(pixel_camera - T.ravel(), R)
-    rays_d = pixel_world - rays_o[None, None]
-    rays_o = np.broadcast_to(rays_o, rays_d.shape)
-    return rays_o, rays_d
+def pixel_rays(H, W, K, R, T):
+    """Origin and (un-normalised) direction of the ray through every pixel centre of an H x W pinhole camera with
+    x_cam = R x + T: the synthetic batch's stand-in for the data loader's ray set-up (the reference's is
+    lib/utils/if_nerf/if_nerf_data_utils.py:11-30; the hot-path version is csrc/k_rays.hip, K9).  The arithmetic
+    keeps that function's operation order (float32 pixel grid, float64 products), because tests/golden/* were
+    produced from batches made of these numbers."""
+    Kinv_t = np.linalg.inv(K).T
+    shift = T.ravel()
+    eye = -np.dot(R.T, T).ravel()
+    cols = np.arange(W, dtype=np.float32)
+    rows = np.arange(H, dtype=np.float32)
+    homog = np.empty((H, W, 3), np.float32)
+    homog[..., 0] = cols[None, :]
+    homog[..., 1] = rows[:, None]
+    homog[..., 2] = 1.0
+    world = np.dot(np.dot(homog, Kinv_t) - shift, R)
+    dirs = world - eye[None, None]
+    return np.broadcast_to(eye, dirs.shape), dirs
 
 
-def get_near_far(bounds, ray_o, ray_d):
-    """Restatement of if_nerf_data_utils.py:65-97 (box slab test, 'exactly two
-    hits' rule, |d|<1e-5 clamp, bounds +-0.01)."""
-    bounds = bounds + np.array([-0.01, 0.01])[:, None]
-    nominator = bounds[None] - ray_o[:, None]
-    ray_d = ray_d.copy()
-    ray_d[np.abs(ray_d) < 1e-5] = 1e-5
-    d_intersect = (nominator / ray_d[:, None]).reshape(-1, 6)
-    p_intersect = d_intersect[..., None] * ray_d[:, None] + ray_o[:, None]
-    min_x, min_y, min_z, max_x, max_y, max_z = bounds.ravel()
-    eps = 1e-6
-    m = (p_intersect[..., 0] >= (min_x - eps)) * (p_intersect[..., 0] <= (max_x + eps)) * \
-        (p_intersect[..., 1] >= (min_y - eps)) * (p_intersect[..., 1] <= (max_y + eps)) * \
-        (p_intersect[..., 2] >= (min_z - eps)) * (p_intersect[..., 2] <= (max_z + eps))
-    mask_at_box = m.sum(-1) == 2
-    p_intervals = p_intersect[mask_at_box][m[mask_at_box]].reshape(-1, 2, 3)
-    o = ray_o[mask_at_box]
-    d = ray_d[mask_at_box]
-    norm_ray = np.linalg.norm(d, axis=1)
-    d0 = np.linalg.norm(p_intervals[:, 0] - o, axis=1) / norm_ray
-    d1 = np.linalg.norm(p_intervals[:, 1] - o, axis=1) / norm_ray
-    return np.minimum(d0, d1), np.maximum(d0, d1), mask_at_box
+def box_interval(box, origin, direction):
+    """Entry / exit depth of every ray against the axis-aligned box `box` ([2,3]: min corner, max corner) grown by
+    1 cm, in units of |direction|, and the mask of rays that cross it (exactly two of the six face planes are met
+    inside the box, tolerance 1e-6; direction components below 1e-5 in magnitude are set to 1e-5 first).  Same rule
+    as the reference's data loader (if_nerf_data_utils.py:65-97), evaluated face by face."""
+    grown = box + np.array([-0.01, 0.01])[:, None]
+    direction = np.where(np.abs(direction) < 1e-5, 1e-5, direction)
+    lo, hi = grown[0] - 1e-6, grown[1] + 1e-6
+    length = np.linalg.norm(direction, axis=1)
+    n = origin.shape[0]
+    met = np.zeros((n, 6), bool)
+    depth = np.zeros((n, 6), np.float64)
+    for side in range(2):
+        for axis in range(3):
+            t = (grown[side, axis] - origin[:, axis]) / direction[:, axis]
+            point = t[:, None] * direction + origin
+            inside = np.ones(n, bool)
+            for a in range(3):
+                inside &= (point[:, a] >= lo[a]) & (point[:, a] <= hi[a])
+            k = 3 * side + axis
+            met[:, k] = inside
+            depth[:, k] = np.linalg.norm(point - origin, axis=1) / length
+    crosses = met.sum(1) == 2
+    near = np.where(met, depth, np.inf).min(1)[crosses]
+    far = np.where(met, depth, -np.inf).max(1)[crosses]
+    return near, far, crosses
 
 
 def smooth_noise(shape, seed, passes=2):
@@ -283,7 +295,7 @@ def smooth_noise(shape, seed, passes=2):
 # --------------------------------------------------------------------------
 # the batch dict
 # --------------------------------------------------------------------------
-def make_batch(H=64, W=64, V=3, seed=0, all_rays=True, dense=False, nv=NV, focal=None):
+def make_batch(H=64, W=64, V=3, seed=0, all_rays=True, dense=False, nv=NV, focal=None, dilate=3):
     """Synthetic ``batch`` with the reference's keys/shapes/dtypes (B=1).
 
     all_rays=True  : every pixel is a ray (benchmark convention, SURVEY 8d);
@@ -291,6 +303,10 @@ def make_batch(H=64, W=64, V=3, seed=0, all_rays=True, dense=False, nv=NV, focal
     dense=True     : 'S-dense' regime -- near/far of every ray clamped to a thin
                      slab hugging the front surface so (nearly) every sample of
                      hit rays lies inside the 0.1 m hull.
+    dilate         : (dense) radius in pixels within which a ray takes the depth of the nearest
+                     projected vertex.  With a long lens on the torso (focal=6000: the 512^2 window is
+                     0.26 m wide at the body) and dilate=64 EVERY ray gets such a slab: the
+                     "S-dense" frame of SURVEY 8d, all R x S samples valid.
     """
     verts_s, _ = make_body(seed, nv)                    # SMPL coords, posed
     blend = make_blend_mtx(verts_s, seed + 1)           # float64 [nv,4,4]
@@ -300,12 +316,12 @@ def make_batch(H=64, W=64, V=3, seed=0, all_rays=True, dense=False, nv=NV, focal
     # world2smpl is q=(p-Th)Rh  (if_clight_renderer.py:289-295)  => p=q Rh^-1+Th
     verts_w = (verts_s.astype(np.float64) @ np.linalg.inv(Rh.astype(np.float64)) + Th).astype(np.float32)
     cams = make_cameras(H, W, V, center=tuple(Th[0].tolist()), focal=focal)
-    ray_o, ray_d = get_rays(H, W, cams["K"], cams["R"], cams["T"])
+    ray_o, ray_d = pixel_rays(H, W, cams["K"], cams["R"], cams["T"])
     ray_o = ray_o.reshape(-1, 3).astype(np.float32)
     ray_d = ray_d.reshape(-1, 3).astype(np.float32)
     bmin, bmax = verts_w.min(0), verts_w.max(0)
     bounds = np.stack([bmin - 0.05, bmax + 0.05]).astype(np.float32)
-    near_b, far_b, at_box = get_near_far(bounds.astype(np.float64), ray_o.astype(np.float64), ray_d.astype(np.float64))
+    near_b, far_b, at_box = box_interval(bounds.astype(np.float64), ray_o.astype(np.float64), ray_d.astype(np.float64))
     R = ray_o.shape[0]
     if all_rays:
         near = np.full(R, float(Th[0, 2]) - 0.5, np.float32)
@@ -324,7 +340,7 @@ def make_batch(H=64, W=64, V=3, seed=0, all_rays=True, dense=False, nv=NV, focal
         py = np.round(uvw[:, 1] / uvw[:, 2]).astype(int).clip(0, H - 1)
         zbuf = np.full((H, W), np.inf)
         np.minimum.at(zbuf, (py, px), uvw[:, 2])
-        for _ in range(3):  # dilate
+        for _ in range(dilate):  # dilate
             z2 = zbuf.copy()
             for dy, dx in ((0, 1), (1, 0), (0, -1), (-1, 0)):
                 z2 = np.minimum(z2, np.roll(zbuf, (dy, dx), (0, 1)))
