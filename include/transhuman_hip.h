@@ -127,13 +127,6 @@ int th_range_last_slot(th_ctx* ctx);
  * batchify_rays chunk is 32768, if_clight_renderer.py:575).  Results do not depend on it; workspace
  * sizes do, so call it before the *_workspace_bytes() queries. */
 int th_set_chunk_samples(int n);
-/* Generation of the fused per-point MLP kernel (process-wide; same inputs, outputs and arithmetic):
- * 2 = mlp_fused2_kernel -- the pixel-feature rows are read once per tile (the RGB branch's products over them
- * are formed in the pixel branch), keys stay in registers, the rows' LDS staging runs under the key/value GEMMs;
- * 1 = mlp_fused_kernel of rounds 1-2.  The two are each other's in-GPU cross-check; the default is the faster one on the
- * headline frame, env TH_FUSED_GEN=1|2 overrides it.  th_get_fused_gen returns the current value. */
-int th_set_fused_gen(int gen);
-int th_get_fused_gen(void);
 int th_set_vit_weights(th_ctx* ctx, int depth, int dim, int heads, const th_vit_block* blocks,
                        const float* norm_w, const float* norm_b, th_stream stream);
 

@@ -30,7 +30,6 @@
 #include <string.h>
 
 #include "k_mlp_fused_kernel.h"
-#include "k_mlp_fused2_kernel.h"
 
 // ---- host: packing -------------------------------------------------------------------
 // cols[] gives, for every (wave, ct), the first output column of that 32-wide tile.
@@ -72,8 +71,8 @@ size_t th_fused_pack_bytes() {
     // every layer, both planes, K padded to 16 (+ biases / column tables / scratch in a 64 KiB tail)
     size_t halves = 0;
     const int dims[][2] = {{256, 64},  {256, 384}, {256, 272}, {384, 256}, {384, 256}, {256, 256}, {256, 256},
-                           {128, 256}, {128, 32},  {256, 384}, {256, 272}, {128, 128}, {128, 256}, {256, 256}};
-    // fc_0pe, ar0, ar0c, kv1, kv0, fc_2, fc_3, vfA, vfD, rst, rstc, fc_4, k0, v0
+                           {128, 256}, {128, 32},  {256, 384}, {256, 272}, {128, 128}};
+    // fc_0pe, ar0, ar0c, kv1, kv0, fc_2, fc_3, vfA, vfD, rst, rstc, fc_4
     for (auto& d : dims) halves += (size_t)d[0] * d[1] * 2 + 4096;
     return th_align(halves * 2) + 16 * 256 + 64 * 1024;
 }
@@ -289,14 +288,6 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
         TH_HIP(hipMemsetAsync(tb + 128, 0, 256 * 4, s));
         TH_TRY(layer_scale_log2(tw, 384LL * 256, amax, &sl2, s));
         TH_TRY(pack_layer(tw, tb, 384, 256, 3, ckv, sl2, cur, which == 0 ? &out->kv1 : &out->kv0, s));
-        if (which == 1) {
-            // the same layer once more as a key image (one column tile per wave) and a value image (two): the
-            // second-generation kernel runs the pixel branch's keys and values as separate passes (same scale, same bias rows)
-            int cv[8];
-            for (int wv = 0; wv < 4; ++wv) { cv[wv * 2] = 128 + wv * 64; cv[wv * 2 + 1] = 128 + wv * 64 + 32; }
-            TH_TRY(pack_layer(tw, tb, 384, 256, 1, c128, sl2, cur, &out->k0, s));
-            TH_TRY(pack_layer(tw, tb, 384, 256, 2, cv, sl2, cur, &out->v0, s));
-        }
     }
     // folded bias of fc_1 (fc_1 itself lives inside the value projections)
     hipLaunchKernelGGL(fold_bias_kernel, dim3(1), dim3(256), 0, s, w->fc_1.w, w->fc_1.b, w->val1.b, w->val0.b, cur.bias);
@@ -351,17 +342,6 @@ int th_tok_split(float* tprime, int rows, float* sc, unsigned int* range, hipStr
     return 0;
 }
 
-#ifndef TH_FUSED_GEN_DEFAULT
-#define TH_FUSED_GEN_DEFAULT 1
-#endif
-static int g_fused_gen = getenv("TH_FUSED_GEN") ? (getenv("TH_FUSED_GEN")[0] == '2' ? 2 : 1) : TH_FUSED_GEN_DEFAULT;
-extern "C" int th_get_fused_gen(void) { return g_fused_gen; }
-extern "C" int th_set_fused_gen(int gen) {
-    TH_REQUIRE(gen == 1 || gen == 2, "th_set_fused_gen: 1 (mlp_fused_kernel) or 2 (mlp_fused2_kernel)");
-    g_fused_gen = gen;
-    return 0;
-}
-
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all, float* raw_c,
                          unsigned int* range, hipStream_t s, const void* tsplit, const float* t_inv, int t_nc) {
@@ -380,16 +360,11 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     if (!attr) {
 #define FM_ATTR(V_, F_)                                                                                       \
     TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<V_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                               FUSED_LDS_BYTES));                                                             \
-    TH_HIP(hipFuncSetAttribute((const void*)mlp_fused2_kernel<V_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                               FUSED2_LDS_BYTES))
+                               FUSED_LDS_BYTES))
         FM_ATTR(1, 0); FM_ATTR(2, 0); FM_ATTR(3, 0); FM_ATTR(1, 1); FM_ATTR(2, 1); FM_ATTR(3, 1);
 #undef FM_ATTR
         attr = true;
     }
-    // kernel generation: 2 (default) = mlp_fused2_kernel (f read once, keys in registers, staging under the GEMMs),
-    // TH_FUSED_GEN=1 = mlp_fused_kernel (kept as the in-GPU cross-check of the rewrite)
-    const int gen = g_fused_gen;
     dim3 grid(th_cdiv(P, FM_PTS));
     // developer experiment (timing only, results are wrong): alias every layer's weights onto fc_1's image
     // so the weight working set is 256 KB -> shows how much of a phase is L2-capacity/latency
@@ -408,11 +383,7 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
         TH_HIP(hipMemsetAsync(dbg_dev, 0, 64 * sizeof(long long), s));
         p.dbg = dbg_dev;
     }
-#define FM_LAUNCH(V_, F_)                                                                                    \
-    do {                                                                                                     \
-        if (gen == 2) hipLaunchKernelGGL((mlp_fused2_kernel<V_, F_>), grid, dim3(256), FUSED2_LDS_BYTES, s, p); \
-        else hipLaunchKernelGGL((mlp_fused_kernel<V_, F_>), grid, dim3(256), FUSED_LDS_BYTES, s, p);         \
-    } while (0)
+#define FM_LAUNCH(V_, F_) hipLaunchKernelGGL((mlp_fused_kernel<V_, F_>), grid, dim3(256), FUSED_LDS_BYTES, s, p)
     switch (V * 2 + (cf ? 1 : 0)) {
         case 2: FM_LAUNCH(1, 0); break;
         case 3: FM_LAUNCH(1, 1); break;

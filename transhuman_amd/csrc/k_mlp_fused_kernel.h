@@ -144,23 +144,6 @@ __device__ __forceinline__ void stage_glds(const _Float16* __restrict__ src, int
     }
 }
 
-// LDS-DMA issued as raw ISA.  The compiler's wait-count pass treats every LDS read behind a __builtin LDS-DMA load as
-// possibly aliasing it (one LDS object, no alias scopes): an LDS-only barrier or a ds_read between the request and
-// the phase that consumes the data is given s_waitcnt vmcnt(0), i.e. nothing can run UNDER a staging burst.  A load
-// issued from inline asm is invisible to that pass: work that touches other LDS regions proceeds, and the consumer
-// side waits explicitly (fm_dma_wait_barrier).  vmcnt returns in order and the compiler's own counts ignore these
-// loads, so a wait for a load issued BEFORE a DMA request and consumed after it also waits for (most of) the DMA loads
-// behind it: consume older loads first.  (m0 is written without being declared: the compiler sets it anew in front of every
-// use of its own and never holds a value in it across statements.)
-__device__ __forceinline__ void fm_dma16(const void* g, const void* lds_wave_base) {
-    const unsigned l = (unsigned)(size_t)(fm_lptr)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(l) : "memory");
-}
-// every outstanding memory operation of this wave (DMA included) has completed, then the workgroup meets
-__device__ __forceinline__ void fm_dma_wait_barrier() {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // ---- GEMM phase ---------------------------------------------------------------------------------------
 template <int RT, int STR, int ROWSTEP>
 __device__ __forceinline__ void load_xfrag(const char* __restrict__ ahi, const char* __restrict__ alo, int aoff, int kb,
@@ -247,9 +230,6 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[CT][RT]) {
 }
 
 struct FmNoStamp { __device__ __forceinline__ void operator()() const {} };
-// per-step hook of a GEMM phase (called behind the scheduling region of ring step `kb + J`): the second-generation kernel
-// issues LDS-DMA requests for a LATER phase from here
-struct FmNoHook { template <int J> __device__ __forceinline__ void step(int) {} };
 
 // Weight ring of a GEMM phase.  A wave's dwordx4 load costs the CU's address unit ~16 cycles whatever it hits, so the
 // D-1 blocks a steady-state ring keeps in flight are NOT requested up front (3 x 2*CT loads x 4 waves = 1.1 k cycles
@@ -271,10 +251,10 @@ __device__ __forceinline__ void ring_prefetch(const uint4* __restrict__ wp, int 
 }
 
 // one ring step: request block kb+j+D-1 (weights; RAMP: blocks 1 .. D-1) and kb+j+1 (activations), multiply block kb+j
-template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int FIRST, int J, bool RAMP, class HK = FmNoHook>
+template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int FIRST, int J, bool RAMP>
 __device__ __forceinline__ void ring_step(const char* __restrict__ ahi, const char* __restrict__ alo, const uint4* __restrict__ wl,
                                           int aoff, int kb, int KB, uint4 (&w)[D][CT][2], h8 (&xh)[2][RT], h8 (&xl)[2][RT],
-                                          f32x16 (&acc)[CT][RT], HK& hook) {
+                                          f32x16 (&acc)[CT][RT]) {
     constexpr int j = J;
     // branch-free (indices clamped: the last blocks re-request a fragment nobody consumes) so that
     // the prefetch and the MFMA burst form ONE scheduling region, then ask for one memory
@@ -321,36 +301,13 @@ __device__ __forceinline__ void ring_step(const char* __restrict__ ahi, const ch
         }
     }
     FM_SB();
-    hook.template step<J>(kb);
 }
 
-template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int FIRST, bool RAMP, class HK, int... Js>
+template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int FIRST, bool RAMP, int... Js>
 __device__ __forceinline__ void ring_round(std::integer_sequence<int, Js...>, const char* __restrict__ ahi,
                                            const char* __restrict__ alo, const uint4* __restrict__ wl, int aoff, int kb, int KB,
-                                           uint4 (&w)[D][CT][2], h8 (&xh)[2][RT], h8 (&xl)[2][RT], f32x16 (&acc)[CT][RT], HK& hook) {
-    (ring_step<RT, CT, STR, ROWSTEP, D, XPP, (Js == 0 ? FIRST : 0), Js, (RAMP && Js == 0), HK>(ahi, alo, wl, aoff, kb, KB, w, xh, xl, acc, hook), ...);
-}
-
-template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, class HK, int... Js>
-__device__ __forceinline__ void gemm_tail(std::integer_sequence<int, Js...>, const char* __restrict__ ahi, const char* __restrict__ alo,
-                                          int aoff, int kb, int KB, uint4 (&w)[D][CT][2], h8 (&xh)[2][RT], h8 (&xl)[2][RT],
-                                          f32x16 (&acc)[CT][RT], HK& hook) {
-    (([&]() __attribute__((always_inline)) {
-         constexpr int j = Js;
-         if (kb + j < KB) {
-             if (XPP) {
-                 if (kb + j + 1 < KB) load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j + 1, xh[(j + 1) & 1], xl[(j + 1) & 1]);
-                 FM_SB();
-                 mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
-             } else {
-                 load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, xh[0], xl[0]);
-                 mfma_kblock<RT, CT>(w[j], xh[0], xl[0], acc);
-             }
-             FM_SB();
-             hook.template step<j>(kb);
-         }
-     }()),
-     ...);
+                                           uint4 (&w)[D][CT][2], h8 (&xh)[2][RT], h8 (&xl)[2][RT], f32x16 (&acc)[CT][RT]) {
+    (ring_step<RT, CT, STR, ROWSTEP, D, XPP, (Js == 0 ? FIRST : 0), Js, (RAMP && Js == 0)>(ahi, alo, wl, aoff, kb, KB, w, xh, xl, acc), ...);
 }
 
 //  * ZMASK (bit c = column tile c): those tiles are acc = W * A^T, the others accumulate.  The first MFMA of a ZMASK
@@ -358,10 +315,10 @@ __device__ __forceinline__ void gemm_tail(std::integer_sequence<int, Js...>, con
 //  * RAMP (KB >= D): the first ring round is peeled out of the loop: it carries the ZMASK MFMAs and the ring ramp-up.
 //    Without it (KB < D) the phase is the up-front prefetch plus the tail.
 //  * PRE: the caller has already requested block 0 (ring_prefetch0) / the first D-1 blocks (ring_prefetch, !RAMP).
-template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int ZMASK, bool PRE, bool RAMP, class ST, class HK>
-__device__ __forceinline__ void gemm_phase_core_h(const char* __restrict__ ahi, const char* __restrict__ alo,
-                                                  const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT],
-                                                  uint4 (&w)[D][CT][2], ST stamp, HK& hook) {
+template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int ZMASK, bool PRE, bool RAMP = true, class ST = FmNoStamp>
+__device__ __forceinline__ void gemm_phase_core(const char* __restrict__ ahi, const char* __restrict__ alo,
+                                                const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT],
+                                                uint4 (&w)[D][CT][2], ST stamp = ST()) {
     static_assert((D & 1) == 0, "ring depth must be even (activation ping-pong parity)");
     static_assert(RAMP || ZMASK == 0, "zero-start tiles need the peeled first round");
     const uint4* wl = wp + lane;     // this wave's stream: per kb: CT x {hi, lo} x 64 lanes x 16 B
@@ -376,23 +333,27 @@ __device__ __forceinline__ void gemm_phase_core_h(const char* __restrict__ ahi, 
     stamp();
     int kb = 0;
     if (RAMP) {
-        ring_round<RT, CT, STR, ROWSTEP, D, XPP, ZMASK, true, HK>(std::make_integer_sequence<int, D>{}, ahi, alo, wl, aoff, 0, KB, w, xh, xl, acc, hook);
+        ring_round<RT, CT, STR, ROWSTEP, D, XPP, ZMASK, true>(std::make_integer_sequence<int, D>{}, ahi, alo, wl, aoff, 0, KB, w, xh, xl, acc);
         kb = D;
     }
 #pragma unroll 1
     for (; kb + D <= KB; kb += D)
-        ring_round<RT, CT, STR, ROWSTEP, D, XPP, 0, false, HK>(std::make_integer_sequence<int, D>{}, ahi, alo, wl, aoff, kb, KB, w, xh, xl, acc, hook);
+        ring_round<RT, CT, STR, ROWSTEP, D, XPP, 0, false>(std::make_integer_sequence<int, D>{}, ahi, alo, wl, aoff, kb, KB, w, xh, xl, acc);
     stamp();
     // tail (KB % D blocks): their weight fragments were requested by the clamped loads above
-    gemm_tail<RT, CT, STR, ROWSTEP, D, XPP, HK>(std::make_integer_sequence<int, D - 1>{}, ahi, alo, aoff, kb, KB, w, xh, xl, acc, hook);
-}
-
-template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, int ZMASK, bool PRE, bool RAMP = true, class ST = FmNoStamp>
-__device__ __forceinline__ void gemm_phase_core(const char* __restrict__ ahi, const char* __restrict__ alo,
-                                                const uint4* __restrict__ wp, int KB, int lane, f32x16 (&acc)[CT][RT],
-                                                uint4 (&w)[D][CT][2], ST stamp = ST()) {
-    FmNoHook nohook;
-    gemm_phase_core_h<RT, CT, STR, ROWSTEP, D, XPP, ZMASK, PRE, RAMP, ST, FmNoHook>(ahi, alo, wp, KB, lane, acc, w, stamp, nohook);
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j)
+        if (kb + j < KB) {
+            if (XPP) {
+                if (kb + j + 1 < KB) load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j + 1, xh[(j + 1) & 1], xl[(j + 1) & 1]);
+                FM_SB();
+                mfma_kblock<RT, CT>(w[j], xh[j & 1], xl[j & 1], acc);
+            } else {
+                load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, xh[0], xl[0]);
+                mfma_kblock<RT, CT>(w[j], xh[0], xl[0], acc);
+            }
+            FM_SB();
+        }
 }
 
 template <int RT, int CT, int STR, int ROWSTEP, int D, bool XPP, bool ZERO, bool RAMP = true>
@@ -421,7 +382,7 @@ __device__ __forceinline__ void gemm_phase_z(const char* __restrict__ ahi, const
 // fc_3 alone re-uses every weight fragment on ONE row tile: its 256 KB of weights per tile ask for 85 B/clk/CU
 // of L2 bandwidth and the phase took 11 k cycles for 3 k cycles of MFMA issue.  Interleaved with the (MFMA-heavy,
 // 3 row tiles per fragment) view_fc product the pair streams 6 KB of weights per 15 MFMAs per wave (50 B/clk/CU).
-template <int V, bool VA_ACC = false>     // VA_ACC: va continues a running sum (the caller's accumulators) instead of starting at 0
+template <int V>
 __device__ __forceinline__ void gemm_dual_fc3_vfa(const char* __restrict__ mhi, const char* __restrict__ mlo,
                                                   const char* __restrict__ xhi, const char* __restrict__ xlo,
                                                   const uint4* __restrict__ w3, const uint4* __restrict__ wa, int lane,
@@ -473,8 +434,7 @@ __device__ __forceinline__ void gemm_dual_fc3_vfa(const char* __restrict__ mhi, 
 #pragma unroll
                 for (int r = 0; r < V; ++r) {
                     va[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&ra[j][0][wp]),
-                                                                      xlo ? xl[j & 1][r] : xh[j & 1][r],
-                                                                      (first && !VA_ACC) ? zero : va[0][r], 0, 0, 0);
+                                                                      xlo ? xl[j & 1][r] : xh[j & 1][r], first ? zero : va[0][r], 0, 0, 0);
                     if (r == 0)
                         a3[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const h8*>(&r3[j][1][wp]),
                                                                           xlo ? ml[j & 1][0] : mh[j & 1][0], first ? zero : a3[1][0], 0, 0, 0);
@@ -908,10 +868,8 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         FM_STAMP();
 #endif
         {
-            // (the value tiles are finished in place: the compiler sinks these FMAs to their use in the attention combine
-            // anyway -- an explicit deferred form, scale and summed biases applied there, changed nothing but the live ranges)
-            const BiasT bk = load_bias(P.kv1.bias, wave * 32, lane);
-            const BiasT bv0 = load_bias(P.kv1.bias, 128 + wave * 64, lane), bv1 = load_bias(P.kv1.bias, 128 + wave * 64 + 32, lane);
+            const BiasT bk = load_bias(P.kv1.bias, wave * 32, lane), bv0 = load_bias(P.kv1.bias, 128 + wave * 64, lane),
+                        bv1 = load_bias(P.kv1.bias, 128 + wave * 64 + 32, lane);
             FM_SB();
             finish_tile_b<V>(acc3[0], bk, P.kv1.inv_scale, false);
             finish_tile_b<V>(acc3[1], bv0, P.kv1.inv_scale, false);
@@ -965,8 +923,8 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         gemm_phase_core<V, 3, STR256, 32 * STR256, FM_RING_D, true, 7, true>(abuf, a256_lo, wslice(P.kv0, wave, 3, 0), P.kv0.KB, lane,
                                                                             acc3, wk3);
         {
-            const BiasT bk = load_bias(P.kv0.bias, wave * 32, lane);
-            const BiasT bv0 = load_bias(P.kv0.bias, 128 + wave * 64, lane), bv1 = load_bias(P.kv0.bias, 128 + wave * 64 + 32, lane);
+            const BiasT bk = load_bias(P.kv0.bias, wave * 32, lane), bv0 = load_bias(P.kv0.bias, 128 + wave * 64, lane),
+                        bv1 = load_bias(P.kv0.bias, 128 + wave * 64 + 32, lane);
             FM_SB();
             finish_tile_b<V>(acc3[0], bk, P.kv0.inv_scale, false);
             finish_tile_b<V>(acc3[1], bv0, P.kv0.inv_scale, false);
@@ -986,7 +944,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     // ================= cross-view attention (cross_transformer.py:128-149) =================
     {
         const float* kpb = reinterpret_cast<const float*>(abuf);
-        BiasT bn[2] = {load_bias(P.fc_1.bias, wave * 64, lane), load_bias(P.fc_1.bias, wave * 64 + 32, lane)};
+        const BiasT bn[2] = {load_bias(P.fc_1.bias, wave * 64, lane), load_bias(P.fc_1.bias, wave * 64 + 32, lane)};
         // A[j][i] = kp_j . ks_i / sqrt(128).  Thread (p = tid >> 3, c8 = tid & 7) owns float4 columns c8, c8 + 8,
         // c8 + 16, c8 + 24 of sample p (8 lanes read 128 contiguous bytes of a key row): it loads the V pixel-branch
         // and the V token-branch keys once, forms all V*V partial products, and the 8 partials of a sample are
@@ -1223,9 +1181,12 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         ring_prefetch0<2, FM_RING_D2>(wslice(P.rst, wave, 2, 0), lane, wk2);
         FM_SB();
         gemm_phase_core<V, 1, STRVD, 0, FM_RING_D2, true, 0, true, false>(vd_hi, vd_lo, wslice(P.vfD, wave, 1, 0), 2, lane, vf, wvd);   // KB < D
+#pragma unroll
+        for (int r = 0; r < V; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc2[1][r][e] = 0.f;
         FM_SYNC();
-        // (column tile 1 = rgb_res_1 starts from the inline constant 0; tile 0 continues the view_fc sums)
-        gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 2, true>(abuf, fa_lo, wslice(P.rst, wave, 2, 0), FL::NA, lane, acc2, wk2);
+        gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 0, true>(abuf, fa_lo, wslice(P.rst, wave, 2, 0), FL::NA, lane, acc2, wk2);
 #ifdef FM_STAMPS
         FM_STAMP();
 #endif

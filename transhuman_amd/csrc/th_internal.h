@@ -247,7 +247,6 @@ struct FusedParams {
     // stacked along out_f (K 384, on f): column tile 0 accumulates onto vfA / vfD, tile 1 is rgb_res_1
     FusedLayer vfA, vfD, rst;
     FusedLayer ar0c, rstc;         // colour-folded (K = 272) forms; the launcher copies them over ar0 / rst
-    FusedLayer k0, v0;             // kv0's key tile (CT 1) and value tiles (CT 2) as separate images (mlp_fused2_kernel: two passes)
     bool compact_ready;
     const float *alpha_w, *alpha_b, *rgb_w, *rgb_b;
     // token branch, written by K4 in TH_ROWS_FOLDED form: the neighbour blend of T' = tokens W_tok^T (fp32) and

@@ -67,8 +67,6 @@ SYMBOLS = {
     "th_range_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "th_range_last_slot": (C.c_int, [C.c_void_p]),
     "th_set_chunk_samples": (C.c_int, [C.c_int]),
-    "th_set_fused_gen": (C.c_int, [C.c_int]),
-    "th_get_fused_gen": (C.c_int, []),
     "th_set_vit_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(ThVitBlock), C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "th_linear_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
@@ -1057,14 +1055,6 @@ def set_chunk_samples(n):
 
 
 PROF_PHASES = ("hull", "dparf", "gather", "mlp", "composite", "vit", "_6", "_7")
-
-
-def set_fused_gen(gen):
-    """th_set_fused_gen: 2 = mlp_fused2_kernel, 1 = the first-generation fused kernel; -> the previous value."""
-    lib = load_library()
-    old = int(lib.th_get_fused_gen())
-    _check(lib.th_set_fused_gen(int(gen)))
-    return old
 
 
 def profile_enable(on=True, device=None):
