@@ -15,7 +15,7 @@ def main():
     d = sys.argv[1]
     vals = {}
     for path in sorted(glob.glob(f"{d}/pass_*_counter_collection.csv")):
-        p = path.split("pass_")[1][0]
+        p = path.split("pass_")[1].split("_")[0]
         rows = list(csv.DictReader(open(path)))
         if not rows:
             continue
@@ -45,6 +45,15 @@ def main():
     if g("SQ_LDS_BANK_CONFLICT") and g("SQ_LDS_IDX_ACTIVE"):
         print(f"#          LDS bank-conflict cycles / LDS active cycles = "
               f"{100.0 * g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE'):.1f} %")
+    if g("TCC_HIT_sum") and g("TCC_MISS_sum"):
+        print(f"#          L2 hit rate = {100.0 * g('TCC_HIT_sum') / (g('TCC_HIT_sum') + g('TCC_MISS_sum')):.1f} % of "
+              f"{g('TCC_REQ_sum', 0):.3e} requests per launch")
+    if g("TCP_TCC_READ_REQ_sum") and g("TCP_TCC_READ_REQ_LATENCY_sum"):
+        print(f"#          L1 -> L2 read latency = {g('TCP_TCC_READ_REQ_LATENCY_sum') / g('TCP_TCC_READ_REQ_sum'):.0f} cycles "
+              f"(average over {g('TCP_TCC_READ_REQ_sum'):.3e} requests)")
+    if g("FETCH_SIZE") and g("WRITE_SIZE"):
+        print(f"#          HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE = {(2 * g('FETCH_SIZE') + g('WRITE_SIZE')) * 1024 / 1e9:.3f} GB "
+              f"(KB counters; gfx950 correction of MI355X_MICROARCH.md)")
     if g("SQ_INSTS_MFMA"):
         print(f"#          instructions per launch: MFMA {g('SQ_INSTS_MFMA'):.3e}, VALU {g('SQ_INSTS_VALU', 0):.3e}, "
               f"SALU {g('SQ_INSTS_SALU', 0):.3e}")
