@@ -41,7 +41,7 @@ sys.path.insert(0, ROOT)
 
 from transhuman_amd import synth                                    # noqa: E402
 from transhuman_amd.config import get_cfg                           # noqa: E402
-from transhuman_amd.dist import shard_ray_indices, gather_image, ImageGatherer, DeferredSum, TokenExchange   # noqa: E402
+from transhuman_amd.dist import shard_ray_indices, gather_image, ImageGatherer, DeferredSum, TokenExchange, StemExchange   # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12        # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 SIGMA_BIAS = -1.7
@@ -457,9 +457,14 @@ def main():
     # TransHE is not replicated: frame j's tokens are computed by rank j % world and broadcast (1.15 MB) from the
     # side stream, two collectives ahead of their use (transhuman_amd/dist.py TokenExchange)
     tokens_x = TokenExchange() if dist_on else (TokenExchange(emulate=(emu, args.emulate_rank)) if emu else None)
+    # ... and from 4 ranks on the ResNet stem too: its low-resolution latents (69 MB) are broadcast, the 0.82 GB map is
+    # still built locally (dist.StemExchange; TH_STEM_EXCHANGE=0|1 overrides)
+    stem_x = None
+    if (dist_on or emu) and StemExchange.wanted(emu or world):
+        stem_x = StemExchange() if dist_on else StemExchange(emulate=(emu, args.emulate_rank))
     seq = None if args.no_pipeline else renderer.render_sequence(itertools.repeat(shard),
                                                                   small_frame_rays=-1 if sharded else 2400,
-                                                                  token_exchange=tokens_x)
+                                                                  token_exchange=tokens_x, stem_exchange=stem_x)
 
     # The reference's R' <= 2400 switch (if_clight_renderer.py:551) looks at the WHOLE frame.  Shards are rendered in the
     # (overwhelmingly common) masked mode; the per-rank hit-ray counts th_render_rays reports anyway are summed with an
@@ -499,6 +504,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         img, stats = step()
+    host_dt = time.perf_counter() - t0             # the host is done queueing here (the device may still be working)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -545,6 +551,7 @@ def main():
                 "rays": R, "hit_rays_rank0": stats["hit_rays"], "valid_samples_rank0": n_valid,
                 "sigma_pos_samples_rank0": n_pos, "parallelism": f"ray-tile x{world}" if world > 1 else "single",
                 "frame_pipeline": "off" if seq is None else "constants(i+1) on a 2nd HIP stream under shading(i)",
+                "stem_exchange": stem_x is not None,
             },
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
                                        mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos)),
@@ -554,6 +561,7 @@ def main():
             # patterns of max |x| per split tensor: f, s, p, n, inter, fc4_in; fp32 bits: conv_in; fp16: vit_in)
             "range_guard": dict(hip.guard_state(dev), fallback=bool(hip.guard_state(dev)["mlp_fp32_fallback"]),
                                 slots=[int(x) for x in (hip.last_range or [])]),
+            "host_queue_ms_per_step": host_dt / max(args.steps, 1) * 1e3,      # python + launch calls; == ms_per_step: host-bound
             "stage_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
             "stage_note": "HIP-event spans per stage; with the frame pipeline hull / vit run on the side stream under the "
                           "other stages (their spans are stretched by the overlap and do not add to the frame time)",

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from transhuman_amd.dist import ImageGatherer, DeferredSum, TokenExchange, gather_image, shard_ray_indices, _tile_skew
+from transhuman_amd.dist import ImageGatherer, DeferredSum, TokenExchange, StemExchange, gather_image, shard_ray_indices, _tile_skew
 
 
 def _free_port():
@@ -65,6 +65,26 @@ def _worker(rank, world, port, H, W, q):
             ok = ok and torch.equal(tok, want_tok)
             ok = ok and torch.equal(ga(full[idx2] * (fr + 1.0)), full * (fr + 1.0))
         ok = ok and calls == [fr for fr in range(2 * world + 1) if fr % world == rank] and tx.computed == len(calls)
+        # the encoder stem sharded over the frames as well (its own communicator, owner staggered by world // 2): every rank
+        # receives the owner's three latents, interleaved with the token exchange and the image gather like in a frame
+        sx = StemExchange()
+        tx2 = TokenExchange()
+        stem_calls = []
+        imgs = torch.zeros(3, 3, 16, 24)
+        shapes = StemExchange.latent_shapes(3, 16, 24)
+        ok = ok and shapes == [(3, 64, 8, 12), (3, 64, 4, 6), (3, 128, 2, 3)]
+        for fr in range(2 * world + 1):
+            def trunk(x, fr=fr):
+                stem_calls.append(fr)
+                return [torch.full(sh, float(fr) + 0.25 * k) + (rank + 1) for k, sh in enumerate(shapes)]
+            lat = sx.latents(trunk, imgs)
+            own = (fr + world // 2) % world
+            ok = ok and all(tuple(l.shape) == sh and bool((l == float(fr) + 0.25 * k + own + 1).all())
+                            for k, (l, sh) in enumerate(zip(lat, shapes)))
+            tok = tx2(lambda fr=fr: torch.full((3, 7, 192), float(fr) + rank), (3, 7, 192), torch.device("cpu"))
+            ok = ok and bool((tok == float(fr) + fr % world).all())
+            ok = ok and torch.equal(ga(full[idx2] * (fr + 1.0)), full * (fr + 1.0))
+        ok = ok and stem_calls == [fr for fr in range(2 * world + 1) if (fr + world // 2) % world == rank]
         # mesh workload: voxel runs of 4096 dealt to the ranks (bench.py run_secondary), sigma gathered back
         g = 32
         nvox = g * g * g
@@ -141,3 +161,22 @@ def test_token_exchange_emulation_counts_the_owned_frames():
             assert tok.shape == (1, 2, 192)
         owned = [fr for fr in range(17) if fr % world == rank]
         assert calls == ([0] if rank != 0 else []) + owned
+
+
+def test_stem_exchange_emulation_and_switch(monkeypatch):
+    """emulation: the stem is computed for the frames this rank owns only (owner staggered by world // 2); the default is
+    off below 4 ranks, TH_STEM_EXCHANGE overrides"""
+    world, rank = 8, 3
+    sx = StemExchange(emulate=(world, rank))
+    shapes = StemExchange.latent_shapes(1, 32, 32)
+    calls = []
+    for fr in range(20):
+        lat = sx.latents(lambda x, fr=fr: (calls.append(fr), [torch.zeros(sh) for sh in shapes])[1], torch.zeros(1, 3, 32, 32))
+        assert [tuple(l.shape) for l in lat] == shapes
+    assert calls == [0] + [fr for fr in range(1, 20) if (fr + 4) % 8 == 3]      # (frame 0: nothing to re-use yet)
+    monkeypatch.delenv("TH_STEM_EXCHANGE", raising=False)
+    assert not StemExchange.wanted(2) and StemExchange.wanted(4) and StemExchange.wanted(8)
+    monkeypatch.setenv("TH_STEM_EXCHANGE", "0")
+    assert not StemExchange.wanted(8)
+    monkeypatch.setenv("TH_STEM_EXCHANGE", "1")
+    assert StemExchange.wanted(2)

@@ -23,8 +23,9 @@ def _free_port():
     return p
 
 
-def _run(n, path, res, extra=()):
+def _run(n, path, res, extra=(), env_extra=None):
     env = dict(os.environ, TH_SAVE_IMAGE=path, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(env_extra or {})
     if n == 1:
         cmd = [sys.executable, "bench.py", "--res", str(res)] + ARGS + list(extra)
     else:
@@ -53,6 +54,17 @@ def test_two_and_three_rank_frames_equal_the_single_rank_frame(tmp_path, res):
 
 
 @pytest.mark.gpu
+def test_stem_exchange_frames_equal_the_single_rank_frame(tmp_path):
+    """dist.StemExchange forced on (it is off below 4 ranks by default): the ResNet stem of frame j runs on one rank, its
+    three latents are broadcast from the side stream next to the token broadcast, every rank builds the map locally --
+    the gathered frames of 2- and 3-rank jobs equal the single-rank frame"""
+    one = _run(1, str(tmp_path / "n1.npy"), 128)
+    for n in (2, 3):
+        img = _run(n, str(tmp_path / f"s{n}.npy"), 128, env_extra={"TH_STEM_EXCHANGE": "1"})
+        assert one.shape == img.shape and float(np.abs(one[:, :4] - img[:, :4]).max()) < 2e-6, (n, float(np.abs(one - img).max()))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("workload,extra", [("orbit", ()), ("mesh", ("--grid", "48"))])
 def test_secondary_workloads_two_ranks(tmp_path, workload, extra):
     """C3 (orbit along gen_path_virt, rays generated on device, pixel tiles dealt to the ranks) and C5 (sigma grid, voxel
@@ -72,7 +84,7 @@ def test_one_rank_job_over_rccl_equals_the_plain_frame(tmp_path):
     every ray tile in ascending order, so the gathered frame is the plain frame bit for bit."""
     one = _run(1, str(tmp_path / "n1.npy"), 128)
     env = dict(os.environ, TH_SAVE_IMAGE=str(tmp_path / "rccl.npy"), TH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1",
-               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", TH_STEM_EXCHANGE="1")      # (+ the latent broadcast)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "TH_DIST_BACKEND", "TH_ONE_GPU"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, "bench.py", "--res", "128"] + ARGS, cwd=ROOT, env=env, capture_output=True,

@@ -391,33 +391,52 @@ static int conv1_launch(const float* x, const uint4* wp, float inv_scale, float*
 }
 
 // ---- max pooling 3x3 / 2, padding 1 (resnet.maxpool), NCHW ---------------------------------------------------------------
+// One thread = 4 consecutive outputs of a row: their 3 x 9 input window is read as two float4 and one scalar per input row
+// (the one-output-per-thread form issued 9 stride-2 scalar loads per output: 143 us for the stem's 3 x 64 planes of 256^2,
+// a kernel that moves 63 MB).  Same comparisons in the same order per output (max is exact: order-free anyway).
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restrict__ x, int H, int W, int Ho, int Wo,
-                                                           long long total, float* __restrict__ y) {
+                                                           long long total4, float* __restrict__ y) {
     const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int ox = (int)(i % Wo);
-    const long long t = i / Wo;
+    if (i >= total4) return;
+    const int Wq = (Wo + 3) >> 2;
+    const int q = (int)(i % Wq);
+    const long long t = i / Wq;
     const int oy = (int)(t % Ho);
     const long long plane = t / Ho;
     const float* p = x + plane * H * W;
-    float m = -3.4028235e38f;
+    const int ox0 = 4 * q, gx0 = 2 * ox0;                       // window columns gx0 - 1 .. gx0 + 7
+    const bool fast = (W & 3) == 0 && gx0 + 8 <= W;
+    float m[4] = {-3.4028235e38f, -3.4028235e38f, -3.4028235e38f, -3.4028235e38f};
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
         const int gy = 2 * oy - 1 + dy;
         if (gy < 0 || gy >= H) continue;
+        const float* r = p + (long long)gy * W;
+        float v[9];
+        if (fast) {
+            const float4 a = *reinterpret_cast<const float4*>(r + gx0), b = *reinterpret_cast<const float4*>(r + gx0 + 4);
+            v[0] = gx0 > 0 ? r[gx0 - 1] : -3.4028235e38f;
+            v[1] = a.x; v[2] = a.y; v[3] = a.z; v[4] = a.w; v[5] = b.x; v[6] = b.y; v[7] = b.z; v[8] = b.w;
+        } else {
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-            const int gx = 2 * ox - 1 + dx;
-            if (gx >= 0 && gx < W) m = fmaxf(m, p[(long long)gy * W + gx]);
+            for (int k = 0; k < 9; ++k) {
+                const int gx = gx0 - 1 + k;
+                v[k] = (gx >= 0 && gx < W) ? r[gx] : -3.4028235e38f;
+            }
         }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) m[o] = fmaxf(m[o], fmaxf(fmaxf(v[2 * o], v[2 * o + 1]), v[2 * o + 2]));
     }
-    y[i] = m;
+    float* dst = y + (plane * Ho + oy) * (long long)Wo + ox0;
+    if ((Wo & 3) == 0) *reinterpret_cast<float4*>(dst) = make_float4(m[0], m[1], m[2], m[3]);
+    else
+        for (int o = 0; o < 4 && ox0 + o < Wo; ++o) dst[o] = m[o];
 }
 
 int th_maxpool3x3s2_launch(const float* x, int planes, int H, int W, float* y, hipStream_t s) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long long total = (long long)planes * Ho * Wo;
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)th_cdiv(total, 256)), dim3(256), 0, s, x, H, W, Ho, Wo, total, y);
+    const long long total4 = (long long)planes * Ho * ((Wo + 3) / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3((unsigned)th_cdiv(total4, 256)), dim3(256), 0, s, x, H, W, Ho, Wo, total4, y);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -820,7 +820,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     if (ray_mode) {
         // hit-ray count, the R' <= 2400 rule (:551) and the compaction in one chain (no_hull: threshold R makes the
         // rule fire -> un-masked mode, rgb for all samples)
-        TH_TRY(th_view_embed_launch(ps.ray_d, R, 4, vd_all, s));
+        TH_TRY(th_view_embed_launch(ps.ray_d, R, 4, vd_all, s, ray_hit));      // (behind the hull test: hit rays only)
         TH_TRY(th_compact_mask_rule(mask, P, ray_hit, R, S, no_hull ? R : f->small_frame_rays, info, idx, info + 2, cws,
                                     cws_b, s));
     } else {
@@ -846,7 +846,6 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         t.npre = 0;
         if (!can_pre || n <= 0) return 0;
         const bool grid = getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
-        if (grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s));
         // K4 of every chunk on the context's second stream, K5 of every chunk on `s`: the two producers share nothing but
         // the sample list -- K5 sits on the texture path (TA busy 80-90 %, VALU 43 %), K4 since TH_ROWS_NBR is a 7-NN scan
         // out of LDS (no row gather) -- so their waves co-reside on the CUs instead of running back to back
@@ -863,6 +862,8 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
             TH_HIP(hipStreamWaitEvent(c->aux, c->aux_fork, 0));
             s4 = c->aux;
         }
+        // (the candidate grid of the 7-NN scan is K4's alone: built on K4's stream, not in front of the pixel gather)
+        if (grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s4));
         int k = 0;
         {
             ProfScope ps1(pf, TH_PROF_DPARF, s4);
@@ -910,7 +911,9 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     const float* table = nullptr;
     if (n > 0) TH_TRY(token_table(c, f->tokens, V, f->n_clusters, tprime, &table, s));
     // exact candidate grid for the 7-NN scan of K4 (TH_DPARF_NOGRID=1: full scan, same result)
-    const bool use_grid = n > 0 && prepass != 1 && getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
+    // (not needed when every chunk's records were pre-gathered: K4 does not run again)
+    const bool use_grid = n > 0 && prepass != 1 && (long long)npre * CH < n && getenv("TH_DPARF_NOGRID") == nullptr &&
+                          (size_t)f->n_clusters * 4 <= 48 * 1024;
     if (use_grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s));
     for (int o = 0, kc = 0; o < n; o += CH, ++kc) {
         int m = (n - o) < CH ? (n - o) : CH;

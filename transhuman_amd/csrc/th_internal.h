@@ -403,7 +403,7 @@ int th_scatter_raw_launch(const float* raw_c, const int32_t* sel, int P, int rgb
 // mask (optional, uint8 per sample): raw is only read where mask != 0, elsewhere it counts as zero
 int th_composite_launch(const float* raw, const float* z, const ThPointSrc& ps, int white, float* rgb, float* acc,
                         float* depth, float* wout, const uint8_t* mask, hipStream_t s, const int32_t* ray_hit = nullptr);
-int th_view_embed_launch(const float* d, int R, int res, float* out, hipStream_t s);
+int th_view_embed_launch(const float* d, int R, int res, float* out, hipStream_t s, const int32_t* hit = nullptr);
 // k_vit.hip
 size_t th_vit_ws(int V, int N, int dim, int heads);
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,

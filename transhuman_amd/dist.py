@@ -141,8 +141,9 @@ class TokenExchange:
     ``emulate=(world, rank)`` (one GPU, no process group): the owner test is applied, non-owned frames re-use the
     last tokens this rank computed -- the per-rank WORK of an N-rank job for timing, not its image."""
 
-    def __init__(self, world=None, rank=None, group=None, emulate=None):
+    def __init__(self, world=None, rank=None, group=None, emulate=None, shift=0):
         self.emulate = emulate
+        self.shift = int(shift)     # owner of frame j = (j + shift) % world: a second exchange (StemExchange) is staggered
         if emulate is not None:
             self.world, self.rank = emulate
             self.group = None
@@ -156,7 +157,7 @@ class TokenExchange:
         self._last = None
 
     def owner(self, j):
-        return j % self.world
+        return (j + self.shift) % self.world
 
     def __call__(self, compute, shape, device, dtype=torch.float32):
         """tokens of the next frame: ``compute()`` on the owner, a receive buffer elsewhere, then the broadcast"""
@@ -178,6 +179,58 @@ class TokenExchange:
         import torch.distributed as dist
         dist.broadcast(tok, src=self.owner(j), group=self.group)
         return tok
+
+
+class StemExchange(TokenExchange):
+    """The ResNet stem of SpatialEncoder (encoder.py:114-126: 31 GFLOP of convolutions + ten train-mode BatchNorms, 0.5 ms
+    on one MI355X) computed by ONE rank per frame as well: its output, the three low-resolution latents ([V,64,H/2,W/2],
+    [V,64,H/4,W/4], [V,128,H/8,W/8]: 69 MB at V = 3, 512^2), is 12 times smaller than the 0.82 GB map built from it, so
+    every rank keeps the (local, 0.3 ms) upsample / concat and receives the latents.  Same protocol as TokenExchange (own
+    communicator, issued from the side stream a frame or two ahead of use); the owner is staggered by half the world size so
+    that a rank does not own the stem and TransHE of the same frame.
+    What it buys is an ESTIMATE until a multi-GPU node has run it: at N = 8 a rank's frame is 3.5 ms of which the replicated
+    stem is 0.5 ms of chip time on 7 frames in 8; the broadcast moves 69 MB per frame and rank (21 GB/s inbound at 3.2 ms per
+    frame, against 7 xGMI links of ~153 GB/s) from a stream of its own.  Off below 4 ranks (the stem is a small share of a
+    rank's frame there); TH_STEM_EXCHANGE=0 | 1 overrides.
+    Side effect: the stem's BatchNorm running statistics advance only on the owner of a frame (they do not enter the
+    train()-mode forward the renderer runs, run.py:29)."""
+
+    def __init__(self, world=None, rank=None, group=None, emulate=None):
+        w = emulate[0] if emulate is not None else (world if world is not None else None)
+        if w is None:
+            import torch.distributed as dist
+            w = dist.get_world_size()
+        super().__init__(world, rank, group, emulate, shift=w // 2)
+
+    @staticmethod
+    def wanted(world):
+        import os
+        e = os.environ.get("TH_STEM_EXCHANGE")
+        return (e == "1") if e in ("0", "1") else world >= 4
+
+    @staticmethod
+    def latent_shapes(V, H, W):
+        h1, w1 = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1          # conv1 7x7 / 2, padding 3
+        h2, w2 = (h1 + 2 - 3) // 2 + 1, (w1 + 2 - 3) // 2 + 1        # maxpool 3x3 / 2, padding 1 (layer1 keeps the size)
+        h3, w3 = (h2 + 2 - 3) // 2 + 1, (w2 + 2 - 3) // 2 + 1        # layer2: 3x3 / 2, padding 1
+        return [(V, 64, h1, w1), (V, 64, h2, w2), (V, 128, h3, w3)]
+
+    def latents(self, trunk, images):
+        """-> [lat0, lat1, lat2] of ``images`` ([V,3,H,W]): ``trunk(images)`` on the owner of this frame, received elsewhere"""
+        V, _, H, W = images.shape
+        shapes = self.latent_shapes(V, H, W)
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes]
+
+        def compute():
+            lat = trunk(images)
+            assert [tuple(l.shape) for l in lat] == shapes, "unexpected latent shapes"
+            return torch.cat([l.reshape(-1) for l in lat])
+        flat = self(compute, (sum(sizes),), images.device)
+        out, o = [], 0
+        for sh, n in zip(shapes, sizes):
+            out.append(flat[o:o + n].view(sh))
+            o += n
+        return out
 
 
 class DeferredSum:

@@ -102,7 +102,7 @@ class Renderer:
 
     # ---- per-frame constants ---------------------------------------------------------
     def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True, token_exchange=None,
-                      pregather=None, defer_tokens=False):
+                      pregather=None, defer_tokens=False, stem_exchange=None):
         """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
 
         fused_encoder_tail=True (default): the ResNet stem runs through SpatialEncoder.trunk (K12 / K11), its tail
@@ -119,6 +119,8 @@ class Renderer:
         All forms give the same tokens / pixels to fp32 rounding (tests/test_gpu_parity.py).
         token_exchange (multi-GPU, transhuman_amd.dist.TokenExchange): callable(compute, shape, device) that either
         runs ``compute`` (paint -> group -> TransHE) here or receives the tokens from the rank that did.
+        stem_exchange (multi-GPU, transhuman_amd.dist.StemExchange): the ResNet stem runs on one rank per frame and its
+        three low-resolution latents (69 MB) are broadcast; the upsample / concat into the 0.82 GB map stays local.
         pregather=(points, slot) (render_fast, behind its hull prepass): the pixel-feature gather and the neighbour
         records of the frame's first chunks (hip.render_pregather: they need the map and the token centres, not the
         tokens) are queued on the current stream and TransHE runs BESIDE them on a second stream instead of in front.
@@ -139,7 +141,7 @@ class Renderer:
         if fused_encoder_tail and hasattr(enc, "trunk"):
             H, W = images.shape[2:]
             V = images.shape[0]
-            lat = enc.trunk(images)
+            lat = enc.trunk(images) if stem_exchange is None else stem_exchange.latents(enc.trunk, images)
             cw, cb = enc.upsample_color.weight, enc.upsample_color.bias
             if compact_map == "interleaved":            # A/B: one [V,H,W,260] tensor (1040-byte texel rows)
                 map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2])
@@ -282,7 +284,8 @@ class Renderer:
             img = gatherer(cat(out))
         return img
 
-    def render_sequence(self, batches, ray_slice=None, small_frame_rays=2400, lookahead=1, token_exchange=None):
+    def render_sequence(self, batches, ray_slice=None, small_frame_rays=2400, lookahead=1, token_exchange=None,
+                        stem_exchange=None):
         """A stream of frames (free-viewpoint video / evaluation loops: the reference calls render_fast once per
         dataset item, run.py:96-118) as a two-stage software pipeline on two HIP streams:
 
@@ -299,7 +302,8 @@ class Renderer:
         of the one being shaded; the iterator is advanced with the side stream current, so device work it issues
         for a coming frame (ray generation, SMPL skinning, uploads) also runs under the shading of the current one.
         ``token_exchange`` (transhuman_amd.dist.TokenExchange, multi-GPU): TransHE of frame j runs on rank j % world
-        only and its tokens are broadcast from the side stream."""
+        only and its tokens are broadcast from the side stream; ``stem_exchange`` (dist.StemExchange): the same for the
+        encoder stem's latents."""
         import collections
         cfg = get_cfg()
         self._check_sampling_options(cfg)
@@ -328,7 +332,7 @@ class Renderer:
                 if V <= 4 and pts.R > 0:
                     hip.render_prepass(pts, b["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
                                        n_clusters=len(self.csr_offsets) - 1, slot=1 + j % nslots)
-                frame = self.prepare_frame(b, token_exchange=token_exchange, defer_tokens=split)
+                frame = self.prepare_frame(b, token_exchange=token_exchange, defer_tokens=split, stem_exchange=stem_exchange)
                 ready = torch.cuda.Event()
                 ready.record(side)
             return [b, pts, frame, ready, ep]
