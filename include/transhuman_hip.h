@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 4
+#define TH_ABI_VERSION 5
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -198,6 +198,21 @@ int th_upsample_concat_nhwc(th_ctx* ctx, const float* img, const float* lat0, co
 /* the compact map in the TH_MAP_SPLIT layout: out = [V,H,W,256] latents followed by [V,H,W,4] (r, g, b, 0) */
 int th_upsample_concat_split(th_ctx* ctx, const float* img, const float* lat0, const float* lat1, const float* lat2,
                              const int32_t* dims_host, int V, int H, int W, float* out, th_stream stream);
+/* Cropped map.  The reference builds pixel_feat_map over the whole image (encoder.py:133-146) and then samples it only
+ * at points within hull_thresh of a target vertex (if_clight_renderer.py:440-444 -> :210-269) and at the projected input
+ * vertices (:168-172).  th_map_box computes, per view, the texel box [x0,y0,x1,y1] (inclusive, box_out: device int32
+ * [V][4]) that contains every texel such a gather can read: the projections of the eight corners of the axis-aligned cube
+ * of half-width `reach` around every vertex of verts_a [na,3] and verts_b [nb,3] (world space; u, v are linear-fractional,
+ * so their extrema over a cube in front of the camera sit at corners), in the texel coordinates of grid_sample
+ * (align_corners=True, scale_xy as in th_pixel_gather), widened by two texels and clamped to the image (border padding
+ * clamps monotonically); the whole image for a view with a cube corner at or behind its camera plane.
+ * th_upsample_concat_split_box writes only the 64-texel spans of `out` that meet the box (box == NULL: everything); the
+ * rest of `out` stays as it was.  No host synchronisation: the box lives on the device. */
+int th_map_box(th_ctx* ctx, const float* verts_a, int na, const float* verts_b, int nb, const float* cams, int V,
+               const float* scale_xy, int H, int W, float reach, int32_t* box_out, th_stream stream);
+int th_upsample_concat_split_box(th_ctx* ctx, const float* img, const float* lat0, const float* lat1, const float* lat2,
+                                 const int32_t* dims_host, int V, int H, int W, float* out, const int32_t* box,
+                                 th_stream stream);
 /* paint_neural_human + can_body_grouping without materialising holder_feat_map: reduction_layer
  * (1x1 conv C->out_f, encoder.py:85,146) commutes with the bilinear sampling at :168-172, so the C-channel
  * channels-last map is sampled at the projected vertices and the layer is applied to those V*n_verts
@@ -356,6 +371,20 @@ int th_smpl_lbs(th_ctx* ctx, const th_smpl_model* model, const float* pose_aa, c
 int th_view_embed(th_ctx* ctx, const float* ray_d, int R, int view_res, float* out, th_stream stream);
 
 /* ---- frame-level entry points -------------------------------------------------- */
+/* What a cropped TH_MAP_SPLIT map was made from (host struct, device pointers; everything must stay alive as long as the
+ * frame is used).  The frame-level entry points write the rest of the map themselves -- on their stream, in front of the
+ * gather -- when a call leaves the crop's premise: the un-masked branch (R' <= small_frame_rays shades EVERY sample of
+ * the hit rays), hull_thresh < 0 (no hull test) or hull_thresh > reach. */
+typedef struct {
+    const int32_t* box;            /* device [V][4], th_map_box                */
+    float          reach;          /* the reach the box was computed with      */
+    const float*   img;            /* arguments of th_upsample_concat_split    */
+    const float*   lat0;
+    const float*   lat1;
+    const float*   lat2;
+    int32_t        dims[6];
+} th_map_source;
+
 /* Per-frame constants produced by th_paint_group / th_vit_forward / the
  * segment means, consumed by the per-sample stage. */
 typedef struct {
@@ -375,6 +404,7 @@ typedef struct {
     int          n_clusters;
     float        hull_thresh;      /* 0.1                                     */
     int          small_frame_rays; /* 2400: R' <= this -> un-masked branch    */
+    const th_map_source* map_source; /* NULL: pixel_map_nhwc is complete; else it is cropped to map_source->box */
 } th_frame;
 
 /* Renderer.render_fast :429-484 incl. _render/batchify_rays/raw2outputs for a

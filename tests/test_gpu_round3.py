@@ -153,3 +153,92 @@ def test_training_entry_refuses_autograd(hip, gpu, net):
     with torch.no_grad():
         out = r.render(b)
     assert out["rgb_map"].shape == (1, 256, 3) and torch.isfinite(out["rgb_map"]).all()
+
+
+def _texel_use(b, frame, pts_world, H, W):
+    """per view the (x, y) texel indices a bilinear gather at pts_world reads (torch restatement of grid_sample's
+    align_corners=True / border coordinates, fp64)"""
+    R, T, K = (b[k][0][0].double().cpu() for k in ("input_R", "input_T", "input_K"))
+    sc = frame.scale.double().cpu()
+    p = pts_world.double().cpu()
+    out = []
+    for v in range(R.shape[0]):
+        cam = p @ R[v].T + T[v].reshape(1, 3)
+        uvw = cam @ K[v].T
+        u, w = uvw[:, 0] / uvw[:, 2], uvw[:, 1] / uvw[:, 2]
+        ix = (u * sc[0] / 2 * (W - 1)).clamp(0, W - 1)
+        iy = (w * sc[1] / 2 * (H - 1)).clamp(0, H - 1)
+        out.append((ix.floor(), (ix.floor() + 1).clamp(max=W - 1), iy.floor(), (iy.floor() + 1).clamp(max=H - 1)))
+    return out
+
+
+@pytest.mark.parametrize("focal,hw", [(600.0, (512, 512)), (150.0, (64, 48))])
+def test_cropped_map_holds_every_texel_the_frame_reads(hip, gpu, net, focal, hw):
+    """prepare_frame writes only the per-view texel box within reach of the hull (th_map_box).  (1) inside the box the map
+    equals the complete map bit for bit; (2) the box contains every texel read by the gather of every hull-valid sample
+    of a full frame and by the painting of the input vertices; (3) tokens and images are the complete map's."""
+    r = _renderer(net, 300, samples=32 if hw[0] < 512 else 64)
+    H, W = hw
+    bc = synth.make_batch(H, W, 3, seed=0, all_rays=True, focal=focal)
+    b = synth.batch_to(bc, gpu)
+    f_crop = r.prepare_frame(b)
+    g_crop = r.last_grouped.clone()
+    f_full = r.prepare_frame(b, crop_map=False)
+    assert f_crop.map.box is not None and f_full.map.box is None and torch.equal(g_crop, r.last_grouped)
+    assert torch.equal(f_crop.tokens, f_full.tokens)
+    box = f_crop.map.box.cpu().numpy()
+    lat_c, lat_f, rgb_c, rgb_f = f_crop.map.latents, f_full.map.latents, f_crop.map.rgb0, f_full.map.rgb0
+    area = 0
+    for v in range(3):
+        x0, y0, x1, y1 = (int(t) for t in box[v])
+        assert 0 <= x0 <= x1 <= W - 1 and 0 <= y0 <= y1 <= H - 1
+        assert torch.equal(lat_c[v, y0:y1 + 1, x0:x1 + 1], lat_f[v, y0:y1 + 1, x0:x1 + 1])
+        assert torch.equal(rgb_c[v, y0:y1 + 1, x0:x1 + 1], rgb_f[v, y0:y1 + 1, x0:x1 + 1])
+        area += (x1 - x0 + 1) * (y1 - y0 + 1)
+    if focal == 600.0:
+        assert area < 0.6 * 3 * H * W                       # the crop is worth something on the headline frame
+    # every valid sample's corner texels and the painted vertices' lie inside the box
+    S = get_cfg_samples()
+    pts = hip.Points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], n_samples=S)
+    mask, hit = hip.hull_mask(pts, b["tar_smpl_vertice"][0])
+    t = torch.linspace(0.0, 1.0, S, device=gpu)
+    z = b["near"][0][:, None] * (1.0 - t) + b["far"][0][:, None] * t
+    world = (b["ray_o"][0][:, None] + b["ray_d"][0][:, None] * z[..., None]).reshape(-1, 3)[mask.reshape(-1).bool()]
+    assert world.shape[0] > 1000
+    for cloud in (world, b["input_smpl_vertice"][0][0].reshape(-1, 3)):
+        for v, (xa, xb, ya, yb) in enumerate(_texel_use(b, f_crop, cloud, H, W)):
+            x0, y0, x1, y1 = (int(q) for q in box[v])
+            assert xa.min() >= x0 and xb.max() <= x1 and ya.min() >= y0 and yb.max() <= y1, (v, box[v])
+    a = r.render_fast(b, frame=f_crop)
+    c = r.render_fast(b, frame=f_full)
+    assert r.last_stats["valid_samples"] > 1000
+    for k in ("rgb_map", "acc_map", "depth_map"):
+        assert torch.equal(a[k], c[k]), k
+
+
+def get_cfg_samples():
+    from transhuman_amd.config import get_cfg
+    return int(get_cfg().N_samples)
+
+
+def test_cropped_map_is_completed_for_the_unmasked_branch(hip, gpu, net):
+    """R' <= 2400 hit rays: the reference shades EVERY sample of those rays (:551), also the ones far outside the hull,
+    whose texels a cropped map does not hold -- the C side writes the rest of the map first (th_frame.map_source).  Same
+    for a frame rendered without a hull test (Renderer.render under no_grad builds an un-cropped map)."""
+    r = _renderer(net, 300, samples=32)
+    bc = synth.make_batch(48, 48, 3, seed=0, all_rays=True)
+    b = synth.batch_to(bc, gpu)
+    f_crop = r.prepare_frame(b)
+    f_full = r.prepare_frame(b, crop_map=False)
+    box = f_crop.map.box.cpu().numpy()
+    assert any((bx[2] - bx[0] + 1) * (bx[3] - bx[1] + 1) < 48 * 48 for bx in box)     # a real crop
+    a = r.render_fast(b, frame=f_crop)
+    st = dict(r.last_stats)
+    c = r.render_fast(b, frame=f_full)
+    assert st["unmasked"] == 1 and 0 < st["hit_rays"] <= 2400
+    for k in ("rgb_map", "acc_map", "depth_map"):
+        assert torch.equal(a[k], c[k]), k
+    assert torch.equal(f_crop.map.interleaved(), f_full.map.interleaved())      # ... and the map is complete now
+    with torch.no_grad():
+        out = r.render(b)
+    assert torch.isfinite(out["rgb_map"]).all()

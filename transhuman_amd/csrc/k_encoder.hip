@@ -41,11 +41,16 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
                                                                    const float* __restrict__ wc,
                                                                    const float* __restrict__ bc, int H, int W,
                                                                    int NG, int CO, float* __restrict__ out,
-                                                                   float* __restrict__ rgb4) {
+                                                                   float* __restrict__ rgb4,
+                                                                   const int32_t* __restrict__ box) {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane, y = blockIdx.y;
     const int v = blockIdx.z / NG, grp = blockIdx.z % NG;
+    if (box != nullptr) {               // cropped map (map_box_kernel): 64-pixel spans outside the view's box are not written
+        const int bx0 = box[4 * v], by0 = box[4 * v + 1], bx1 = box[4 * v + 2], by1 = box[4 * v + 3];
+        if (y < by0 || y > by1 || (int)blockIdx.x * 64 + 63 < bx0 || (int)blockIdx.x * 64 > bx1) return;
+    }
     int cout0;
     if (grp == 4 && NG == 5) {          // compact map: channels 256..259 = r, g, b, 0 (one float4 per pixel)
         if (wave == 0 && x < W) {
@@ -91,14 +96,84 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
 
 int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
                               const int* dims /* h0,w0,h1,w1,h2,w2 */, int V, int H, int W, const float* wc,
-                              const float* bc, float* out, hipStream_t s, int split) {
+                              const float* bc, float* out, hipStream_t s, int split, const int32_t* box) {
     UpsSrc s0{lat0, 64, dims[0], dims[1], 0};
     UpsSrc s1{lat1, 64, dims[2], dims[3], 64};
     UpsSrc s2{lat2, 128, dims[4], dims[5], 128};
     const int NG = wc ? 6 : 5, CO = wc ? 384 : (split ? 256 : 260);
     float* rgb4 = (!wc && split) ? out + (long long)V * H * W * 256 : nullptr;
     hipLaunchKernelGGL(upsample_concat_nhwc_kernel, dim3(th_cdiv(W, 64), H, V * NG), dim3(256), 0, s, s0, s1, s2, img, wc,
-                       bc, H, W, NG, CO, out, rgb4);
+                       bc, H, W, NG, CO, out, rgb4, box);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+// The part of a view's map the per-sample stage can touch.  Every point it gathers at lies within `reach` of a vertex
+// (hull-valid samples: within hull_thresh of a target vertex, if_clight_renderer.py:440-444; painting: the input
+// vertices themselves), i.e. inside the axis-aligned cube of half-width `reach` around that vertex.  u = px / pz and
+// v = py / pz are linear-fractional in the point, so over a cube that lies in front of the camera (pz > 0 at its eight
+// corners) their extrema sit at corners: the box of the projected corners of all cubes, in map texel coordinates (the
+// expression of th_bilinear_setup), widened by two texels for the second bilinear corner and fp32 rounding, contains
+// every texel those gathers read.  Border clamping is monotone, so clamping the box to the image keeps that true.  A cube
+// that reaches behind a camera makes that view's box the whole image.  One workgroup per view.
+__global__ __launch_bounds__(1024) void map_box_kernel(const float* __restrict__ va, int na, const float* __restrict__ vb,
+                                                       int nb, const float* __restrict__ cams,
+                                                       const float* __restrict__ scale, int H, int W, float reach,
+                                                       int32_t* __restrict__ box) {
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const float* cam = cams + 21 * v;
+    float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+    bool bad = false;
+    for (int i = tid; i < na + nb; i += 1024) {
+        const float* p = i < na ? va + 3 * i : vb + 3 * (i - na);
+        const float x = p[0], y = p[1], z = p[2];
+        for (int k = 0; k < 8; ++k) {
+            const float qx = x + ((k & 1) ? reach : -reach), qy = y + ((k & 2) ? reach : -reach),
+                        qz = z + ((k & 4) ? reach : -reach);
+            const float cx = fmaf(cam[2], qz, fmaf(cam[1], qy, cam[0] * qx)) + cam[9];
+            const float cy = fmaf(cam[5], qz, fmaf(cam[4], qy, cam[3] * qx)) + cam[10];
+            const float cz = fmaf(cam[8], qz, fmaf(cam[7], qy, cam[6] * qx)) + cam[11];
+            const float* K = cam + 12;
+            const float pz = fmaf(K[8], cz, fmaf(K[7], cy, K[6] * cx));
+            float u, w;
+            th_project(cam, qx, qy, qz, u, w);
+            const float ix = ((u * scale[0] - 1.0f + 1.0f) / 2.0f) * (float)(W - 1);
+            const float iy = ((w * scale[1] - 1.0f + 1.0f) / 2.0f) * (float)(H - 1);
+            if (!(pz > 1e-6f) || !(fabsf(ix) < 1.0e9f) || !(fabsf(iy) < 1.0e9f)) bad = true;
+            xmin = fminf(xmin, ix); xmax = fmaxf(xmax, ix);
+            ymin = fminf(ymin, iy); ymax = fmaxf(ymax, iy);
+        }
+    }
+    __shared__ float red[4][16];
+    __shared__ int sbad;
+    if (tid == 0) sbad = 0;
+    __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+        ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    }
+    if (bad) atomicOr(&sbad, 1);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = xmin; red[1][tid >> 6] = xmax; red[2][tid >> 6] = ymin; red[3][tid >> 6] = ymax; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) {
+            xmin = fminf(xmin, red[0][w]); xmax = fmaxf(xmax, red[1][w]);
+            ymin = fminf(ymin, red[2][w]); ymax = fmaxf(ymax, red[3][w]);
+        }
+        int x0 = 0, y0 = 0, x1 = W - 1, y1 = H - 1;
+        if (!sbad && na + nb > 0) {
+            const float fx0 = fminf(fmaxf(floorf(xmin) - 2.0f, 0.0f), (float)(W - 1));
+            const float fx1 = fminf(fmaxf(floorf(xmax) + 3.0f, 0.0f), (float)(W - 1));
+            const float fy0 = fminf(fmaxf(floorf(ymin) - 2.0f, 0.0f), (float)(H - 1));
+            const float fy1 = fminf(fmaxf(floorf(ymax) + 3.0f, 0.0f), (float)(H - 1));
+            x0 = (int)fx0; x1 = (int)fx1; y0 = (int)fy0; y1 = (int)fy1;
+        }
+        box[4 * v] = x0; box[4 * v + 1] = y0; box[4 * v + 2] = x1; box[4 * v + 3] = y1;
+    }
+}
+int th_map_box_launch(const float* va, int na, const float* vb, int nb, const float* cams, int V, const float* scale, int H,
+                      int W, float reach, int32_t* box, hipStream_t s) {
+    hipLaunchKernelGGL(map_box_kernel, dim3(V), dim3(1024), 0, s, va, na, vb, nb, cams, scale, H, W, reach, box);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -392,7 +392,23 @@ int th_segment_mean_rot_f64(th_ctx* c, const double* blend, const int32_t* off, 
 int th_upsample_concat_split(th_ctx* c, const float* img, const float* lat0, const float* lat1, const float* lat2,
                              const int32_t* dims_host, int V, int H, int W, float* out, th_stream stream) {
     TH_REQUIRE(c && img && lat0 && lat1 && lat2 && dims_host && out, "null argument");
-    return th_upsample_concat_launch(img, lat0, lat1, lat2, dims_host, V, H, W, nullptr, nullptr, out, (hipStream_t)stream, 1);
+    return th_upsample_concat_launch(img, lat0, lat1, lat2, dims_host, V, H, W, nullptr, nullptr, out, (hipStream_t)stream, 1,
+                                     nullptr);
+}
+
+int th_upsample_concat_split_box(th_ctx* c, const float* img, const float* lat0, const float* lat1, const float* lat2,
+                                 const int32_t* dims_host, int V, int H, int W, float* out, const int32_t* box,
+                                 th_stream stream) {
+    TH_REQUIRE(c && img && lat0 && lat1 && lat2 && dims_host && out, "null argument");
+    return th_upsample_concat_launch(img, lat0, lat1, lat2, dims_host, V, H, W, nullptr, nullptr, out, (hipStream_t)stream, 1,
+                                     box);
+}
+
+int th_map_box(th_ctx* c, const float* verts_a, int na, const float* verts_b, int nb, const float* cams, int V,
+               const float* scale_xy, int H, int W, float reach, int32_t* box_out, th_stream stream) {
+    TH_REQUIRE(c && cams && scale_xy && box_out && (verts_a || na == 0) && (verts_b || nb == 0), "null argument");
+    TH_REQUIRE(V > 0 && H > 0 && W > 0 && na >= 0 && nb >= 0 && reach >= 0.f, "bad sizes");
+    return th_map_box_launch(verts_a, na, verts_b, nb, cams, V, scale_xy, H, W, reach, box_out, (hipStream_t)stream);
 }
 
 int th_upsample_concat_nhwc(th_ctx* c, const float* img, const float* lat0, const float* lat1, const float* lat2,
@@ -401,7 +417,7 @@ int th_upsample_concat_nhwc(th_ctx* c, const float* img, const float* lat0, cons
     TH_REQUIRE(c && img && lat0 && lat1 && lat2 && dims_host && out_nhwc, "null argument");
     TH_REQUIRE(color_w == nullptr || color_b != nullptr, "color_b is required with color_w");
     return th_upsample_concat_launch(img, lat0, lat1, lat2, dims_host, V, H, W, color_w, color_b, out_nhwc,
-                                     (hipStream_t)stream);
+                                     (hipStream_t)stream, 0, nullptr);
 }
 
 size_t th_paint_group_nhwc_workspace_bytes(int V, int n_verts, int C, int out_f) {
@@ -839,6 +855,16 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     }
     const int hit_rays = hp[0], unmasked = hp[1], n = hp[2];
     if (stats_host) { stats_host[0] = hit_rays; stats_host[1] = n; stats_host[2] = -1; stats_host[3] = unmasked; }
+    // A cropped map (th_frame.map_source) holds the texels within reach of the hull only.  The un-masked branch (:551,
+    // R' <= small_frame_rays: every sample of the hit rays is shaded), a frame without a hull test and a hull test wider
+    // than the crop's reach gather outside it: the rest of the map is written first (same values inside the box).
+    if (f->map_source != nullptr && prepass != 1 && n > 0 &&
+        (unmasked || f->hull_thresh < 0.f || f->hull_thresh > f->map_source->reach)) {
+        const th_map_source* ms = f->map_source;
+        TH_REQUIRE(f->map_channels == TH_MAP_SPLIT && ms->img && ms->lat0 && ms->lat1 && ms->lat2, "map_source: split map only");
+        TH_TRY(th_upsample_concat_launch(ms->img, ms->lat0, ms->lat1, ms->lat2, ms->dims, V, f->H, f->W, nullptr, nullptr,
+                                         const_cast<float*>(f->pixel_map_nhwc), s, 1, nullptr));
+    }
     const bool can_pre = ray_mode && tok_gather(c, V) && fmt == TH_ROWS_SPLIT;
     if (prepass == 3) {
         // pre-gather stage: K5 + K4 of the first chunks (needs the map, the cameras, the token centres -- not the tokens)

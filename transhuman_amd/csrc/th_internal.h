@@ -427,7 +427,9 @@ int th_bound_mask_launch(const int32_t* corners_xy /* host [8][2] */, int H, int
 // k_encoder.hip
 int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
                               const int* dims, int V, int H, int W, const float* wc, const float* bc, float* out,
-                              hipStream_t s, int split = 0);
+                              hipStream_t s, int split, const int32_t* box /* device [V][4] or null: th_map_box_launch */);
+int th_map_box_launch(const float* va, int na, const float* vb, int nb, const float* cams, int V, const float* scale, int H,
+                      int W, float reach, int32_t* box, hipStream_t s);
 // W' [N,260] = [W[:, :256] | W[:, 256:384] Wc | 0], b' = b + W[:, 256:384] bc  (fp64 accumulation)
 // K12 (k_conv.hip): convolutions of the ResNet stem on the fp16-split MFMA path
 size_t th_conv_pack_size(int COUT, int CIN, int KS);

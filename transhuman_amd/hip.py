@@ -48,7 +48,12 @@ class ThFrame(C.Structure):
                 ("cams", C.c_void_p), ("scale_xy", C.c_void_p), ("pixel_map_nhwc", C.c_void_p), ("V", C.c_int),
                 ("H", C.c_int), ("W", C.c_int), ("map_channels", C.c_int), ("tokens", C.c_void_p), ("centres", C.c_void_p),
                 ("rot", C.c_void_p), ("n_clusters", C.c_int), ("hull_thresh", C.c_float),
-                ("small_frame_rays", C.c_int)]
+                ("small_frame_rays", C.c_int), ("map_source", C.c_void_p)]
+
+
+class ThMapSource(C.Structure):
+    _fields_ = [("box", C.c_void_p), ("reach", C.c_float), ("img", C.c_void_p), ("lat0", C.c_void_p),
+                ("lat1", C.c_void_p), ("lat2", C.c_void_p), ("dims", C.c_int32 * 6)]
 
 
 # every symbol include/transhuman_hip.h declares (tests/test_cabi.py checks the export table)
@@ -87,6 +92,11 @@ SYMBOLS = {
                                           C.c_void_p, C.c_void_p]),
     "th_upsample_concat_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "th_upsample_concat_split_box": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]),
+    "th_map_box": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                             C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "th_paint_group_nhwc_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "th_paint_group_nhwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ThLinear), C.POINTER(ThLinear),
@@ -167,7 +177,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 4:
+    if lib.th_abi_version() != 5:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -523,10 +533,18 @@ class SplitMap:
     texel is ONE aligned wave load; the interleaved 260-channel rows straddle nine 128-byte lines instead of eight and
     cost a second load instruction for their 65th float4) followed by [V,H,W,4] (r, g, b, 0)."""
 
-    def __init__(self, buf, V, H, W):
+    def __init__(self, buf, V, H, W, source=None):
         self.buf, self.V, self.H, self.W = buf, V, H, W
         self.shape = (V, H, W, 256)
         self.device = buf.device
+        # cropped map (upsample_concat_split(box=...)): (ThMapSource, the tensors it points to); texels outside the
+        # per-view box are NOT written until a frame-level call needs them (th_frame.map_source)
+        self.source = source
+
+    @property
+    def box(self):
+        """device int32 [V,4] (x0, y0, x1, y1 inclusive) of a cropped map, else None"""
+        return self.source[1][0] if self.source is not None else None
 
     def data_ptr(self):
         return self.buf.data_ptr()
@@ -544,16 +562,38 @@ class SplitMap:
         return torch.cat([self.latents, self.rgb0], dim=-1).contiguous()
 
 
-def upsample_concat_split(images, lat0, lat1, lat2):
-    """th_upsample_concat_split: the compact map (colour lift folded into the consumers) in the split layout."""
+def map_box(verts_a, verts_b, cams, scale_xy, H, W, reach):
+    """th_map_box: per view the texel box (device int32 [V,4]: x0, y0, x1, y1 inclusive) that holds every texel a
+    bilinear gather at a point within ``reach`` (per axis) of a vertex of verts_a / verts_b can read."""
+    lib = load_library()
+    a = _f32(verts_a).reshape(-1, 3)
+    b = _f32(verts_b).reshape(-1, 3) if verts_b is not None else None
+    V = cams.shape[0]
+    box = torch.empty((V, 4), dtype=torch.int32, device=a.device)
+    _check(lib.th_map_box(ctx(a.device), _p(a), a.shape[0], _p(b), b.shape[0] if b is not None else 0, _p(cams), V,
+                          _p(scale_xy), int(H), int(W), float(reach), _p(box), _stream()))
+    return box
+
+
+def upsample_concat_split(images, lat0, lat1, lat2, box=None, reach=0.0):
+    """th_upsample_concat_split(_box): the compact map (colour lift folded into the consumers) in the split layout.
+    ``box`` (map_box, computed with ``reach``): only the texels of each view's box are written -- the returned SplitMap
+    carries what it was made from (``source``) and hip.Frame hands that to the C side, which completes the map on its
+    own if a call gathers outside the hull's reach (un-masked small-frame branch, no hull test)."""
     lib = load_library()
     img, l0, l1, l2 = _f32(images), _f32(lat0), _f32(lat1), _f32(lat2)
     V, _, H, W = img.shape
     assert l0.shape[1] == 64 and l1.shape[1] == 64 and l2.shape[1] == 128
     dims = (C.c_int32 * 6)(l0.shape[2], l0.shape[3], l1.shape[2], l1.shape[3], l2.shape[2], l2.shape[3])
     buf = torch.empty(V * H * W * 260, dtype=torch.float32, device=img.device)
-    _check(lib.th_upsample_concat_split(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf), _stream()))
-    return SplitMap(buf, V, H, W)
+    if box is None:
+        _check(lib.th_upsample_concat_split(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf), _stream()))
+        return SplitMap(buf, V, H, W)
+    assert box.dtype == torch.int32 and tuple(box.shape) == (V, 4) and box.is_contiguous()
+    _check(lib.th_upsample_concat_split_box(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf),
+                                            _p(box), _stream()))
+    src = ThMapSource(_p(box), float(reach), _p(img), _p(l0), _p(l1), _p(l2), dims)
+    return SplitMap(buf, V, H, W, source=(src, (box, img, l0, l1, l2)))
 
 
 def upsample_concat_nhwc(images, lat0, lat1, lat2, color_w=None, color_b=None):
@@ -896,9 +936,11 @@ class Frame:
         V, H, W, Cc = pixel_map_nhwc.shape
         assert Cc in (384, 260) or isinstance(pixel_map_nhwc, SplitMap), \
             "pixel map must be the full (384) or the compact (260 interleaved / SplitMap) channels-last map"
+        src = getattr(pixel_map_nhwc, "source", None)
         self.c = ThFrame(_p(self.verts), self.verts.shape[0], _p(self.Rh), _p(self.Th), _p(self.cams), _p(self.scale),
                          _p(self.map), V, H, W, Cc, _p(self.tokens), _p(self.centres), _p(self.rot),
-                         self.centres.shape[0], hull_thresh, small_frame_rays)
+                         self.centres.shape[0], hull_thresh, small_frame_rays,
+                         C.cast(C.pointer(src[0]), C.c_void_p).value if src is not None else None)
 
     def set_tokens(self, tokens):
         """TransHE output [V, N_c, 192] of a frame that was built without it (render_pregather runs beside TransHE)"""

@@ -102,7 +102,7 @@ class Renderer:
 
     # ---- per-frame constants ---------------------------------------------------------
     def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True, token_exchange=None,
-                      pregather=None, defer_tokens=False, stem_exchange=None):
+                      pregather=None, defer_tokens=False, stem_exchange=None, crop_map=None):
         """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
 
         fused_encoder_tail=True (default): the ResNet stem runs through SpatialEncoder.trunk (K12 / K11), its tail
@@ -117,6 +117,12 @@ class Renderer:
         rgb_res_0, rgb_res_1, reduction_layer: W' = [W_lat | W_col Wc], b' = b + W_col bc) -- a third less
         map/gather/staging traffic and 12 % fewer MLP MACs, same function.
         All forms give the same tokens / pixels to fp32 rounding (tests/test_gpu_parity.py).
+        crop_map (default: on for the split compact map, TH_MAP_CROP=0 switches it off): the reference writes the map over
+        the whole image and then reads it only at samples within the hull threshold of a target vertex (:440-444) and at
+        the projected input vertices (:168-172) -- here only the per-view texel box those reads can touch is written
+        (hip.map_box: projected corners of the threshold-sized cube around every vertex; about a third of a 512 x 512
+        view for a standing body).  Same pixels: the box is a superset by construction, and a call that leaves its premise
+        (un-masked small-frame branch, no hull test) makes the C side write the rest first (th_frame.map_source).
         token_exchange (multi-GPU, transhuman_amd.dist.TokenExchange): callable(compute, shape, device) that either
         runs ``compute`` (paint -> group -> TransHE) here or receives the tokens from the rank that did.
         stem_exchange (multi-GPU, transhuman_amd.dist.StemExchange): the ResNet stem runs on one rank per frame and its
@@ -143,13 +149,20 @@ class Renderer:
             V = images.shape[0]
             lat = enc.trunk(images) if stem_exchange is None else stem_exchange.latents(enc.trunk, images)
             cw, cb = enc.upsample_color.weight, enc.upsample_color.bias
+            scale = hip.feat_scale(enc.feat_scale(H, W), image_shape, dev)
+            thr = cfg_hull() if hull_thresh is None else hull_thresh
+            if crop_map is None:
+                crop_map = os.environ.get("TH_MAP_CROP") != "0"
             if compact_map == "interleaved":            # A/B: one [V,H,W,260] tensor (1040-byte texel rows)
                 map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2])
+            elif compact_map and crop_map and thr >= 0:
+                reach = float(thr) * 1.001 + 1e-6
+                box = hip.map_box(batch["tar_smpl_vertice"][0], batch["input_smpl_vertice"][t][0], cams, scale, H, W, reach)
+                map_nhwc = hip.upsample_concat_split(images, lat[0], lat[1], lat[2], box=box, reach=reach)
             elif compact_map:
                 map_nhwc = hip.upsample_concat_split(images, lat[0], lat[1], lat[2])
             else:
                 map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2], cw, cb)
-            scale = hip.feat_scale(enc.feat_scale(H, W), image_shape, dev)
 
             def group():
                 return hip.paint_group_nhwc(map_nhwc, batch["input_smpl_vertice"][t][0], cams, scale, viz,
@@ -208,7 +221,7 @@ class Renderer:
         # (range guard, hip.render_rays: the same constants again -- through the stock convolutions -- if the stem's
         # input left the fp16 range)
         # (a rebuilt frame computes its own tokens: the exchange's frame counter must not advance twice)
-        frame.rebuild = lambda: self.prepare_frame(batch, hull_thresh, fused_encoder_tail, compact_map)
+        frame.rebuild = lambda: self.prepare_frame(batch, hull_thresh, fused_encoder_tail, compact_map, crop_map=crop_map)
         return frame
 
     # ---- reference API -------------------------------------------------------------------
