@@ -552,6 +552,7 @@ def main():
                 "sigma_pos_samples_rank0": n_pos, "parallelism": f"ray-tile x{world}" if world > 1 else "single",
                 "frame_pipeline": "off" if seq is None else "constants(i+1) on a 2nd HIP stream under shading(i)",
                 "stem_exchange": stem_x is not None,
+                "map_crop": os.environ.get("TH_MAP_CROP") != "0",      # pixel map written inside the hull's texel box only
             },
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
                                        mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos)),
