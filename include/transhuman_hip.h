@@ -118,7 +118,10 @@ int th_set_tok_gather(th_ctx* ctx, int on);
 #define TH_RANGE_FP16_FLOOR 0x2400u     /* 2^-6  */
 /* slot 7: fp16 bit pattern of max |a| of the operands of TransHE's dense layers (th_gemm_h3).  Slots 6 and 7 are
  * written by the stream that computes a frame's constants and are sticky (not cleared by a snapshot; slot 7 is cleared by
- * th_set_vit_weights, slot 6 by th_set_mlp_weights).  th_set_vit_mode(ctx, 0) moves TransHE's dense layers back to the fp32 MFMA GEMMs. */
+ * th_set_vit_weights, slot 6 by th_set_mlp_weights).  th_set_vit_mode(ctx, 0) moves TransHE's dense layers back to the fp32 MFMA GEMMs;
+ * 1 (default): fp16-split arithmetic, one launch per layer (63 launches); 2: fp16-split arithmetic, the whole forward as ONE persistent
+ * launch when the shape allows (dim 192, 3 heads, depth <= 12, N_c <= 1100: k_vit_persist.hip -- 2 launches, values within 2e-6 of
+ * mode 1; fewer CUs for longer: see DESIGN.md 9), else as mode 1. */
 int th_set_vit_mode(th_ctx* ctx, int mode);
 int th_range_snapshot(th_ctx* ctx, th_stream stream);
 int th_range_read(th_ctx* ctx, int slot, uint32_t* out /* [TH_RANGE_SLOTS] */);

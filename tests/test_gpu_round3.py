@@ -242,3 +242,43 @@ def test_cropped_map_is_completed_for_the_unmasked_branch(hip, gpu, net):
     with torch.no_grad():
         out = r.render(b)
     assert torch.isfinite(out["rgb_map"]).all()
+
+
+@pytest.mark.parametrize("nc,V", [(500, 3), (300, 1), (37, 3), (1, 1), (800, 2), (1100, 3)])
+def test_transhe_as_one_persistent_launch(hip, gpu, net, nc, V):
+    """th_set_vit_mode(ctx, 2): the whole TransHE forward as one persistent kernel (k_vit_persist.hip: V * ceil(N_c / 32)
+    workgroups, one device-wide barrier per block) against the 63 launches of mode 1.  Same arithmetic per element up to
+    the final LayerNorm's summation order, v_exp_f32 in the softmax and a polynomial erf in GELU: within 1e-5 (the parity bar
+    of the stage against the oracle is 1e-4); deterministic from run to run; ragged last workgroup (N_c % 32 != 0)."""
+    g = torch.randn(V, nc, 192, device=gpu, generator=torch.Generator(device=gpu).manual_seed(nc))
+    pe = torch.rand(V, nc, 3, device=gpu, generator=torch.Generator(device=gpu).manual_seed(nc + 1)) * 2 - 1
+    try:
+        hip.set_vit_mode(1, gpu)
+        ref = net.ViT(g, pe, mask=None).clone()
+        hip.set_vit_mode(2, gpu)
+        outs = [net.ViT(g, pe, mask=None).clone() for _ in range(4)]
+    finally:
+        hip.set_vit_mode(1, gpu)
+    assert all(torch.equal(o, outs[0]) for o in outs)
+    assert torch.isfinite(outs[0]).all() and maxdiff(outs[0].cpu(), ref.cpu()) < 1e-5
+    assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")
+
+
+def test_frames_with_the_persistent_transhe(hip, gpu, net):
+    """a frame rendered with TransHE in mode 2 equals the mode-1 frame within 2e-5 (pipeline and render_fast agree bit for bit
+    with each other in either mode: both run the same kernels)"""
+    r = _renderer(net, 300, samples=32)
+    b = synth.batch_to(synth.make_batch(64, 64, 3, seed=0, focal=210.0), gpu)
+    ref = r.render_fast(b, is_train=False)
+    try:
+        hip.set_vit_mode(2, gpu)
+        out = r.render_fast(b, is_train=False)
+        seq = r.render_sequence(itertools.repeat(b))
+        next(seq)
+        piped = next(seq)
+        seq.close()
+    finally:
+        hip.set_vit_mode(1, gpu)
+    assert r.last_stats["valid_samples"] > 1000
+    for k in ("rgb_map", "acc_map"):
+        assert maxdiff(out[k].cpu(), ref[k].cpu()) < 2e-5 and torch.equal(piped[k], out[k])

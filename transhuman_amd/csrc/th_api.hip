@@ -274,7 +274,8 @@ int th_range_read(th_ctx* c, int id, uint32_t* out) {
 int th_range_last_slot(th_ctx* c) { return c ? c->range_last : -1; }
 
 int th_set_vit_mode(th_ctx* c, int mode) {
-    TH_REQUIRE(c && (mode == 0 || mode == 1), "mode must be 0 (fp32 MFMA GEMMs) or 1 (fp16-split MFMA GEMMs)");
+    TH_REQUIRE(c && mode >= 0 && mode <= 2, "mode must be 0 (fp32 MFMA GEMMs), 1 (fp16-split MFMA, one launch per layer) or 2 "
+               "(fp16-split MFMA, one persistent launch when the shape allows)");
     c->vit_mode = mode;
     return 0;
 }
@@ -500,8 +501,8 @@ int th_vit_forward(th_ctx* c, const float* x, const float* pe, int V, int N, flo
                    th_stream stream) {
     TH_REQUIRE(c && x && pe && out && ws, "null argument");
     ProfScope sc(prof_of(c), TH_PROF_VIT, (hipStream_t)stream);
-    return th_vit_launch(c->vit, x, pe, V, N, out, ws, ws_bytes, (hipStream_t)stream, c->vit_mode == 1 ? c->range_dev : nullptr,
-                         c->vit_mode == 1);
+    return th_vit_launch(c->vit, x, pe, V, N, out, ws, ws_bytes, (hipStream_t)stream, c->vit_mode >= 1 ? c->range_dev : nullptr,
+                         c->vit_mode >= 1, c->vit_mode == 2);
 }
 
 int th_dparf_encode(th_ctx* c, const float* pts, const int32_t* sel, int P, const float* centres, const float* rot,

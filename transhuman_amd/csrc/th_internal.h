@@ -88,6 +88,12 @@ bool th_gemm_h3_ok(int M, const ThPacked& W, bool ln);
 // qkv epilogue of the ViT (optional): output columns >= dim (the keys and values of row = view * N + key) are not stored
 // as fp32 but as the fp16 hi | lo operand planes of attn2_kernel (k_vit.hip: Kp [V][heads][2][Npad][64],
 // Vp [V][heads][2][64][Npad] in the fragment key order) -- the per-layer kv_split launch disappears
+// k_vit_persist.hip: TransHE as one persistent launch
+struct ThVitPacked;
+bool th_vit_persist_ok(const ThVitPacked& W, int V, int N);
+size_t th_vit_persist_extra_ws(int V, int N, int heads);
+int th_vit_persist_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, float* X, float* Qb,
+                          char* planes, hipStream_t s, unsigned int* range);
 struct ThQkvSplit {
     _Float16* Kp;
     _Float16* Vp;
@@ -407,7 +413,7 @@ int th_view_embed_launch(const float* d, int R, int res, float* out, hipStream_t
 // k_vit.hip
 size_t th_vit_ws(int V, int N, int dim, int heads);
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
-                  size_t ws_bytes, hipStream_t s, unsigned int* range = nullptr, bool allow_h3 = true);
+                  size_t ws_bytes, hipStream_t s, unsigned int* range = nullptr, bool allow_h3 = true, bool allow_persist = false);
 
 // k_smpl.hip
 size_t th_smpl_ws(int nv);

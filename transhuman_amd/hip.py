@@ -309,7 +309,7 @@ def _sync_weights(mod, kind):
                 _check(load_library().th_set_mlp_mode(ctx(dev), _user_mode.get(key[0], 1)))
             _conv_fallback.pop(key[0], None)
         elif _vit_fallback.pop(key[0], None):
-            _check(load_library().th_set_vit_mode(ctx(dev), 1))
+            _check(load_library().th_set_vit_mode(ctx(dev), _user_vit_mode.get(key[0], 1)))
 
 
 # ---------------------------------------------------------------------------
@@ -323,6 +323,7 @@ _user_mode = {}                    # device index -> mode requested through set_
 _range_fallback = {}               # device index -> True while the guard forces mode 0 on this context
 _range_epoch = {}                  # device index -> number of fallbacks so far (frames queued earlier are re-rendered)
 _conv_fallback = {}                # device index -> True once the stem convolutions' input left the fp16 range: stock convolutions
+_user_vit_mode = {}                # device index -> the TransHE mode the caller asked for (set_vit_mode): restored with new weights
 _vit_fallback = {}                 # device index -> True once an operand of TransHE's fp16-split GEMMs left the fp16 range: fp32 MFMA GEMMs
 last_range = None                  # the last table read (debugging / tests)
 
@@ -1109,3 +1110,13 @@ def profile_read(device=None):
     cnt = (C.c_int64 * 8)()
     _check(load_library().th_profile_read(ctx(device), ms, cnt))
     return {PROF_PHASES[i]: (ms[i], cnt[i]) for i in range(6)}
+
+
+def set_vit_mode(mode, device=None):
+    """th_set_vit_mode: 0 = TransHE's dense layers on the fp32 MFMA GEMMs, 1 (default) = fp16-split arithmetic, one launch per
+    layer, 2 = fp16-split arithmetic with the whole forward as one persistent launch when the shape allows (k_vit_persist.hip)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    _check(load_library().th_set_vit_mode(ctx(dev), int(mode)))
+    _user_vit_mode[_dev_index(dev)] = int(mode)
+    if int(mode) != 0:
+        _vit_fallback.pop(_dev_index(dev), None)
