@@ -76,7 +76,8 @@ def hbm_traffic():
     p = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(p) as f:
-            return json.load(f)
+            text = f.read()
+        return json.loads(text[text.index("{"):])           # (tolerates a commented table in front of the object)
     except (OSError, ValueError):
         return None
 
@@ -88,7 +89,7 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
     of its 2.5 PFLOP/s dense peak; mode 0: fp32 MFMA GEMM launches, peak 157.3 TFLOP/s."""
     if mlp_mode == 1:
         peak = MFMA_F16_PEAK / 3.0
-        kernel = "mlp_fused2_kernel<3,1> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0"
+        kernel = "mlp_fused_kernel<3,1> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0"
     else:
         peak = MFMA_F32_PEAK
         kernel = "per-point MLP stage (gemm_f32_mfma_kernel x14 + glue kernels), rank 0"

@@ -193,3 +193,15 @@ def test_synthetic_rays_match_the_oracle_restatement_of_the_loader():
     assert np.array_equal(near.astype(np.float32), ref["near"][m]) and np.array_equal(far.astype(np.float32), ref["far"][m])
     assert np.array_equal(o, ref["ray_o"])
     assert np.array_equal(np.where(np.abs(d) < 1e-5, np.float32(1e-5), d), ref["ray_d"])
+
+
+def test_bench_reads_the_committed_hbm_traffic():
+    """bench.py takes roofline.traffic from profiles/hbm_traffic.json (written by tools/collect_profiles.sh): the file must parse
+    and carry the fused MLP's bytes per launch from a summary that is itself under profiles/"""
+    import os
+    import bench
+    t = bench.hbm_traffic()
+    assert t is not None and t["mlp_fused_bytes_per_launch"] > 1e9 and t["launch_samples"] == 524288
+    assert t["source"].startswith("profiles/") and os.path.exists(os.path.join(os.path.dirname(bench.__file__), t["source"]))
+    blk = bench.roofline_block(1, 5.0e14, 9.4e12, 17.9, 4.0)
+    assert blk["traffic"] == t["mlp_fused_bytes_per_launch"] and "mlp_fused_kernel<3,1>" in blk["kernel"]

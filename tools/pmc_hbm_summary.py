@@ -24,9 +24,10 @@ def main():
     as_json = "--json" in sys.argv
     f = load(f"{d}/pmc_FETCH_SIZE_counter_collection.csv", "FETCH_SIZE")
     w = load(f"{d}/pmc_WRITE_SIZE_counter_collection.csv", "WRITE_SIZE")
-    print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1")
-    print("# KB per launch = MAX over the launches of a kernel (the full 262144-sample chunks); hbm = 2*FETCH + WRITE")
-    print(f"{'kernel':62s} {'launches':>8s} {'FETCH_KB':>12s} {'WRITE_KB':>12s} {'HBM_GB(2F+W)':>13s}")
+    if not as_json:            # (the --json form prints the JSON object only: bench.py json.load()s the file)
+        print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1")
+        print("# KB per launch = MAX over the launches of a kernel (the full 262144-sample chunks); hbm = 2*FETCH + WRITE")
+        print(f"{'kernel':62s} {'launches':>8s} {'FETCH_KB':>12s} {'WRITE_KB':>12s} {'HBM_GB(2F+W)':>13s}")
     rows = []
     for k in f:
         fk = max(f[k])
