@@ -113,8 +113,11 @@ def test_pipeline_rebuilds_frames_built_before_a_conv_fallback(hip, gpu):
     assert any("convolution" in str(x.message) for x in w)
     ref = r.render_fast(b, is_train=False)             # stock convolutions now
     assert torch.isfinite(ref["rgb_map"]).all()
+    # (the fallen-back frames go through torch's stock convolutions: MIOpen on two streams is not bit-reproducible from call
+    # to call -- one frame in ~50 differs from render_fast's by 1e-15 -- so this comparison is to 1e-6, not torch.equal)
     for f in frames:
-        assert torch.equal(f["rgb_map"], ref["rgb_map"]) and torch.equal(f["acc_map"], ref["acc_map"])
+        assert torch.isfinite(f["rgb_map"]).all()
+        assert maxdiff(f["rgb_map"], ref["rgb_map"]) < 1e-6 and maxdiff(f["acc_map"], ref["acc_map"]) < 1e-6
     # new weights bring the HIP convolutions back (and clear the sticky slot)
     with torch.no_grad():
         net2.alpha_fc.bias.add_(0.0)
