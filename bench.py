@@ -101,6 +101,16 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
                              f"{t['mlp_fused_algorithmic_bytes_per_launch']:.3g} (" + t["algorithmic_note"] + ")") if t else
                             "no committed PMC pass (profiles/hbm_traffic.json absent)",
             "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK,
+            # the same ALGORITHMIC number against the raw dense fp16 MFMA peak (what a reader who does not accept the /3 sees)
+            "frac_of_fp16_mfma_peak": achieved / MFMA_F16_PEAK,
+            # executed MFMA work (3 fp16 products per executed fp32 MAC) / time / raw fp16 peak: how busy the matrix pipe is
+            "mfma_pipe_util": (3.0 * executed_step / max(stage_ms * 1e-3, 1e-12) / MFMA_F16_PEAK) if (executed_step and mlp_mode == 1) else None,
+            "traffic_per_frame": ({"measured_K4_K5_K6_bytes": (t["mlp_fused_bytes_per_launch"] + t["pixgather_bytes_per_launch"] +
+                                                               t["dparf_bytes_per_launch"]) * launches,
+                                   "survey_8d_algorithmic_bytes": 1.22e9,
+                                   "note": "PMC bytes per full launch x launches of this frame (partial last launch counted as "
+                                           "full: upper bound) against SURVEY 8d's unique-footprint figure; the gap is the "
+                                           "K5 -> HBM -> K6 row round trip (rows written once, read twice)"} if t else None),
             "algorithmic_flop_per_step": flops_step, "kernel_ms_per_step": stage_ms,
             "launches_per_step": launches,
             # what the matrix pipes really did (after the algebraic folds): executed FLOPs / time / peak
@@ -115,8 +125,15 @@ def gather_block(V, n_valid, gather_ms, n_cu=256, clock_hz=2.4e9):
     rows = float(n_valid) * V
     byts = rows * (4 * 1040 + 1088)
     sec = max(gather_ms * 1e-3, 1e-12)
-    return {"kernel": "pixgather_kernel<true>", "bytes_per_step": byts, "ms_per_step": gather_ms, "TB_per_s": byts / sec / 1e12,
+    t = hbm_traffic()
+    hbm = (t["pixgather_bytes_per_launch"] * n_valid / t["launch_samples"]) if t else None
+    return {"kernel": "pixgather_kernel<true>", "texture_path_bytes_per_step": byts, "ms_per_step": gather_ms,
+            # bytes through the TEXTURE path (L1 / L2 hits included) -- NOT HBM bytes: this figure can exceed the HBM peak
+            "texture_path_TB_per_s": byts / sec / 1e12,
+            "hbm_TB_per_s": (hbm / sec / 1e12) if hbm else None,
+            "hbm_note": ("HBM bytes from the committed PMC pass (" + t["source"] + "), scaled to this frame's samples") if t else None,
             "B_per_clk_per_CU": byts / sec / clock_hz / n_cu, "ubench_ceiling_B_per_clk_per_CU": 50.0,
+            "frac_of_ubench_ceiling": byts / sec / clock_hz / n_cu / 50.0,
             "note": f"at the nominal {clock_hz / 1e9:.1f} GHz, {n_cu} CUs; runs beside K4 (neighbour records) on a second stream"}
 
 
@@ -189,8 +206,11 @@ def cpu_baseline(batch, assign, n_samples, stride=64, gpu_img=None):
     return res
 
 
-def oracle_rays_check(batch_cpu, assign, n_samples, ray_idx, gpu_img, sd=None):
-    """max |rgb, acc| of the GPU image against the CPU oracle on the rays `ray_idx` of the frame (masked branch)"""
+def oracle_rays_check(batch_cpu, assign, n_samples, ray_idx, gpu_img, sd=None, truth=False):
+    """max |rgb, acc| of the GPU image against the CPU oracle on the rays `ray_idx` of the frame (masked branch).
+    truth=True adds the float64 evaluation of the same graph on the same fp32 inputs (oracle.widen): the distance of the
+    GPU image AND of the fp32 oracle from it -- whether the HIP path is further from the exact result than the
+    reference's own fp32 arithmetic."""
     from oracle import th_oracle as O
     from transhuman_amd.networks.cross_transformer import Network
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
@@ -209,10 +229,43 @@ def oracle_rays_check(batch_cpu, assign, n_samples, ray_idx, gpu_img, sd=None):
         hol, pix = O.encoder_forward(sd, batch_cpu["input_imgs"][0][0])
         o_out, _ = O.render_fast(sd, sub, hol, pix, off, mem, can_c, n_samples=n_samples, vit_depth=12, small_frame_rays=-1)
     ref = torch.cat([o_out["rgb_map"][0], o_out["acc_map"][0][:, None]], dim=1).double()
-    d = gpu_img[ray_idx].detach().cpu().double()[:, :4] - ref
-    return {"rays": int(len(ray_idx)), "rays_hit": int((o_out["acc_map"][0] > 0).sum()),
-            "max_abs_rgb_acc": float(d.abs().max()),
-            "psnr_rgb_db": float(-10.0 * torch.log10(torch.clamp((d[:, :3] ** 2).mean(), min=1e-30)))}
+    g = gpu_img[ray_idx].detach().cpu().double()[:, :4]
+    d = g - ref
+    res = {"rays": int(len(ray_idx)), "rays_hit": int((o_out["acc_map"][0] > 0).sum()),
+           "max_abs_rgb_acc": float(d.abs().max()),
+           "psnr_rgb_db": float(-10.0 * torch.log10(torch.clamp((d[:, :3] ** 2).mean(), min=1e-30)))}
+    if truth:
+        sub64, sd64 = O.widen(sub), O.widen(sd)
+        with torch.no_grad():
+            hol, pix = O.encoder_forward(sd64, sub64["input_imgs"][0][0])
+            t_out, _ = O.render_fast(sd64, sub64, hol, pix, off, mem, can_c, n_samples=n_samples, vit_depth=12, small_frame_rays=-1)
+        t = torch.cat([t_out["rgb_map"][0], t_out["acc_map"][0][:, None]], dim=1)
+        res["vs_float64_oracle"] = {"gpu": float((g - t).abs().max()), "fp32_oracle": float((ref - t).abs().max()),
+                                    "note": "max |rgb, acc| against the float64 evaluation of the same graph on the same fp32 "
+                                            "inputs: the fp32 oracle's own distance from it is the reference's rounding noise"}
+    return res
+
+
+def fused_vs_fp32(renderer, b, hip):
+    """The whole frame `b` rendered by the fused fp16 hi/lo x3 kernel (mode 1) and by the per-layer fp32 MFMA path (mode 0,
+    itself golden-checked): max and 99.99th percentile of |d rgb|, |d acc| over ALL rays of the frame."""
+    try:
+        hip.set_mlp_mode(1)
+        o1 = renderer.render_fast(b)
+        st = dict(renderer.last_stats)
+        hip.set_mlp_mode(0)
+        o0 = renderer.render_fast(b)
+    finally:
+        hip.set_mlp_mode(1)
+    d_rgb = (o1["rgb_map"][0].double() - o0["rgb_map"][0].double()).abs().max(dim=-1)[0]
+    d_acc = (o1["acc_map"][0].double() - o0["acc_map"][0].double()).abs()
+    n = d_rgb.numel()
+    k = max(1, int(round(n * 0.9999)))
+    return {"rays": int(n), "valid_samples": int(st["valid_samples"]),
+            "max_abs_rgb": float(d_rgb.max()), "p9999_abs_rgb": float(d_rgb.kthvalue(k)[0]),
+            "max_abs_acc": float(d_acc.max()), "p9999_abs_acc": float(d_acc.kthvalue(k)[0]),
+            "worst_ray": int(torch.argmax(torch.maximum(d_rgb, d_acc))),
+            "vs": "per-layer fp32 MFMA path (th_set_mlp_mode 0), same kernels otherwise; bar 5e-5 (half the 1e-4 budget)"}
 
 
 def time_steps(fn, steps, warmup=1):
@@ -239,7 +292,7 @@ def run_extras(dev, net, args, H, W, V):
     extra = {}
     rs = np.random.RandomState(3)
 
-    def frame_case(name, nc, dense):
+    def frame_case(name, nc, dense, n_hit_rays=192, modes=False):
         cfg.num_class = nc
         bc = synth.make_batch(H, W, V, seed=0, all_rays=True, dense=dense)
         body = bc["tar_smpl_vertice_smplcoord"][0].numpy()
@@ -250,14 +303,16 @@ def run_extras(dev, net, args, H, W, V):
         ms, out = time_steps(lambda: next(seq), 3, warmup=2)
         img = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
         hit = torch.nonzero(out["acc_map"][0] > 0).reshape(-1).cpu().numpy()
-        idx = np.sort(np.concatenate([rs.choice(hit, 192, replace=False), rs.choice(H * W, 64, replace=False)]))
+        idx = np.sort(np.concatenate([rs.choice(hit, n_hit_rays, replace=False), rs.choice(H * W, 64, replace=False)]))
         chk = oracle_rays_check(bc, assign, args.samples, idx, img)
         extra[name] = {"ms_per_frame": ms, "rays_per_s": H * W / ms * 1e3, "valid_samples": int(r.last_stats["valid_samples"]),
                        "n_clusters": nc, "gpu_vs_oracle": chk}
         seq.close()
+        if modes:
+            extra[name]["fused_vs_fp32_full_frame"] = fused_vs_fp32(r, b, hip)
 
     frame_case("S_dense", args.nc, True)
-    frame_case("C4_nc1500", 1500, False)
+    frame_case("C4_nc1500", 1500, False, n_hit_rays=448, modes=True)
     cfg.num_class = args.nc
 
     # SURVEY 8d's S-dense regime proper: a long lens on the torso + a per-ray slab hugging the surface -> (nearly) every one
@@ -281,13 +336,15 @@ def run_extras(dev, net, args, H, W, V):
     n_pos = count_sigma_positive(hip, net, r.last_frame, pts)
     flops = algorithmic_mlp_flops(V, n_valid, n_pos)
     mlp_ms = prof["mlp"][0] / 3.0
-    idx = np.sort(rs.choice(H * W, 48, replace=False))
+    idx = np.sort(rs.choice(H * W, args.dense_oracle_rays, replace=False))
+    seq.close()
+    dense_modes = fused_vs_fp32(r, b, hip)
     extra["S_dense_full"] = {"ms_per_frame": ms, "rays_per_s": H * W / ms * 1e3, "valid_samples": n_valid,
                              "sigma_pos_samples": n_pos, "algorithmic_mlp_flop": flops, "mlp_ms_per_frame": mlp_ms,
                              "mlp_TFLOP_per_s": flops / max(mlp_ms * 1e-3, 1e-12) / 1e12,
                              "roofline_frac": flops / max(mlp_ms * 1e-3, 1e-12) / (MFMA_F16_PEAK / 3.0),
-                             "gpu_vs_oracle": oracle_rays_check(bc, assign, args.samples, idx, img)}
-    seq.close()
+                             "gpu_vs_oracle": oracle_rays_check(bc, assign, args.samples, idx, img, truth=True),
+                             "fused_vs_fp32_full_frame": dense_modes}
     hip.drop_workspaces(dev)
     torch.cuda.empty_cache()
 
@@ -382,6 +439,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short post-run measurements of the other configurations")
     ap.add_argument("--cpu-stride", type=int, default=128)
+    ap.add_argument("--dense-oracle-rays", type=int, default=1024,
+                    help="extras: rays of the all-valid S_dense_full frame checked against the CPU oracle")
     ap.add_argument("--mlp-mode", type=int, default=1, help="1 fused fp16-split MFMA kernel, 0 per-layer fp32 MFMA")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="render every frame with Renderer.render_fast (constants -> shading back to back on one stream) "
@@ -499,13 +558,21 @@ def main():
         step()
     hip.profile_enable(os.environ.get("TH_NO_PROF") != "1")
     hip.profile_read()
+    # shader-clock probes: one 15 us wave queued behind the shading of every (up to 64) timed steps
+    n_probe = min(args.steps, 64) if os.environ.get("TH_NO_PROF") != "1" else 0
+    clk = torch.zeros((max(n_probe, 1), 4), dtype=torch.int64, device=dev)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
+    hip.host_wait_read(dev)
+    dist_wait = 0.0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         img, stats = step()
+        if i < n_probe:
+            hip.clock_probe(clk[i])
     host_dt = time.perf_counter() - t0             # the host is done queueing here (the device may still be working)
+    host_wait_ms = hip.host_wait_read(dev)         # ... of which it spent this long blocked on counts / guard snapshots
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
@@ -563,11 +630,19 @@ def main():
             # patterns of max |x| per split tensor: f, s, p, n, inter, fc4_in; fp32 bits: conv_in; fp16: vit_in)
             "range_guard": dict(hip.guard_state(dev), fallback=bool(hip.guard_state(dev)["mlp_fp32_fallback"]),
                                 slots=[int(x) for x in (hip.last_range or [])]),
-            "host_queue_ms_per_step": host_dt / max(args.steps, 1) * 1e3,      # python + launch calls; == ms_per_step: host-bound
+            "host_queue_ms_per_step": host_dt / max(args.steps, 1) * 1e3,      # wall time of the queueing loop (incl. its blocking waits)
+            # the host's OWN cost per frame: the loop's wall time minus the time it sat in blocking waits (sample counts,
+            # range-guard snapshots: back-pressure from the device, th_host_wait_read) -- Python + ctypes + launch calls.
+            # A frame shorter than this is host-bound whatever the kernels do.
+            "host_pure_ms_per_step": (host_dt * 1e3 - host_wait_ms) / max(args.steps, 1),
+            "host_wait_ms_per_step": host_wait_ms / max(args.steps, 1),
+            "shader_clock_GHz": shader_clock(clk, n_probe),
             "stage_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
             "stage_note": "HIP-event spans per stage; with the frame pipeline hull / vit run on the side stream under the "
                           "other stages (their spans are stretched by the overlap and do not add to the frame time)",
         }
+        res["peak_device_GiB"] = {"headline_allocated": torch.cuda.max_memory_allocated(dev) / 2**30,
+                                  "headline_reserved": torch.cuda.max_memory_reserved(dev) / 2**30}
         if emu:
             res["config"]["emulated_rank0_of"] = emu
         if world == 1 and not emu:
@@ -576,6 +651,8 @@ def main():
             ms_rf, _ = time_steps(lambda: renderer.render_fast(shard), max(3, args.steps // 2), warmup=1)
             res["render_fast_ms_per_step"] = ms_rf
             res["render_fast_rays_per_s"] = R / ms_rf * 1e3
+            if args.mlp_mode == 1 and not args.no_extras:
+                res["fused_vs_fp32_full_frame"] = fused_vs_fp32(renderer, batch, hip)
         if world == 1 and not args.no_cpu_baseline and not emu:
             res["cpu_baseline"] = cpu_baseline(batch_cpu, assign, args.samples, stride=args.cpu_stride, gpu_img=img)
         if world == 1 and not args.no_extras and not args.no_cpu_baseline and not emu and args.workload == "real":
@@ -584,9 +661,24 @@ def main():
             except Exception as e:        # noqa: BLE001
                 res["extra"] = {"error": f"{type(e).__name__}: {e}"}
             cfg.num_class = args.nc
+            res["peak_device_GiB"].update(with_extras_allocated=torch.cuda.max_memory_allocated(dev) / 2**30,
+                                          with_extras_reserved=torch.cuda.max_memory_reserved(dev) / 2**30)
     else:
         res = None
     finish(dist_on, res)
+
+
+def shader_clock(clk, n):
+    """median / min / max GHz of the probes queued behind the timed steps (th_clock_probe), None without probes"""
+    if n <= 0:
+        return None
+    c = clk[:n].cpu().double()
+    ok = c[:, 1] > 0
+    if not bool(ok.any()):
+        return None
+    g = (c[ok, 0] / (10.0 * c[ok, 1])).numpy()
+    return {"median": float(np.median(g)), "min": float(g.min()), "max": float(g.max()), "probes": int(ok.sum()),
+            "note": "s_memtime ticks / s_memrealtime (100 MHz) of a one-wave probe queued behind each timed step's shading"}
 
 
 def finish(dist_on, res):

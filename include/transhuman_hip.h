@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 5
+#define TH_ABI_VERSION 6
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -50,6 +50,16 @@ enum { TH_PROF_HULL = 0, TH_PROF_DPARF = 1, TH_PROF_GATHER = 2, TH_PROF_MLP = 3,
        TH_PROF_VIT = 5, TH_PROF_PHASES = 8 };
 int th_profile_enable(th_ctx* ctx, int on);
 int th_profile_read(th_ctx* ctx, double* ms_out, int64_t* count_out);
+/* Host milliseconds the calling thread spent inside the BLOCKING waits of the entry points (sample counts of
+ * th_render_rays / th_render_pregather / th_eval_sigma_grid, th_range_read) since the last call; reads and clears.
+ * bench.py subtracts it from the wall time of its queueing loop: what is left is the host's own cost per frame
+ * (Python + ctypes + launch calls), the figure that decides whether a short multi-GPU frame is host-bound. */
+int th_host_wait_read(th_ctx* ctx, double* ms_out);
+/* Shader-clock probe: one wave, ~15 us, queued on `stream`; out_dev[0] = shader-clock ticks, out_dev[1] = the same
+ * interval in 10 ns units of the constant 100 MHz counter (GHz = ticks / (10 * units)).  bench.py queues one behind
+ * the dominant kernel of every timed step and reports the median: the frequency the chip sustains under the load
+ * the roofline is priced at. */
+int th_clock_probe(th_ctx* ctx, int64_t* out_dev /* [3] */, th_stream stream);
 
 /* ---- weights ----------------------------------------------------------- */
 /* One dense layer: weight row-major [out_f][in_f] (a Conv1d(k=1)/Linear
@@ -119,9 +129,8 @@ int th_set_tok_gather(th_ctx* ctx, int on);
 /* slot 7: fp16 bit pattern of max |a| of the operands of TransHE's dense layers (th_gemm_h3).  Slots 6 and 7 are
  * written by the stream that computes a frame's constants and are sticky (not cleared by a snapshot; slot 7 is cleared by
  * th_set_vit_weights, slot 6 by th_set_mlp_weights).  th_set_vit_mode(ctx, 0) moves TransHE's dense layers back to the fp32 MFMA GEMMs;
- * 1 (default): fp16-split arithmetic, one launch per layer (63 launches); 2: fp16-split arithmetic, the whole forward as ONE persistent
- * launch when the shape allows (dim 192, 3 heads, depth <= 12, N_c <= 1100: k_vit_persist.hip -- 2 launches, values within 2e-6 of
- * mode 1; fewer CUs for longer: see DESIGN.md 9), else as mode 1. */
+ * 1 (default): fp16-split arithmetic.  (ABI 5 had a mode 2, the whole forward as one persistent launch: correct, but slower
+ * than the 63 launches and resident-workgroup-count dependent -- removed in ABI 6) */
 int th_set_vit_mode(th_ctx* ctx, int mode);
 int th_range_snapshot(th_ctx* ctx, th_stream stream);
 int th_range_read(th_ctx* ctx, int slot, uint32_t* out /* [TH_RANGE_SLOTS] */);
@@ -413,11 +422,24 @@ typedef struct {
 /* Renderer.render_fast :429-484 incl. _render/batchify_rays/raw2outputs for a
  * range of rays (the unit that is sharded across GPUs).  Outputs are dense
  * over the R rays (zeros for rays that miss the hull).
- * stats_host (optional, int64[4]): hit rays, valid samples, range-guard snapshot slot (th_range_read), mode. */
+ * stats_host (optional, int64[4]): hit rays, valid samples, range-guard snapshot slot (th_range_read), mode.
+ *
+ * Two caller-supplied buffers (ABI 6; one 25 GB worst-case workspace per frame in flight before):
+ *  - `workspace` (th_render_workspace_bytes: ~25 B per SAMPLE of the ray list -- hull mask, sample list, dense raw, counts,
+ *    view embeddings, the per-frame token table): one per frame in flight, it is what th_render_prepass writes;
+ *  - `shade_pool` (th_shade_pool_bytes: ~3.6 KB per VALID sample on the fused path -- the pixel-feature rows K5 writes
+ *    and K6 reads back (batchify_rays :607-656 / get_pixel_aligned_feature :210-269), the neighbour records and
+ *    positional encodings of K4): ONE per context, shared by every workspace (the per-sample stage of a context runs
+ *    on one stream at a time).  It is sized from the frame's valid-sample count, which th_render_prepass_wait puts on
+ *    the host before the stage is queued; without a prepass size it for n_valid = R * S (then only the chunk buffers of
+ *    th_set_chunk_samples samples are needed: the count bounds the chunk, not the pool). */
 size_t th_render_workspace_bytes(const th_frame* f, int R, int S);
+/* `f` needs V and map_channels; the result depends on the context's MLP / token-gather modes (ask again after
+ * th_set_mlp_mode / th_set_tok_gather).  with_pregather = 1: large enough for th_render_pregather + th_render_rays. */
+size_t th_shade_pool_bytes(th_ctx* ctx, const th_frame* f, long long n_valid, int with_pregather);
 int th_render_rays(th_ctx* ctx, const th_frame* f, const th_points* rays, float* rgb, float* acc,
                    float* depth, int white_bkgd, void* workspace, size_t workspace_bytes,
-                   int64_t* stats_host, th_stream stream);
+                   void* shade_pool, size_t shade_pool_bytes, int64_t* stats_host, th_stream stream);
 
 /* Optional: run the ray-only front of th_render_rays (sample placement + hull mask :440-444, the R' <= 2400
  * rule :551, compaction, view-direction embedding) ahead of time.  It needs only the rays and, of `f`, the
@@ -440,7 +462,11 @@ int th_render_prepass(th_ctx* ctx, const th_frame* f, const th_points* rays, voi
  * count on the host.  A no-op (return 0) without a matching prepass or off the fused neighbour-record path; results are
  * identical with or without it. */
 int th_render_pregather(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
-                        size_t workspace_bytes, th_stream stream);
+                        size_t workspace_bytes, void* shade_pool, size_t shade_pool_bytes, th_stream stream);
+/* Waits (host) for the counts of the prepass pending in `workspace`: counts_host[0] = hit rays, [1] = 1 when the
+ * R' <= small_frame_rays rule fired (un-masked branch), [2] = valid samples -- what th_shade_pool_bytes wants.
+ * Returns 1 (and leaves counts_host alone) when no prepass is pending for that workspace. */
+int th_render_prepass_wait(th_ctx* ctx, const void* workspace, int64_t* counts_host /* [3] */);
 /* Drops a pending prepass (a caller that abandons the frame it was queued for must not let a later
  * th_render_rays that happens to reuse the same buffers pick it up). */
 int th_render_prepass_cancel(th_ctx* ctx);                          /* all pending prepasses */
@@ -450,7 +476,8 @@ int th_render_prepass_drop(th_ctx* ctx, const void* workspace);     /* the one q
  * point (0 outside the hull).  pts [P,3] world space. */
 size_t th_sigma_grid_workspace_bytes(const th_frame* f, int P);
 int th_eval_sigma_grid(th_ctx* ctx, const th_frame* f, const float* pts, int P, float* sigma_out,
-                       void* workspace, size_t workspace_bytes, int64_t* stats_host, th_stream stream);
+                       void* workspace, size_t workspace_bytes, void* shade_pool, size_t shade_pool_bytes,
+                       int64_t* stats_host, th_stream stream);
 
 #ifdef __cplusplus
 }

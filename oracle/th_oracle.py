@@ -25,6 +25,20 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+def widen(obj, dtype=torch.float64):
+    """Every floating tensor of a batch dict / state dict / list as ``dtype`` (values unchanged: fp32 -> fp64 is exact).
+    With float64 inputs every function below evaluates the SAME graph in double precision -- the 'truth' the fp32
+    evaluations (this oracle's own and the HIP path's) are both approximations of; discrete decisions (hull mask, 7-NN
+    sets, the ViT's 32-octave PE table, which is defined by fp32 argument rounding) stay those of the fp32 pass."""
+    if torch.is_tensor(obj):
+        return obj.to(dtype) if obj.is_floating_point() else obj
+    if isinstance(obj, dict):
+        return {k: widen(v, dtype) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(widen(v, dtype) for v in obj)
+    return obj
+
+
 # ---------------------------------------------------------------------------
 # a-1  sample placement   lib/networks/renderer/if_clight_renderer.py:271-287
 # ---------------------------------------------------------------------------
@@ -45,7 +59,7 @@ def knn_points_exact(p, q, K, chunk=4096):
     L2 computed as (dx*dx + dy*dy) + dz*dz in fp32, idx [P,K] int64; ties go to
     the lower index)."""
     P = p.shape[0]
-    d2o = torch.empty((P, K), dtype=torch.float32)
+    d2o = torch.empty((P, K), dtype=p.dtype)
     ido = torch.empty((P, K), dtype=torch.int64)
     for s in range(0, P, chunk):
         pp = p[s:s + chunk]
@@ -86,7 +100,7 @@ def view_embed(ray_d, view_res=4):
     v=d/|d|; [v, sin(2^k v), cos(2^k v)] k<view_res -> [R, 3+6*view_res]."""
     v = ray_d / torch.norm(ray_d, dim=-1, keepdim=True)
     out = [v]
-    freqs = 2.0 ** torch.linspace(0.0, view_res - 1, steps=view_res)
+    freqs = (2.0 ** torch.linspace(0.0, view_res - 1, steps=view_res)).to(ray_d.dtype)
     for f in freqs:
         out.append(torch.sin(v * f))
         out.append(torch.cos(v * f))
@@ -103,7 +117,8 @@ def pe_encode(x, num_freqs, include_input=True):
     _phases[1::2] = np.pi * 0.5                                   # :121
     _phases = _phases.view(1, -1, 1)
     e = x.unsqueeze(1).repeat(1, num_freqs * 2, 1)
-    e = torch.sin(torch.addcmul(_phases, e, _freqs))              # :132
+    # (the fp32 constants of the reference, widened when the oracle runs in float64: see render_fast(dtype=...))
+    e = torch.sin(torch.addcmul(_phases.to(x.dtype), e, _freqs.to(x.dtype)))              # :132
     e = e.view(x.shape[0], -1)
     if include_input:
         e = torch.cat((x, e), dim=-1)
@@ -191,7 +206,9 @@ def segment_mean(src, offsets, members):
 def vit_forward(x, pe_xyz, sd, depth, prefix="ViT.", heads=3):
     """x [V,N,192] tokens; pe_xyz [V,N,3] normalised canonical centres."""
     V, N, C = x.shape
-    pe = pe_encode(pe_xyz.reshape(-1, 3), C // 6, include_input=False).view(V, N, C)
+    # (32 octaves: the top ones are sin(pi 2^31 x) -- DEFINED by the fp32 rounding of the argument, a hash of x; the table
+    # is therefore always the fp32 one, widened when the oracle runs in float64)
+    pe = pe_encode(pe_xyz.float().reshape(-1, 3), C // 6, include_input=False).view(V, N, C).to(x.dtype)
     x = x + pe                                                     # :366-367
     hd = C // heads
     for i in range(depth):
@@ -220,17 +237,21 @@ def dparf(pts_s, centres, blend, tokens, K=7, n_freq=10, alpha=0.5):
     """pts_s [P,3] (SMPL coords); centres [N_c,3]; blend [N_c,4,4] (any float
     dtype, cast to fp32 like :185); tokens [V,N_c,192]
     -> human_rep [P,V,255] (token part then PE part, as torch.cat at :199)."""
-    d2, idx = knn_points_exact(pts_s, centres, K)
+    d2, idx = knn_points_exact(pts_s.float(), centres.float(), K)
+    if pts_s.dtype != torch.float32:
+        # float64 "truth" mode: the neighbour SET is a discrete decision and stays the fp32 pass's; distances are recomputed
+        dd = pts_s.unsqueeze(1) - centres.to(pts_s.dtype)[idx]
+        d2 = (dd * dd).sum(-1)
     d = d2.sqrt()                                                  # :171
     w = F.softmax(-d / alpha, dim=1)                               # :153-154
-    rel = pts_s.unsqueeze(1) - centres[idx]                        # :183-184
-    rot = blend[..., :3, :3].type(torch.float32)[idx]              # :185-186
+    rel = pts_s.unsqueeze(1) - centres.to(pts_s.dtype)[idx]        # :183-184
+    rot = blend[..., :3, :3].type(torch.float32).to(pts_s.dtype)[idx]   # :185-186 (the fp32 cast is the reference's)
     de = torch.matmul(rel.unsqueeze(-2), rot).squeeze(-2)          # :187-188
     P = pts_s.shape[0]
     pe = pe_encode(de.reshape(-1, 3), n_freq, True).view(P, K, -1)
     out = []
     for v in range(tokens.shape[0]):
-        f = torch.cat([tokens[v][idx], pe], dim=-1)                # :198-199
+        f = torch.cat([tokens[v][idx].to(pe.dtype), pe], dim=-1)   # :198-199
         out.append(torch.sum(w.unsqueeze(-1) * f, dim=1))          # :200
     return torch.stack(out, dim=1)
 
@@ -282,7 +303,7 @@ def network_forward(sd, pixel_feat, viewdir, pts_s, centres, blend, tokens, pts_
     P = pts_s.shape[0]
     f_all = pixel_feat.permute(2, 0, 1)
     if pts_mask is not None:
-        raw = torch.zeros((P, 4))
+        raw = torch.zeros((P, 4), dtype=pts_s.dtype)
         if pts_mask.sum() == 0:
             return raw
         sel = pts_mask
@@ -293,7 +314,7 @@ def network_forward(sd, pixel_feat, viewdir, pts_s, centres, blend, tokens, pts_
     inter = multiview_agg(sd, h, f)
     sig = alpha_forward(sd, inter)
     if pts_mask is not None:
-        rgb = torch.zeros((ps.shape[0], 3))
+        rgb = torch.zeros((ps.shape[0], 3), dtype=pts_s.dtype)
         dm = sig[:, 0] > 0
         if dm.sum() > 0:
             rgb[dm] = rgb_forward(sd, inter[dm], f[dm], vd[dm])
@@ -312,7 +333,7 @@ def raw2outputs(raw, z, ray_d, white_bkgd=False):
     d = d * torch.norm(ray_d[..., None, :], dim=-1)                # :37
     c = torch.sigmoid(raw[..., :3])
     a = 1.0 - torch.exp(-F.relu(raw[..., 3]) * d)                  # :27-28,:44
-    T = torch.cumprod(torch.cat([torch.ones((a.shape[0], 1)), 1.0 - a + 1e-10], -1), -1)[:, :-1]
+    T = torch.cumprod(torch.cat([torch.ones((a.shape[0], 1), dtype=a.dtype), 1.0 - a + 1e-10], -1), -1)[:, :-1]
     w = a * T                                                      # :46-49
     rgb = torch.sum(w[..., None] * c, -2)
     depth = torch.sum(w * z, -1)
@@ -335,7 +356,7 @@ def frame_constants(sd, batch, holder_feat_map, offsets, members, can_centres64,
                 batch["input_R"][t].reshape(-1, 3, 3), batch["input_T"][t].reshape(-1, 3, 1),
                 batch["input_K"][t].reshape(-1, 3, 3), batch["input_vizmaps"][t][0])
     grouped = torch.stack([segment_mean(big[v], offsets, members) for v in range(V)])
-    pe_xyz = normalize_pe(can_centres64.unsqueeze(0).repeat(V, 1, 1))
+    pe_xyz = normalize_pe(can_centres64.unsqueeze(0).repeat(V, 1, 1)).to(grouped.dtype)      # (fp32 cast: the reference's)
     tokens = vit_forward(grouped, pe_xyz, sd, vit_depth)
     centres = segment_mean(batch["tar_smpl_vertice_smplcoord"][0], offsets, members)
     blend = segment_mean(batch["blend_mtx"][0], offsets, members)
@@ -359,10 +380,15 @@ def render_fast(sd, batch, holder_feat_map, pixel_feat_map, offsets, members, ca
     ray_o, ray_d = batch["ray_o"][0], batch["ray_d"][0]
     near, far = batch["near"][0], batch["far"][0]
     R = ray_o.shape[0]
+    dt = ray_o.dtype
     pts, z = sampling_points(ray_o, ray_d, near, far, n_samples)
-    vm = hull_mask(pts.reshape(-1, 3), batch["tar_smpl_vertice"][0], hull).view(R, n_samples)
+    # float64 "truth" mode (every floating tensor of `batch` / `sd` / the feature maps handed in as float64: the exact
+    # arithmetic of the same graph on the same fp32 inputs): discrete decisions -- this hull mask, the 7-NN sets of
+    # dparf -- are taken from the fp32 pass, as the reference would take them
+    pts32 = pts if dt == torch.float32 else sampling_points(ray_o.float(), ray_d.float(), near.float(), far.float(), n_samples)[0]
+    vm = hull_mask(pts32.reshape(-1, 3), batch["tar_smpl_vertice"][0].float(), hull).view(R, n_samples)
     hit = vm.sum(-1) > 0                                           # :443
-    out = dict(rgb_map=torch.zeros(1, R, 3), acc_map=torch.zeros(1, R), depth_map=torch.zeros(1, R))
+    out = dict(rgb_map=torch.zeros(1, R, 3, dtype=dt), acc_map=torch.zeros(1, R, dtype=dt), depth_map=torch.zeros(1, R, dtype=dt))
     Rp = int(hit.sum())
     fc = frame_constants(sd, batch, holder_feat_map, offsets, members, can_centres64, vit_depth)
     if Rp == 0:
@@ -383,6 +409,7 @@ def render_fast(sd, batch, holder_feat_map, pixel_feat_map, offsets, members, ca
                                         fc["blend"], fc["tokens"], mm[s:s + chunk]))
         raw = torch.cat(raws, 0)
     rgb, acc, depth, _ = raw2outputs(raw.view(Rp, n_samples, 4), zz, d, white_bkgd)       # :593 (hit rays only)
+    fc = dict(fc, hit=hit, raw=raw.view(Rp, n_samples, 4), mask=m)      # (test diagnostics: per-sample outputs of the hit rays)
     out["rgb_map"][0, hit] = rgb
     out["acc_map"][0, hit] = acc
     out["depth_map"][0, hit] = depth

@@ -72,25 +72,6 @@ def test_headline_frame_oracle_sample(hip, gpu, net):
     assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")
 
 
-def test_s_dense_full_frame_oracle_sample(hip, gpu, net):
-    """SURVEY 8d's S-dense regime: a long lens on the torso and a per-ray slab hugging the surface make (nearly) every
-    one of the 512 x 512 x 64 = 16.8 M samples valid -- 32 full passes of the per-sample stage.  Properties over the
-    frame + the oracle on 40 rays."""
-    r = _renderer(net, 500)
-    bc = synth.make_batch(512, 512, 3, seed=0, all_rays=True, dense=True, focal=6000.0, dilate=64)
-    b = synth.batch_to(bc, gpu)
-    out = r.render_fast(b, is_train=False)
-    st = dict(r.last_stats)
-    rgb, acc = out["rgb_map"][0], out["acc_map"][0]
-    assert st["hit_rays"] == 512 * 512 and st["valid_samples"] > 0.99 * 512 * 512 * 64 and st["unmasked"] == 0
-    assert torch.isfinite(rgb).all() and float(acc.min()) >= 0.0 and float(acc.max()) <= 1.0 + 1e-5
-    rs = np.random.RandomState(6)
-    pick = np.sort(rs.choice(512 * 512, 40, replace=False))
-    ref = _oracle_on(bc, pick, synth_assign(500))
-    assert maxdiff(rgb[pick].cpu(), ref["rgb_map"][0]) < 1e-4 and maxdiff(acc[pick].cpu(), ref["acc_map"][0]) < 1e-4
-    hip.drop_workspaces(gpu)
-
-
 def test_pipeline_rebuilds_frames_built_before_a_conv_fallback(hip, gpu):
     """Range guard across render_sequence: the stem convolutions' range slot is sticky and written by the side stream
     one or two frames AHEAD, so the overflow of a coming frame is first seen in the snapshot of an earlier one.  Every
@@ -245,43 +226,3 @@ def test_cropped_map_is_completed_for_the_unmasked_branch(hip, gpu, net):
     with torch.no_grad():
         out = r.render(b)
     assert torch.isfinite(out["rgb_map"]).all()
-
-
-@pytest.mark.parametrize("nc,V", [(500, 3), (300, 1), (37, 3), (1, 1), (800, 2), (1100, 3)])
-def test_transhe_as_one_persistent_launch(hip, gpu, net, nc, V):
-    """th_set_vit_mode(ctx, 2): the whole TransHE forward as one persistent kernel (k_vit_persist.hip: V * ceil(N_c / 32)
-    workgroups, one device-wide barrier per block) against the 63 launches of mode 1.  Same arithmetic per element up to
-    the final LayerNorm's summation order, v_exp_f32 in the softmax and a polynomial erf in GELU: within 1e-5 (the parity bar
-    of the stage against the oracle is 1e-4); deterministic from run to run; ragged last workgroup (N_c % 32 != 0)."""
-    g = torch.randn(V, nc, 192, device=gpu, generator=torch.Generator(device=gpu).manual_seed(nc))
-    pe = torch.rand(V, nc, 3, device=gpu, generator=torch.Generator(device=gpu).manual_seed(nc + 1)) * 2 - 1
-    try:
-        hip.set_vit_mode(1, gpu)
-        ref = net.ViT(g, pe, mask=None).clone()
-        hip.set_vit_mode(2, gpu)
-        outs = [net.ViT(g, pe, mask=None).clone() for _ in range(4)]
-    finally:
-        hip.set_vit_mode(1, gpu)
-    assert all(torch.equal(o, outs[0]) for o in outs)
-    assert torch.isfinite(outs[0]).all() and maxdiff(outs[0].cpu(), ref.cpu()) < 1e-5
-    assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")
-
-
-def test_frames_with_the_persistent_transhe(hip, gpu, net):
-    """a frame rendered with TransHE in mode 2 equals the mode-1 frame within 2e-5 (pipeline and render_fast agree bit for bit
-    with each other in either mode: both run the same kernels)"""
-    r = _renderer(net, 300, samples=32)
-    b = synth.batch_to(synth.make_batch(64, 64, 3, seed=0, focal=210.0), gpu)
-    ref = r.render_fast(b, is_train=False)
-    try:
-        hip.set_vit_mode(2, gpu)
-        out = r.render_fast(b, is_train=False)
-        seq = r.render_sequence(itertools.repeat(b))
-        next(seq)
-        piped = next(seq)
-        seq.close()
-    finally:
-        hip.set_vit_mode(1, gpu)
-    assert r.last_stats["valid_samples"] > 1000
-    for k in ("rgb_map", "acc_map"):
-        assert maxdiff(out[k].cpu(), ref[k].cpu()) < 2e-5 and torch.equal(piped[k], out[k])

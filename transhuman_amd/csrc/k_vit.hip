@@ -453,13 +453,12 @@ static int vit_npad(int N) { return (N + 63) / 64 * 64; }
 size_t th_vit_ws(int V, int N, int dim, int heads) {
     size_t T = (size_t)V * N;
     // X, Y, qkv / hidden, and the split K / V^T planes of one layer (2 x [V][heads][2][Npad][64] halves)
-    // (+ the second K / V^T pair and the barrier word of the one-launch form, k_vit_persist.hip)
     return 2 * th_align(T * dim * 4) + th_align(T * 4 * dim * 4) +
-           2 * th_align((size_t)V * heads * 2 * vit_npad(N) * 64 * sizeof(_Float16)) + th_vit_persist_extra_ws(V, N, heads);
+           2 * th_align((size_t)V * heads * 2 * vit_npad(N) * 64 * sizeof(_Float16));
 }
 
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
-                  size_t ws_bytes, hipStream_t s, unsigned int* range, bool allow_h3, bool allow_persist) {
+                  size_t ws_bytes, hipStream_t s, unsigned int* range, bool allow_h3) {
     TH_REQUIRE(W.ready, "ViT weights not set (th_set_vit_weights)");
     const int dim = W.dim, heads = W.heads;
     TH_REQUIRE(dim == heads * 64, "attention kernel is built for head_dim 64 (ViT-tiny: 192 = 3 x 64)");
@@ -473,14 +472,7 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
     const int Npad = vit_npad(N);
     _Float16* Kp = ar.take<_Float16>((size_t)V * heads * 2 * Npad * 64);
     _Float16* Vp = ar.take<_Float16>((size_t)V * heads * 2 * Npad * 64);
-    char* extra = ar.take<char>(th_vit_persist_extra_ws(V, N, heads));
-    TH_REQUIRE(Vp != nullptr && extra != nullptr, "workspace too small");
-    // one persistent launch (k_vit_persist.hip) when the fp16-split path is allowed and the shape is the one it is built for;
-    // (th_set_vit_mode(ctx, 2) or TH_VIT_PERSIST=1; default: the per-layer launches below).  Kp .. extra are contiguous carves.
-    static const bool persist_env = getenv("TH_VIT_PERSIST") != nullptr && getenv("TH_VIT_PERSIST")[0] == '1';
-    if (allow_h3 && (allow_persist || persist_env) && getenv("TH_VIT_GEMM_F32") == nullptr && getenv("TH_VIT_SEPARATE_LN") == nullptr &&
-        getenv("TH_ATTN_FORM") == nullptr && th_vit_persist_ok(W, V, N))
-        return th_vit_persist_launch(W, x, pe, V, N, out, X, Q, (char*)Kp, s, range);
+    TH_REQUIRE(Vp != nullptr, "workspace too small");
     // few tokens: the register-fed form (more, shorter workgroups); many: the LDS-staged form (64 queries share every K / V
     // tile: a quarter of the L2 traffic, which is what bounds the register-fed form from N ~ 1000 on).
     // Measured ViT forward, N_c = 300 / 500 / 1500: 0.80 / 0.99 / 2.15 ms register-fed, 0.86 / 1.07 / 2.06 ms LDS-staged.

@@ -42,6 +42,18 @@ struct ProfScope {
     ~ProfScope() { close(); }
 };
 static ThProf* prof_of(th_ctx* c);
+// one wave: shader-clock ticks (s_memtime) against the constant 100 MHz counter (s_memrealtime) over a short dependent
+// VALU chain -> out[0] = ticks, out[1] = 10 ns units.  The clock domain is chip-wide, so a probe queued right behind a
+// kernel reads the frequency the DVFS governor holds under that kernel's load.
+__global__ void clock_probe_kernel(long long* __restrict__ out, int iters) {
+    float x = 1.0f + threadIdx.x * 1e-3f;
+    const long long t0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) x = fmaf(x, 0.999f, 1e-3f);
+    const long long t1 = clock64(), w1 = wall_clock64();
+    if (threadIdx.x == 0) { out[0] = t1 - t0; out[1] = w1 - w0; }
+    if (x == 12345.678f) out[2] = 1;
+}
+
 
 extern "C" {
 
@@ -102,6 +114,20 @@ int th_profile_enable(th_ctx* c, int on) {
     p->on = on != 0;
     p->used = 0;
     p->spans.clear();
+    return 0;
+}
+
+int th_clock_probe(th_ctx* c, int64_t* out_dev, th_stream stream) {
+    TH_REQUIRE(c && out_dev, "null argument");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)out_dev, 4096);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
+int th_host_wait_read(th_ctx* c, double* ms_out) {
+    TH_REQUIRE(c && ms_out, "null argument");
+    *ms_out = c->host_wait_ms;
+    c->host_wait_ms = 0.0;
     return 0;
 }
 
@@ -266,7 +292,10 @@ int th_range_read(th_ctx* c, int id, uint32_t* out) {
         th_set_error("th_range_read: snapshot " + std::to_string(id) + " has been overwritten by later snapshots");
         return 2;
     }
-    TH_HIP(hipEventSynchronize(c->range_ev[slot]));
+    {
+        ThWaitClock wc(c);
+        TH_HIP(hipEventSynchronize(c->range_ev[slot]));
+    }
     memcpy(out, c->range_host + slot * TH_RANGE_SLOTS, TH_RANGE_SLOTS * sizeof(unsigned int));
     return 0;
 }
@@ -274,8 +303,7 @@ int th_range_read(th_ctx* c, int id, uint32_t* out) {
 int th_range_last_slot(th_ctx* c) { return c ? c->range_last : -1; }
 
 int th_set_vit_mode(th_ctx* c, int mode) {
-    TH_REQUIRE(c && mode >= 0 && mode <= 2, "mode must be 0 (fp32 MFMA GEMMs), 1 (fp16-split MFMA, one launch per layer) or 2 "
-               "(fp16-split MFMA, one persistent launch when the shape allows)");
+    TH_REQUIRE(c && (mode == 0 || mode == 1), "mode must be 0 (fp32 MFMA GEMMs) or 1 (fp16-split MFMA GEMMs)");
     c->vit_mode = mode;
     return 0;
 }
@@ -502,7 +530,7 @@ int th_vit_forward(th_ctx* c, const float* x, const float* pe, int V, int N, flo
     TH_REQUIRE(c && x && pe && out && ws, "null argument");
     ProfScope sc(prof_of(c), TH_PROF_VIT, (hipStream_t)stream);
     return th_vit_launch(c->vit, x, pe, V, N, out, ws, ws_bytes, (hipStream_t)stream, c->vit_mode >= 1 ? c->range_dev : nullptr,
-                         c->vit_mode >= 1, c->vit_mode == 2);
+                         c->vit_mode >= 1);
 }
 
 int th_dparf_encode(th_ctx* c, const float* pts, const int32_t* sel, int P, const float* centres, const float* rot,
@@ -626,23 +654,6 @@ struct ChunkBufs {
     void* mlp_ws;
     size_t mlp_ws_bytes;
 };
-static size_t chunk_bytes(int V, int CH) {
-    size_t rows = (size_t)V * CH;
-    return th_align(rows * 256 * 4) + th_align(rows * 384 * 4) + th_align((size_t)CH * 27 * 4) +
-           th_align((size_t)CH * 4 * 4) + th_align((size_t)CH * 64 * 4) + th_mlp_ws(V, CH);
-}
-static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
-    size_t rows = (size_t)V * CH;
-    b->h = ar.take<float>(rows * 256);
-    b->f = ar.take<float>(rows * 384);
-    b->vdc = ar.take<float>((size_t)CH * 27);
-    b->raw_c = ar.take<float>((size_t)CH * 4);
-    b->pe = ar.take<float>((size_t)CH * 64);
-    b->mlp_ws_bytes = th_mlp_ws(V, CH);
-    b->mlp_ws = ar.take<char>(b->mlp_ws_bytes);
-    TH_REQUIRE(b->mlp_ws != nullptr, "workspace too small");
-    return 0;
-}
 
 // K6 dispatch: fused fp16x3-split kernel (default, V <= 3) or the layer-by-layer fp32 MFMA form
 // which K6 form runs for V views, and therefore which row format the producers must emit into cb.h / cb.f
@@ -652,24 +663,60 @@ static bool tok_gather(const th_ctx* c, int V);
 static int dparf_row_format(const th_ctx* c, int V) {                                                                  // K4
     return mlp_is_fused(c, V) ? (tok_gather(c, V) ? TH_ROWS_NBR : TH_ROWS_FOLDED) : TH_ROWS_F32;
 }
-// Pre-gather sets (th_render_pregather): K5's rows and K4's records of the first TH_PRE_SETS chunks of a frame, written
-// BEFORE the frame's tokens exist -- neither kernel needs them on the TH_ROWS_NBR path -- so that a caller can run TransHE
-// beside them; th_render_rays then only runs the fused kernel for those chunks.
-#define TH_PRE_SETS 5
-struct PreSet { float *f, *h, *pe; };
-static size_t pre_set_bytes(int V, int CH) {
-    // (records of the chunk rounded up to whole tiles, then one 512-byte header per tile)
-    return th_align((size_t)V * CH * 384 * 4) + th_align(((size_t)CH + 32) * 16 * 4 + ((size_t)CH / 32 + 2) * 128 * 4) +
-           th_align((size_t)CH * 64 * 4);
+
+// bytes of K4's TH_ROWS_NBR output for m samples: records rounded up to whole tiles + one 512-byte header per tile
+static size_t nbr_bytes(size_t m) { return (m + 32) * 16 * 4 + (m / 32 + 2) * 128 * 4; }
+
+// ---- the shading pool -------------------------------------------------------------------------------------------
+// Everything the per-sample stage needs PER VALID SAMPLE lives in a second caller-supplied buffer, the shading pool,
+// sized from the frame's valid-sample count (on the host before the stage is queued: th_render_prepass_wait) and shared
+// by all of a context's ray workspaces -- the stage runs on one stream at a time.  Round 3 carved the worst case
+// (5 pre-gather sets + the per-layer path's scratch, 25 GB) into EVERY workspace: 105 GiB for the headline frame.
+//   region A (fused neighbour-record path behind a prepass): the pixel-feature rows, neighbour records + tile headers and
+//            positional encodings of the first pre_n = min(n, TH_PRE_SAMPLES) valid samples as ONE contiguous block each,
+//            written by one K5 and one K4 launch (th_render_pregather) and read by ONE launch of the fused kernel;
+//   region B the chunk buffers (TH_CHUNK samples, row format of the active path) for whatever region A does not cover.
+static long th_pre_init() {
+    const char* e = getenv("TH_PRE_SAMPLES");
+    long v = e ? atol(e) : 0;
+    return (v >= 1024 && v <= (1L << 26)) ? v : 5L * 524288;
 }
-static int pre_carve(ThArena& ar, int V, int CH, PreSet* p) {
-    for (int k = 0; k < TH_PRE_SETS; ++k) {
-        p[k].f = ar.take<float>((size_t)V * CH * 384);
-        p[k].h = (float*)ar.take<char>(((size_t)CH + 32) * 16 * 4 + ((size_t)CH / 32 + 2) * 128 * 4);
-        p[k].pe = ar.take<float>((size_t)CH * 64);
-        TH_REQUIRE(p[k].pe != nullptr, "workspace too small");
+static const long TH_PRE_SAMPLES = th_pre_init();
+struct PoolPlan {
+    long long pre_n = 0;        // samples of region A
+    int ch = 0;                 // samples per pass of region B (0: no region B)
+    size_t a_f = 0, a_h = 0, a_pe = 0, b_h = 0, b_f = 0, b_vdc = 0, b_pe = 0, b_mlp = 0, raw_c = 0, total = 0;
+    size_t b_mlp_bytes = 0;
+};
+static PoolPlan pool_plan(const th_ctx* c, int V, int f_ld, long long n, bool with_pre) {
+    PoolPlan p;
+    const bool fused = mlp_is_fused(c, V);
+    const bool can_pre = fused && tok_gather(c, V);
+    if (n < 0) n = 0;
+    p.pre_n = (with_pre && can_pre) ? (n < TH_PRE_SAMPLES ? n : TH_PRE_SAMPLES) : 0;
+    const long long rest = n - p.pre_n;
+    p.ch = (int)(rest < TH_CHUNK ? rest : TH_CHUNK);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += th_align(bytes); return o; };
+    if (p.pre_n > 0) {
+        p.a_f = take((size_t)p.pre_n * V * f_ld * 4);
+        p.a_h = take(nbr_bytes((size_t)p.pre_n));
+        p.a_pe = take((size_t)p.pre_n * 64 * 4);
     }
-    return 0;
+    if (p.ch > 0) {
+        const size_t rows = (size_t)V * p.ch;
+        // h: fp32 rows / folded rows [rows][256], or the neighbour records of the chunk
+        p.b_h = take(can_pre ? nbr_bytes((size_t)p.ch) : rows * 256 * 4);
+        p.b_f = take(rows * (fused ? f_ld : 384) * 4);
+        p.b_vdc = take((size_t)p.ch * 27 * 4);
+        p.b_pe = take((size_t)p.ch * 64 * 4);
+        p.b_mlp_bytes = fused ? 0 : th_mlp_ws(V, p.ch);
+        p.b_mlp = take(p.b_mlp_bytes);
+    }
+    const long long rc = p.pre_n > p.ch ? p.pre_n : p.ch;
+    p.raw_c = take((size_t)(rc > 0 ? rc : 1) * 4 * 4);
+    p.total = off;
+    return p;
 }
 
 // Fused path: per-frame table T' = tokens fc_0[:, :192]^T ([V*N_c, 256] fp32, one small GEMM) that K4 blends instead
@@ -708,6 +755,24 @@ static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, 
         vd = cb.vdc;
     }
     return th_mlp_forward(c->mlp, V, m, cb.h, cb.f, f_ld, vd, cb.raw_c, cb.mlp_ws, cb.mlp_ws_bytes, s);
+}
+
+static size_t chunk_bytes(int V, int CH) {
+    size_t rows = (size_t)V * CH;
+    return th_align(rows * 256 * 4) + th_align(rows * 384 * 4) + th_align((size_t)CH * 27 * 4) +
+           th_align((size_t)CH * 4 * 4) + th_align((size_t)CH * 64 * 4) + th_mlp_ws(V, CH);
+}
+static int chunk_carve(ThArena& ar, int V, int CH, ChunkBufs* b) {
+    size_t rows = (size_t)V * CH;
+    b->h = ar.take<float>(rows * 256);
+    b->f = ar.take<float>(rows * 384);
+    b->vdc = ar.take<float>((size_t)CH * 27);
+    b->raw_c = ar.take<float>((size_t)CH * 4);
+    b->pe = ar.take<float>((size_t)CH * 64);
+    b->mlp_ws_bytes = th_mlp_ws(V, CH);
+    b->mlp_ws = ar.take<char>(b->mlp_ws_bytes);
+    TH_REQUIRE(b->mlp_ws != nullptr, "workspace too small");
+    return 0;
 }
 
 size_t th_network_workspace_bytes(int V, int P) {
@@ -775,24 +840,28 @@ static int frame_ok(const th_frame* f) {
     return 0;
 }
 
+// ray-stage workspace (per frame in flight): hull mask, hit flags, grid, compaction scratch, sample list, counts, view
+// embeddings, dense raw, the per-frame token table and K4's candidate grid.  Nothing here scales with the VALID samples.
 static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
-    int CH = P < TH_CHUNK ? (int)(P > 0 ? P : 1) : TH_CHUNK;
     return th_align((size_t)P) + th_align((size_t)R * 4) + th_hull_ws(f->n_verts) + th_compact_ws(P) +
            th_align((size_t)P * 4) + th_align(64) + th_align((size_t)R * 27 * 4) + th_align((size_t)P * 16) +
-           th_align(TPRIME_FLOATS(f->V) * 4) + th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1) +
-           chunk_bytes(f->V, CH) + TH_PRE_SETS * pre_set_bytes(f->V, CH);
+           th_align(TPRIME_FLOATS(f->V) * 4) + th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1);
+}
+static int frame_f_ld(const th_frame* f) {
+    return (f->map_channels == TH_MAP_COMPACT || f->map_channels == TH_MAP_SPLIT) ? 272 : 384;
 }
 
 // hull mask -> (small-frame rule) -> compaction -> chunked DPaRF + gather + MLP -> dense raw[P,4]
 // stage A (hull mask, small-frame rule, compaction, view embedding, cleared raw) may run ahead of time
 // (th_render_prepass): it needs only the rays, the posed vertices and the two thresholds.  `prepass` = 1: run
-// stage A only and leave the counts on their way to host_pinned[16..]; 2: stage A already ran into this workspace.
+// stage A only and leave the counts on their way to host_pinned[16..]; 2: stage A already ran into this workspace;
+// 3: stage A ran, queue the pre-gather stage (region A of the pool) and return.
 static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long long P, bool ray_mode, ThArena& ar,
-                        float** raw_out, const uint8_t** mask_out, int64_t* stats_host, hipStream_t s, int prepass = 0,
-                        int slot = 0, const int32_t** ray_hit_out = nullptr) {
+                        void* pool, size_t pool_bytes, float** raw_out, const uint8_t** mask_out, int64_t* stats_host,
+                        hipStream_t s, int prepass = 0, int slot = 0, const int32_t** ray_hit_out = nullptr) {
     const int R = ps.R, S = ps.S, V = f->V;
     const bool compact = f->map_channels == TH_MAP_COMPACT || f->map_channels == TH_MAP_SPLIT;
-    const int f_ld = compact ? 272 : 384;
+    const int f_ld = frame_f_ld(f);
     const int fmt = mlp_row_format(c, V);
     TH_REQUIRE(prepass == 1 || !compact || c->mlp.compact_ready,
                "compact pixel map needs th_mlp_weights.upsample_color (colour-folded layers) to be uploaded");
@@ -809,18 +878,14 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     float* tprime = ar.take<float>(TPRIME_FLOATS(V));
     const size_t gws_b = th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1);
     void* gws = ar.take<char>(gws_b);
-    int CH = P < TH_CHUNK ? (int)P : TH_CHUNK;
-    ChunkBufs cb;
     TH_REQUIRE(raw != nullptr && tprime != nullptr && gws != nullptr, "workspace too small");
-    TH_TRY(chunk_carve(ar, V, CH, &cb));
-    PreSet pre[TH_PRE_SETS];
-    TH_TRY(pre_carve(ar, V, CH, pre));
 
     ThProf* pf = prof_of(c);
     int32_t* hp = c->host_pinned;
     if (prepass == 2 || prepass == 3) {
         hp = c->host_pinned + 16 + 4 * slot;
         TH_HIP(hipStreamWaitEvent(s, c->prepass[slot].ev, 0));      // the prepass may have run on another stream
+        ThWaitClock wc(c);
         TH_HIP(hipEventSynchronize(c->prepass[slot].ev));
     } else {
     ProfScope sc_hull(pf, TH_PROF_HULL, s);          // (RAII: an early error return closes the span)
@@ -852,31 +917,42 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         return 0;
     }
     TH_HIP(hipMemcpyAsync(c->host_pinned, info, 4 * 4, hipMemcpyDeviceToHost, s));
+    ThWaitClock wc(c);
     TH_HIP(hipStreamSynchronize(s));
     }
     const int hit_rays = hp[0], unmasked = hp[1], n = hp[2];
     if (stats_host) { stats_host[0] = hit_rays; stats_host[1] = n; stats_host[2] = -1; stats_host[3] = unmasked; }
+    th_ctx::Prepass* tk = (prepass == 2 || prepass == 3) ? &c->prepass[slot] : nullptr;
     // A cropped map (th_frame.map_source) holds the texels within reach of the hull only.  The un-masked branch (:551,
     // R' <= small_frame_rays: every sample of the hit rays is shaded), a frame without a hull test and a hull test wider
-    // than the crop's reach gather outside it: the rest of the map is written first (same values inside the box).
-    if (f->map_source != nullptr && prepass != 1 && n > 0 &&
+    // than the crop's reach gather outside it: the rest of the map is written first (same values inside the box) -- once
+    // per frame (the pre-gather stage and the shading of one prepass share the completed map).
+    if (f->map_source != nullptr && n > 0 && !(tk && tk->map_done == f->pixel_map_nhwc) &&
         (unmasked || f->hull_thresh < 0.f || f->hull_thresh > f->map_source->reach)) {
         const th_map_source* ms = f->map_source;
         TH_REQUIRE(f->map_channels == TH_MAP_SPLIT && ms->img && ms->lat0 && ms->lat1 && ms->lat2, "map_source: split map only");
         TH_TRY(th_upsample_concat_launch(ms->img, ms->lat0, ms->lat1, ms->lat2, ms->dims, V, f->H, f->W, nullptr, nullptr,
                                          const_cast<float*>(f->pixel_map_nhwc), s, 1, nullptr));
+        if (tk) tk->map_done = f->pixel_map_nhwc;
     }
     const bool can_pre = ray_mode && tok_gather(c, V) && fmt == TH_ROWS_SPLIT;
+    char* pb = (char*)pool;
     if (prepass == 3) {
-        // pre-gather stage: K5 + K4 of the first chunks (needs the map, the cameras, the token centres -- not the tokens)
+        // pre-gather stage: K5 + K4 of the first pre_n valid samples, ONE launch each (needs the map, the cameras, the
+        // token centres -- not the tokens)
         th_ctx::Prepass& t = c->prepass[slot];
         t.npre = 0;
         if (!can_pre || n <= 0) return 0;
+        const PoolPlan pl = pool_plan(c, V, f_ld, n, true);
+        TH_REQUIRE(pool != nullptr && pool_bytes >= pl.total, "shading pool too small (th_shade_pool_bytes)");
+        const int m = (int)pl.pre_n;
+        float* a_f = (float*)(pb + pl.a_f);
+        float* a_h = (float*)(pb + pl.a_h);
+        float* a_pe = (float*)(pb + pl.a_pe);
         const bool grid = getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
-        // K4 of every chunk on the context's second stream, K5 of every chunk on `s`: the two producers share nothing but
-        // the sample list -- K5 sits on the texture path (TA busy 80-90 %, VALU 43 %), K4 since TH_ROWS_NBR is a 7-NN scan
-        // out of LDS (no row gather) -- so their waves co-reside on the CUs instead of running back to back
-        // (TH_K4_SIDE=0: one stream, K5 then K4 per chunk).
+        // K4 on the context's second stream, K5 on `s`: the two producers share nothing but the sample list -- K5 sits on
+        // the texture path (TA busy 80-90 %, VALU 43 %), K4 since TH_ROWS_NBR is a 7-NN scan out of LDS (no row gather) --
+        // so their waves co-reside on the CUs instead of running back to back (TH_K4_SIDE=0: one stream, K4 then K5).
         static const bool k4_side = !(getenv("TH_K4_SIDE") && getenv("TH_K4_SIDE")[0] == '0');
         hipStream_t s4 = s;
         if (k4_side) {
@@ -885,77 +961,81 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
                 TH_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
                 TH_HIP(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
             }
-            TH_HIP(hipEventRecord(c->aux_fork, s));          // sample list, candidate grid and every earlier user of the sets
+            TH_HIP(hipEventRecord(c->aux_fork, s));          // sample list, candidate grid and every earlier user of the pool
             TH_HIP(hipStreamWaitEvent(c->aux, c->aux_fork, 0));
             s4 = c->aux;
         }
-        // (the candidate grid of the 7-NN scan is K4's alone: built on K4's stream, not in front of the pixel gather)
-        if (grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s4));
-        int k = 0;
+        // From here on work may be in flight on the second stream: whatever happens, `s` waits for it before this call
+        // returns (a caller that frees or reuses the pool after an error must not race with K4).
+        int rc = 0;
         {
-            ProfScope ps1(pf, TH_PROF_DPARF, s4);
-            for (int o = 0; o < n && k < TH_PRE_SETS; o += CH, ++k) {
-                const int m = (n - o) < CH ? (n - o) : CH;
-                TH_TRY(th_dparf_launch(nullptr, &ps, f->Rh, f->Th, idx + o, m, f->centres, f->rot, nullptr, V, f->n_clusters, 0.5f,
-                                       pre[k].h, pre[k].pe, TH_ROWS_NBR, grid ? gws : nullptr, s4));
-                if (!k4_side) {
-                    ProfScope ps2(pf, TH_PROF_GATHER, s);
-                    TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx + o, m, f->cams,
-                                               f->scale_xy, pre[k].f, f_ld, fmt, s, c->range_dev));
-                }
+            // (the candidate grid of the 7-NN scan is K4's alone: built on K4's stream, not in front of the pixel gather)
+            if (grid) rc = th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s4);
+            if (rc == 0) {
+                ProfScope ps1(pf, TH_PROF_DPARF, s4);
+                rc = th_dparf_launch(nullptr, &ps, f->Rh, f->Th, idx, m, f->centres, f->rot, nullptr, V, f->n_clusters, 0.5f, a_h,
+                                     a_pe, TH_ROWS_NBR, grid ? gws : nullptr, s4);
+            }
+            if (rc == 0) {
+                ProfScope ps2(pf, TH_PROF_GATHER, s);
+                rc = th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx, m, f->cams,
+                                         f->scale_xy, a_f, f_ld, fmt, s, c->range_dev);
             }
         }
         if (k4_side) {
-            ProfScope ps2(pf, TH_PROF_GATHER, s);
-            int k5 = 0;
-            for (int o = 0; o < n && k5 < TH_PRE_SETS; o += CH, ++k5) {
-                const int m = (n - o) < CH ? (n - o) : CH;
-                TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx + o, m, f->cams,
-                                           f->scale_xy, pre[k5].f, f_ld, fmt, s, c->range_dev));
-            }
-            ps2.close();
-            TH_HIP(hipEventRecord(c->aux_join, c->aux));
-            TH_HIP(hipStreamWaitEvent(s, c->aux_join, 0));
+            const hipError_t e1 = hipEventRecord(c->aux_join, c->aux);
+            const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, c->aux_join, 0) : e1;
+            if (e2 != hipSuccess) (void)hipStreamSynchronize(c->aux);      // last resort: nothing left in flight
         }
+        if (rc != 0) return rc;
         if (!t.ev2) TH_HIP(hipEventCreateWithFlags(&t.ev2, hipEventDisableTiming));
         TH_HIP(hipEventRecord(t.ev2, s));
-        t.npre = k;
+        t.npre = m;
         t.pre_map = f->pixel_map_nhwc;
         t.pre_centres = f->centres;
+        t.pre_pool = pool;
         return 0;
     }
-    int npre = 0;
+    int npre = 0;                        // valid samples whose rows / records sit in region A of the pool
     if (prepass == 2) {
         th_ctx::Prepass& t = c->prepass[slot];
-        if (t.npre > 0 && can_pre && t.pre_map == f->pixel_map_nhwc && t.pre_centres == f->centres) {
+        if (t.npre > 0 && can_pre && t.pre_map == f->pixel_map_nhwc && t.pre_centres == f->centres && t.pre_pool == pool) {
             npre = t.npre;
             TH_HIP(hipStreamWaitEvent(s, t.ev2, 0));
         }
         t.npre = 0;
     }
-    if (!ray_mode) TH_HIP(hipMemsetAsync(cb.vdc, 0, (size_t)CH * 27 * 4, s));   // zero view dirs, if_mesh_renderer.py:62
+    const PoolPlan pl = pool_plan(c, V, f_ld, n, npre > 0);
+    TH_REQUIRE(n <= 0 || (pool != nullptr && pool_bytes >= pl.total), "shading pool too small (th_shade_pool_bytes)");
+    TH_REQUIRE(npre == 0 || npre == pl.pre_n, "pre-gather stage and shading disagree on the pool layout");
+    ChunkBufs cb{};
+    const int CH = pl.ch;
+    cb.raw_c = (float*)(pb + pl.raw_c);
+    if (CH > 0) {
+        cb.h = (float*)(pb + pl.b_h); cb.f = (float*)(pb + pl.b_f); cb.vdc = (float*)(pb + pl.b_vdc);
+        cb.pe = (float*)(pb + pl.b_pe); cb.mlp_ws = pb + pl.b_mlp; cb.mlp_ws_bytes = pl.b_mlp_bytes;
+    }
+    if (!ray_mode && CH > 0) TH_HIP(hipMemsetAsync(cb.vdc, 0, (size_t)CH * 27 * 4, s));   // zero view dirs, if_mesh_renderer.py:62
     TH_REQUIRE(f->n_clusters <= TH_MAX_CLUSTERS, "too many token clusters");
     const float* table = nullptr;
     if (n > 0) TH_TRY(token_table(c, f->tokens, V, f->n_clusters, tprime, &table, s));
     // exact candidate grid for the 7-NN scan of K4 (TH_DPARF_NOGRID=1: full scan, same result)
-    // (not needed when every chunk's records were pre-gathered: K4 does not run again)
-    const bool use_grid = n > 0 && prepass != 1 && (long long)npre * CH < n && getenv("TH_DPARF_NOGRID") == nullptr &&
-                          (size_t)f->n_clusters * 4 <= 48 * 1024;
+    // (not needed when every sample's records were pre-gathered: K4 does not run again)
+    const bool use_grid = n > npre && getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
     if (use_grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s));
-    for (int o = 0, kc = 0; o < n; o += CH, ++kc) {
+    if (npre > 0) {          // rows and records of these samples were written by th_render_pregather: ONE fused launch
+        ChunkBufs pc = cb;
+        pc.f = (float*)(pb + pl.a_f); pc.h = (float*)(pb + pl.a_h); pc.pe = (float*)(pb + pl.a_pe);
+        {
+            ProfScope ps3(pf, TH_PROF_MLP, s);
+            TH_TRY(mlp_dispatch(c, V, npre, pc, f_ld, vd_all, idx, S, unmasked, s, tprime, f->n_clusters));
+        }
+        ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
+        TH_TRY(th_scatter_raw_launch(cb.raw_c, idx, npre, unmasked, raw, s));
+    }
+    for (int o = npre; o < n; o += CH) {
         int m = (n - o) < CH ? (n - o) : CH;
         const int32_t* sel = idx + o;
-        if (kc < npre) {        // rows and records of this chunk were written by th_render_pregather
-            ChunkBufs pc = cb;
-            pc.f = pre[kc].f; pc.h = pre[kc].h; pc.pe = pre[kc].pe;
-            {
-                ProfScope ps3(pf, TH_PROF_MLP, s);
-                TH_TRY(mlp_dispatch(c, V, m, pc, f_ld, vd_all, sel, S, unmasked, s, tprime, f->n_clusters));
-            }
-            ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
-            TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));
-            continue;
-        }
         // (K5 first: K4's small output -- records, tile headers, positional encodings, 0.3 KB per sample -- is then the
         // last thing written before the fused kernel reads it at the start of every tile: MALL instead of HBM)
         {
@@ -989,8 +1069,36 @@ size_t th_render_workspace_bytes(const th_frame* f, int R, int S) {
     return shade_ws_bytes(f, (long long)R * S, R);
 }
 
+size_t th_shade_pool_bytes(th_ctx* c, const th_frame* f, long long n_valid, int with_pregather) {
+    if (!c || !f || f->V < 1) return 0;
+    const int f_ld = frame_f_ld(f);
+    size_t a = pool_plan(c, f->V, f_ld, n_valid, false).total;
+    if (with_pregather) {
+        const size_t b = pool_plan(c, f->V, f_ld, n_valid, true).total;
+        if (b > a) a = b;
+    }
+    return a;
+}
+
+int th_render_prepass_wait(th_ctx* c, const void* ws, int64_t* counts_host) {
+    TH_REQUIRE(c && ws && counts_host, "null argument");
+    for (int k = 0; k < th_ctx::kPrepassSlots; ++k) {
+        th_ctx::Prepass& t = c->prepass[k];
+        if (!t.valid || t.ws != ws || !t.ev) continue;
+        {
+            ThWaitClock wc(c);
+            TH_HIP(hipEventSynchronize(t.ev));
+        }
+        const int32_t* hp = c->host_pinned + 16 + 4 * k;
+        counts_host[0] = hp[0]; counts_host[1] = hp[1]; counts_host[2] = hp[2];
+        return 0;
+    }
+    return 1;                                   // no prepass pending for this workspace
+}
+
 int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* rgb, float* acc, float* depth,
-                   int white_bkgd, void* ws, size_t ws_bytes, int64_t* stats_host, th_stream stream) {
+                   int white_bkgd, void* ws, size_t ws_bytes, void* pool, size_t pool_bytes, int64_t* stats_host,
+                   th_stream stream) {
     TH_REQUIRE(c && f && rays && rgb && acc && depth && ws, "null argument");
     TH_TRY(frame_ok(f));
     TH_REQUIRE(rays->pts == nullptr && rays->ray_o && rays->ray_d && rays->near && rays->far && rays->t_vals &&
@@ -1015,7 +1123,8 @@ int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* r
         if (t.rays == (const void*)rays->ray_o && t.R == R && t.S == S) slot = k;
     }
     const int32_t* ray_hit = nullptr;
-    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, stats_host, s, slot >= 0 ? 2 : 0, slot >= 0 ? slot : 0, &ray_hit));
+    TH_TRY(shade_points(c, f, ps, P, true, ar, pool, pool_bytes, &raw, &mask, stats_host, s, slot >= 0 ? 2 : 0,
+                        slot >= 0 ? slot : 0, &ray_hit));
     ProfScope sc(prof_of(c), TH_PROF_COMPOSITE, s);
     TH_TRY(th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, mask, s, ray_hit));
     const int snap = th_range_snapshot(c, stream);
@@ -1042,6 +1151,7 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     th_ctx::Prepass& t = c->prepass[slot];
     t.valid = false;
     t.npre = 0;                                   // (a pre-gather of an abandoned frame must not outlive its prepass)
+    t.map_done = nullptr;
     if (R <= 0) return 0;
     long long P = (long long)R * S;
     TH_REQUIRE(P < (1LL << 31), "R*S must fit in int32");
@@ -1050,13 +1160,14 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     ThPointSrc ps = th_src(rays);
     float* raw = nullptr;
     const uint8_t* mask = nullptr;
-    TH_TRY(shade_points(c, f, ps, P, true, ar, &raw, &mask, nullptr, s, 1, slot));
+    TH_TRY(shade_points(c, f, ps, P, true, ar, nullptr, 0, &raw, &mask, nullptr, s, 1, slot));
     t.ws = ws; t.rays = rays->ray_o; t.R = R; t.S = S;
     t.valid = true;
     return 0;
 }
 
-int th_render_pregather(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, th_stream stream) {
+int th_render_pregather(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, void* pool,
+                        size_t pool_bytes, th_stream stream) {
     TH_REQUIRE(c && f && rays && ws, "null argument");
     TH_REQUIRE(f->verts_world && f->Rh && f->Th && f->cams && f->scale_xy && f->pixel_map_nhwc && f->centres && f->rot &&
                    f->n_clusters >= 7 && f->V >= 1 && f->V <= 4,
@@ -1076,7 +1187,7 @@ int th_render_pregather(th_ctx* c, const th_frame* f, const th_points* rays, voi
     ThPointSrc ps = th_src(rays);
     float* raw = nullptr;
     const uint8_t* mask = nullptr;
-    return shade_points(c, f, ps, P, true, ar, &raw, &mask, nullptr, (hipStream_t)stream, 3, slot);
+    return shade_points(c, f, ps, P, true, ar, pool, pool_bytes, &raw, &mask, nullptr, (hipStream_t)stream, 3, slot);
 }
 
 int th_render_prepass_cancel(th_ctx* c) {
@@ -1101,7 +1212,7 @@ __global__ void extract_sigma_kernel(const float4* __restrict__ raw, const uint8
 size_t th_sigma_grid_workspace_bytes(const th_frame* f, int P) { return shade_ws_bytes(f, P, P); }
 
 int th_eval_sigma_grid(th_ctx* c, const th_frame* f, const float* pts, int P, float* sigma_out, void* ws,
-                       size_t ws_bytes, int64_t* stats_host, th_stream stream) {
+                       size_t ws_bytes, void* pool, size_t pool_bytes, int64_t* stats_host, th_stream stream) {
     TH_REQUIRE(c && f && pts && sigma_out && ws, "null argument");
     TH_TRY(frame_ok(f));
     hipStream_t s = (hipStream_t)stream;
@@ -1112,7 +1223,7 @@ int th_eval_sigma_grid(th_ctx* c, const th_frame* f, const float* pts, int P, fl
     ps.pts = pts; ps.R = P; ps.S = 1;
     float* raw = nullptr;
     const uint8_t* mask = nullptr;
-    TH_TRY(shade_points(c, f, ps, P, false, ar, &raw, &mask, stats_host, s));
+    TH_TRY(shade_points(c, f, ps, P, false, ar, pool, pool_bytes, &raw, &mask, stats_host, s));
     hipLaunchKernelGGL(extract_sigma_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, (const float4*)raw, mask, (long long)P,
                        sigma_out);
     TH_LAUNCH_CHECK();

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <time.h>
 #include <string>
 
 #include "transhuman_hip.h"
@@ -88,12 +89,6 @@ bool th_gemm_h3_ok(int M, const ThPacked& W, bool ln);
 // qkv epilogue of the ViT (optional): output columns >= dim (the keys and values of row = view * N + key) are not stored
 // as fp32 but as the fp16 hi | lo operand planes of attn2_kernel (k_vit.hip: Kp [V][heads][2][Npad][64],
 // Vp [V][heads][2][64][Npad] in the fragment key order) -- the per-layer kv_split launch disappears
-// k_vit_persist.hip: TransHE as one persistent launch
-struct ThVitPacked;
-bool th_vit_persist_ok(const ThVitPacked& W, int V, int N);
-size_t th_vit_persist_extra_ws(int V, int N, int heads);
-int th_vit_persist_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, float* X, float* Qb,
-                          char* planes, hipStream_t s, unsigned int* range);
 struct ThQkvSplit {
     _Float16* Kp;
     _Float16* Vp;
@@ -315,12 +310,14 @@ struct th_ctx {
         const void* rays = nullptr;
         int R = 0, S = 0;
         bool valid = false;
-        // th_render_pregather: the first `npre` chunks' pixel rows (K5) and neighbour records (K4) are already in the
-        // workspace's pre-gather sets, written for this map / these token centres; ev2 marks their completion
+        // th_render_pregather: the pixel rows (K5) and neighbour records (K4) of the first `npre` valid SAMPLES are already
+        // in region A of the shading pool `pre_pool`, written for this map / these token centres; ev2 marks their completion
         hipEvent_t ev2 = nullptr;
         int npre = 0;
         const void* pre_map = nullptr;
         const void* pre_centres = nullptr;
+        const void* pre_pool = nullptr;
+        const void* map_done = nullptr;      // the cropped map this prepass's frame has already completed (written once)
     };
     static constexpr int kPrepassSlots = 4;
     Prepass prepass[kPrepassSlots];
@@ -338,6 +335,20 @@ struct th_ctx {
     hipEvent_t range_ev[kRangeSnaps] = {};
     int range_gen[kRangeSnaps] = {-1, -1, -1, -1, -1, -1, -1, -1};   // generation each pinned buffer holds
     int range_gen_next = 0, range_last = -1;
+    // host time spent inside BLOCKING waits of the entry points (hipEventSynchronize / hipStreamSynchronize on counts
+    // and range snapshots): bench.py subtracts it from its host-side loop time to get the pure queueing cost
+    double host_wait_ms = 0.0;
+};
+// RAII stopwatch around a blocking wait (th_host_wait_read drains the sum)
+struct ThWaitClock {
+    th_ctx* c;
+    timespec t0;
+    explicit ThWaitClock(th_ctx* c_) : c(c_) { clock_gettime(CLOCK_MONOTONIC, &t0); }
+    ~ThWaitClock() {
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        c->host_wait_ms += (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    }
 };
 
 // ---- launchers (one group per .hip file) -------------------------------------------
@@ -413,7 +424,7 @@ int th_view_embed_launch(const float* d, int R, int res, float* out, hipStream_t
 // k_vit.hip
 size_t th_vit_ws(int V, int N, int dim, int heads);
 int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, int N, float* out, void* ws,
-                  size_t ws_bytes, hipStream_t s, unsigned int* range = nullptr, bool allow_h3 = true, bool allow_persist = false);
+                  size_t ws_bytes, hipStream_t s, unsigned int* range = nullptr, bool allow_h3 = true);
 
 // k_smpl.hip
 size_t th_smpl_ws(int nv);

@@ -190,8 +190,9 @@ class StemExchange(TokenExchange):
     that a rank does not own the stem and TransHE of the same frame.
     What it buys is an ESTIMATE until a multi-GPU node has run it: at N = 8 a rank's frame is 3.5 ms of which the replicated
     stem is 0.5 ms of chip time on 7 frames in 8; the broadcast moves 69 MB per frame and rank (21 GB/s inbound at 3.2 ms per
-    frame, against 7 xGMI links of ~153 GB/s) from a stream of its own.  Off below 4 ranks (the stem is a small share of a
-    rank's frame there); TH_STEM_EXCHANGE=0 | 1 overrides.
+    frame, against 7 xGMI links of ~153 GB/s) from a stream of its own.  OFF by default (round 4): the first run on a
+    real multi-GPU node measures the safe variant; TH_STEM_EXCHANGE=1 switches it on (tools/run_scale.sh runs both and
+    prints the A/B), and only a hardware line that shows it paying flips the default.
     Side effect: the stem's BatchNorm running statistics advance only on the owner of a frame (they do not enter the
     train()-mode forward the renderer runs, run.py:29)."""
 
@@ -205,8 +206,7 @@ class StemExchange(TokenExchange):
     @staticmethod
     def wanted(world):
         import os
-        e = os.environ.get("TH_STEM_EXCHANGE")
-        return (e == "1") if e in ("0", "1") else world >= 4
+        return os.environ.get("TH_STEM_EXCHANGE") == "1" and world >= 2
 
     @staticmethod
     def latent_shapes(V, H, W):

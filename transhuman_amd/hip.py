@@ -64,6 +64,8 @@ SYMBOLS = {
     "th_ctx_destroy": (None, [C.c_void_p]),
     "th_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "th_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "th_host_wait_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "th_clock_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "th_set_mlp_weights": (C.c_int, [C.c_void_p, C.POINTER(ThMlpWeights), C.c_void_p]),
     "th_set_mlp_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_vit_mode": (C.c_int, [C.c_void_p, C.c_int]),
@@ -132,12 +134,15 @@ SYMBOLS = {
                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "th_view_embed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "th_render_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int, C.c_int]),
+    "th_shade_pool_bytes": (C.c_size_t, [C.c_void_p, C.POINTER(ThFrame), C.c_longlong, C.c_int]),
+    "th_render_prepass_wait": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     "th_render_rays": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_void_p,
-                                 C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
+                                 C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                 C.POINTER(C.c_int64), C.c_void_p]),
     "th_render_prepass": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
                                     C.c_void_p]),
     "th_render_pregather": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
-                                      C.c_void_p]),
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "th_conv_pack_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "th_conv_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                C.POINTER(C.c_float), C.c_void_p]),
@@ -153,7 +158,7 @@ SYMBOLS = {
     "th_render_prepass_drop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_sigma_grid_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int]),
     "th_eval_sigma_grid": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                     C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
+                                     C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.c_void_p]),
 }
 
 _lib = None
@@ -177,7 +182,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 5:
+    if lib.th_abi_version() != 6:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -772,7 +777,7 @@ def network_forward(net, pixel_feat, viewdir, pts_smpl, centres, rot, tokens, ma
     if P == 0:
         return raw
     ws = _ws(lib.th_network_workspace_bytes(V, P), pf.device)
-    for _ in range(2):
+    for _ in range(3):
         _check(lib.th_network_forward(ctx(pf.device), _p(pf), _p(vd), _p(ps), _p(m), P, _p(c), _p(r), _p(t), V, t.shape[1],
                                       _p(raw), _p(ws), ws.numel(), _stream()))
         if _guard(pf.device, lib.th_range_last_slot(ctx(pf.device))):
@@ -965,10 +970,42 @@ def _cached_ws(nbytes, device, slot=0):
     return cur
 
 
+_pool_cache = {}
+
+
+def _shade_pool(frame_c, n_valid, with_pregather, device):
+    """The context's shading pool (include/transhuman_hip.h: th_shade_pool_bytes), ONE per device, grown on demand to what
+    ``n_valid`` valid samples need in the context's current mode.  Growth allocates on the current stream; the old pool
+    goes back to torch's allocator, which hands it out again only behind the work already queued on it."""
+    need = int(load_library().th_shade_pool_bytes(ctx(device), C.byref(frame_c), int(n_valid), int(with_pregather)))
+    key = str(device)
+    cur = _pool_cache.get(key)
+    if cur is None or cur.numel() < need:
+        _pool_cache[key] = None
+        # (headroom: frames of a sequence differ by a few per cent; a pool that grows every other frame would thrash)
+        cur = torch.empty(int(need * 1.0625) + 4096, dtype=torch.uint8, device=device)
+        _pool_cache[key] = cur
+    cur.record_stream(torch.cuda.current_stream(device))
+    return cur
+
+
+def _prepass_counts(ws, device):
+    """(hit_rays, unmasked, n_valid) of the prepass pending in workspace ``ws`` (host wait), or None"""
+    out = (C.c_int64 * 3)()
+    rc = load_library().th_render_prepass_wait(ctx(device), _p(ws), out)
+    if rc == 1:
+        return None
+    _check(rc)
+    return int(out[0]), int(out[1]), int(out[2])
+
+
 def drop_workspaces(device=None):
-    """Forget the cached render workspaces (tens of GB each at full frame size) -- e.g. between unrelated workloads of
-    one process; pending prepasses of those workspaces are cancelled."""
+    """Forget the cached render workspaces and the shading pool (GBs at full frame size) -- e.g. between unrelated
+    workloads of one process; pending prepasses of those workspaces are cancelled."""
     lib = load_library()
+    for dev in list(_pool_cache.keys()):
+        if device is None or str(device) == dev:
+            _pool_cache.pop(dev, None)
     for (dev, _slot) in list(_ws_cache.keys()):
         if device is None or str(device) == dev:
             _ws_cache.pop((dev, _slot), None)
@@ -1005,7 +1042,13 @@ def render_pregather(net, frame, points, slot=0):
     _sync_weights(net, "mlp")
     dev = frame.verts.device
     _, ws = points._prepass_keep
-    _check(lib.th_render_pregather(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(ws), ws.numel(), _stream()))
+    cnt = _prepass_counts(ws, dev)
+    if cnt is None:
+        return
+    pool = _shade_pool(frame.c, cnt[2], True, dev)
+    points._pregathered = True
+    _check(lib.th_render_pregather(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(ws), ws.numel(), _p(pool), pool.numel(),
+                                   _stream()))
 
 
 def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_frame_rays=None):
@@ -1031,29 +1074,44 @@ def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_f
         fc = ThFrame.from_buffer_copy(frame.c)
         fc.small_frame_rays = int(small_frame_rays)
     need = lib.th_render_workspace_bytes(C.byref(fc), R, points.S)
+    n_bound, pre = R * points.S, False
     if getattr(points, "_prepass_pending", False) and points._prepass_keep[1].numel() >= need:
         points._prepass_pending = False
         ws = points._prepass_keep[1]                        # the workspace its prepass ran in
+        cnt = _prepass_counts(ws, dev)                      # (on the host long ago in a frame pipeline)
+        if cnt is not None:
+            n_bound, pre = cnt[2], bool(getattr(points, "_pregathered", False))
     else:
         ws = _cached_ws(need, dev)
         _check(lib.th_render_prepass_drop(ctx(dev), _p(ws)))  # a token queued there for other (possibly freed) rays
+    points._pregathered = False
+    # the shading pool: sized from the valid-sample count when a prepass has put it on the host, else for the chunk
+    # buffers only (the count bounds the chunk, not the pool)
+    pool = _shade_pool(fc, n_bound, pre, dev)
     stats = (C.c_int64 * 4)()
     _check(lib.th_render_rays(ctx(dev), C.byref(fc), C.byref(points.c), _p(rgb), _p(acc), _p(dep), int(white_bkgd),
-                              _p(ws), ws.numel(), stats, _stream()))
+                              _p(ws), ws.numel(), _p(pool), pool.numel(), stats, _stream()))
     st = dict(hit_rays=stats[0], valid_samples=stats[1], unmasked=stats[3])
     slot = int(stats[2])
     if defer_guard:
         return rgb, acc, dep, st, (lambda: _guard(dev, slot))
-    if not _guard(dev, slot):
+    # a snapshot that is not clean (or was overwritten before it could be read) -> the paths the guard switched are in
+    # effect now: render again and check THAT frame's snapshot too (bounded: every switch is one-way, three tries cover
+    # MLP + stem + TransHE tripping one after the other)
+    for _ in range(3):
+        if _guard(dev, slot):
+            break
         if (conv_fallback(dev) or vit_fallback(dev)) and getattr(frame, "rebuild", None) is not None:
             frame = frame.rebuild()                  # frame constants again, through the stock convolutions
             keep_sfr = fc.small_frame_rays
             fc = ThFrame.from_buffer_copy(frame.c)
             fc.small_frame_rays = keep_sfr
         _check(lib.th_render_prepass_drop(ctx(dev), _p(ws)))
+        pool = _shade_pool(fc, st["valid_samples"], False, dev)   # (the guard may have changed the mode: other row formats)
         _check(lib.th_render_rays(ctx(dev), C.byref(fc), C.byref(points.c), _p(rgb), _p(acc), _p(dep),
-                                  int(white_bkgd), _p(ws), ws.numel(), stats, _stream()))
+                                  int(white_bkgd), _p(ws), ws.numel(), _p(pool), pool.numel(), stats, _stream()))
         st = dict(hit_rays=stats[0], valid_samples=stats[1], unmasked=stats[3])
+        slot = int(stats[2])
     return rgb, acc, dep, st
 
 
@@ -1067,9 +1125,10 @@ def eval_sigma_grid(net, frame, pts):
         return out, dict(valid_samples=0)
     ws = _cached_ws(lib.th_sigma_grid_workspace_bytes(C.byref(frame.c), P), p.device)
     stats = (C.c_int64 * 4)()
-    for _ in range(2):
-        _check(lib.th_eval_sigma_grid(ctx(p.device), C.byref(frame.c), _p(p), P, _p(out), _p(ws), ws.numel(), stats,
-                                      _stream()))
+    for _ in range(3):
+        pool = _shade_pool(frame.c, P, False, p.device)        # (inside the loop: the guard may have changed the mode)
+        _check(lib.th_eval_sigma_grid(ctx(p.device), C.byref(frame.c), _p(p), P, _p(out), _p(ws), ws.numel(), _p(pool),
+                                      pool.numel(), stats, _stream()))
         if _guard(p.device, int(stats[2])):
             break
         if (conv_fallback(p.device) or vit_fallback(p.device)) and getattr(frame, "rebuild", None) is not None:
@@ -1112,9 +1171,22 @@ def profile_read(device=None):
     return {PROF_PHASES[i]: (ms[i], cnt[i]) for i in range(6)}
 
 
+def clock_probe(out):
+    """th_clock_probe: queue the shader-clock probe on the current stream; ``out`` = int64 device tensor of >= 3 words
+    (ticks, 10 ns units, scratch).  GHz = out[0] / (10 * out[1]) once the stream has passed it."""
+    assert out.dtype == torch.int64 and out.numel() >= 3 and out.is_cuda
+    _check(load_library().th_clock_probe(ctx(out.device), _p(out), _stream()))
+
+
+def host_wait_read(device=None):
+    """th_host_wait_read: host ms spent in the blocking waits of the entry points since the last call (reads and clears)"""
+    ms = C.c_double()
+    _check(load_library().th_host_wait_read(ctx(device), C.byref(ms)))
+    return float(ms.value)
+
+
 def set_vit_mode(mode, device=None):
-    """th_set_vit_mode: 0 = TransHE's dense layers on the fp32 MFMA GEMMs, 1 (default) = fp16-split arithmetic, one launch per
-    layer, 2 = fp16-split arithmetic with the whole forward as one persistent launch when the shape allows (k_vit_persist.hip)."""
+    """th_set_vit_mode: 0 = TransHE's dense layers on the fp32 MFMA GEMMs, 1 (default) = fp16-split arithmetic."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     _check(load_library().th_set_vit_mode(ctx(dev), int(mode)))
     _user_vit_mode[_dev_index(dev)] = int(mode)

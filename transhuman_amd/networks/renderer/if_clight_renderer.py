@@ -135,6 +135,10 @@ class Renderer:
         cfg = get_cfg()
         assert cfg.time_steps == 1                                                  # :412
         t = 0
+        # the weight image (and with it the sticky range slot of the stem convolutions, which belongs to the same
+        # parameter set) is brought up to date BEFORE the stem runs and on the stream that runs it: a frame's own
+        # convolutions are then never queued in front of the clear that new weights trigger
+        hip._sync_weights(self.net, "mlp")
         images = batch["input_imgs"][t]
         images = images.reshape(-1, *images.shape[2:])                              # :397
         dev = images.device
