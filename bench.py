@@ -558,9 +558,12 @@ def main():
         step()
     hip.profile_enable(os.environ.get("TH_NO_PROF") != "1")
     hip.profile_read()
-    # shader-clock probes: one 15 us wave queued behind the shading of every (up to 64) timed steps
+    # shader-clock probes: one 15 us wave per timed step (up to 64) on a stream of its own -- it starts as soon as a CU
+    # has room, i.e. beside whatever the device is running when the host queues it (the fused MLP, 85 % of the time): the
+    # clock the DVFS governor holds UNDER the load, not the one it jumps to when the queue drains
     n_probe = min(args.steps, 64) if os.environ.get("TH_NO_PROF") != "1" else 0
     clk = torch.zeros((max(n_probe, 1), 4), dtype=torch.int64, device=dev)
+    probe_stream = torch.cuda.Stream(dev)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
@@ -570,7 +573,8 @@ def main():
     for i in range(args.steps):
         img, stats = step()
         if i < n_probe:
-            hip.clock_probe(clk[i])
+            with torch.cuda.stream(probe_stream):
+                hip.clock_probe(clk[i])
     host_dt = time.perf_counter() - t0             # the host is done queueing here (the device may still be working)
     host_wait_ms = hip.host_wait_read(dev)         # ... of which it spent this long blocked on counts / guard snapshots
     torch.cuda.synchronize()
@@ -678,7 +682,8 @@ def shader_clock(clk, n):
         return None
     g = (c[ok, 0] / (10.0 * c[ok, 1])).numpy()
     return {"median": float(np.median(g)), "min": float(g.min()), "max": float(g.max()), "probes": int(ok.sum()),
-            "note": "s_memtime ticks / s_memrealtime (100 MHz) of a one-wave probe queued behind each timed step's shading"}
+            "note": "s_memtime ticks / s_memrealtime (100 MHz) of a one-wave probe per timed step on its own stream (runs beside "
+                    "the frame's kernels: the clock under load)"}
 
 
 def finish(dist_on, res):

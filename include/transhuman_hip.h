@@ -289,6 +289,13 @@ int th_nchw_to_nhwc(th_ctx* ctx, const float* src, int V, int C, int H, int W, f
 int th_pixel_gather(th_ctx* ctx, const float* pixel_map_nhwc, int V, int C, int H, int W,
                     const float* pts_world, const int32_t* sel, int P, const float* cams,
                     const float* scale_xy, float* out, int ldo, th_stream stream);
+/* The form of the same gather that the frame-level entry points run (ABI 6): the split compact map (th_upsample_concat_split:
+ * [V,H,W,256] latents followed by a [V,H,W,4] r g b 0 plane) in, TH_ROWS_SPLIT rows out -- per (sample, view) 272 / 8 groups
+ * of [8 fp16 hi halves | 8 fp16 lo halves], x = hi + lo, the layout the fused MLP kernel stages by LDS-DMA; out_rows holds
+ * P * V * ldo * 4 bytes.  (Exposed so that the split-row kernel can be tested on its own against th_pixel_gather.) */
+int th_pixel_gather_split(th_ctx* ctx, const float* map_split, int V, int H, int W, const float* pts_world,
+                          const int32_t* sel, int P, const float* cams, const float* scale_xy, void* out_rows,
+                          int ldo, th_stream stream);
 
 /* ---- K6: per-point multi-view MLP ------------------------------------------ */
 /* Network.forward, cross_transformer.py:207-353, on already-gathered inputs.

@@ -153,3 +153,57 @@ def test_reference_loading_renders_like_the_injected_renderer(reference_env, gpu
     assert renderer.last_stats["hit_rays"] > 100
     for k in ("rgb_map", "acc_map", "depth_map"):
         assert out[k].shape == ref[k].shape and torch.equal(out[k], ref[k]), k
+
+
+@pytest.mark.gpu
+def test_trainer_wrapper_validation_step(reference_env, gpu):
+    """The reference's training-side caller of the boundary, restated: lib/train/trainers/if_nerf_clight.py:24-31 builds
+    ``if_clight_renderer.Renderer(self.net)`` directly (module import at :4, not through the YAML path), :45 calls
+    ``self.renderer.render(batch)`` and :83-86 forms the image loss on ``batch['mask_at_box']``; Trainer.val
+    (trainer.py:131-150) runs that wrapper with ``network.eval()`` under ``torch.no_grad()`` -- evaluation during
+    training.  With the renderer module swapped for this repository's the validation step runs (eval-mode BatchNorm:
+    the stem goes through the stock modules' running statistics, everything behind it through the HIP kernels) and
+    the train step is refused with a message that says why (Renderer.render carries no autograd)."""
+    from transhuman_amd import synth
+    from util import make_sd
+    cfg = reference_env
+    mod = load_source(cfg.renderer_module, cfg.renderer_path)
+    network = load_source(cfg.cross_transformer_network_module, cfg.cross_transformer_network_path).Network().cuda()
+    network.load_state_dict(make_sd(), strict=True)
+
+    class NetworkWrapper(torch.nn.Module):                       # if_nerf_clight.py:24-104, non-patch branch
+        def __init__(self, net):
+            super().__init__()
+            self.net = net
+            self.renderer = mod.Renderer(self.net)               # :29
+            self.img2mse = lambda x, y: torch.mean((x - y) ** 2)   # :31
+
+        def forward(self, batch):
+            ret = self.renderer.render(batch)                    # :45
+            mask = batch["mask_at_box"]                          # :83
+            img_loss = self.img2mse(ret["rgb_map"][mask], batch["rgb"][mask])
+            return ret, img_loss, {"img_loss": img_loss, "loss": img_loss}, {}
+
+    wrapper = NetworkWrapper(network)
+    bc = synth.make_batch(24, 24, 3, seed=0, all_rays=False, focal=75.0)
+    R = bc["ray_o"].shape[1]
+    bc["rgb"] = torch.rand(1, R, 3)
+    bc["mask_at_box"] = torch.ones(1, R, dtype=torch.bool)
+    b = synth.batch_to(bc, gpu)
+    # Trainer.train (trainer.py:79-86): gradients on -> refused, loudly
+    wrapper.train()
+    with pytest.raises(RuntimeError, match="inference-only"):
+        wrapper(b)
+    # Trainer.val (trainer.py:131-150)
+    wrapper.eval()
+    with torch.no_grad():
+        out, loss, stats, _ = wrapper(b)
+        out2, loss2, _, _ = wrapper(b)
+    assert out["rgb_map"].shape == (1, R, 3) and torch.isfinite(out["rgb_map"]).all() and torch.isfinite(loss)
+    assert torch.equal(out["rgb_map"], out2["rgb_map"]) and float(loss) == float(loss2)       # eval mode: no state changes
+    assert float(out["acc_map"].max()) > 0.0
+    # the same call with the network in train() (run.py:29's state): batch statistics in the stem, HIP kernels end to end
+    wrapper.train()
+    with torch.no_grad():
+        out3, loss3, _, _ = wrapper(b)
+    assert torch.isfinite(out3["rgb_map"]).all() and torch.isfinite(loss3)

@@ -374,9 +374,19 @@ int th_small_frame_rule(uint8_t* mask, const int32_t* ray_hit, int R, int S, int
 }
 
 // ---------------------------------------------------------------------------
-// stream compaction of the mask -> ascending index list (deterministic)
+// stream compaction of the mask -> index list (deterministic)
 // ---------------------------------------------------------------------------
+// Order of the list (round 4): groups of CMP_G = 16 consecutive rays, DEPTH-MAJOR inside a group -- position e of the
+// permuted index space maps to ray g * 16 + (e mod 16), sample (e / 16) mod S, g = e / (16 S) -- so consecutive entries
+// are the same depth of neighbouring rays (a caller that hands rays over in 8 x 8 pixel tiles, like bench.py and
+// dist.shard_ray_indices, gets 8 x 2 pixel blocks) instead of consecutive depths of one ray.  A batch of 32 entries is then
+// a compact blob in space: its bilinear footprints in a reference view share texel rows (tools/k5_replay.py: 20 % of
+// the corner reads are distinct rows against 51 % ray-major; K5 loads each distinct row once), and its 7-NN sets share
+// token centres (K6's tile unions).  Every consumer of the list is order-agnostic (K4 / K5 / K6 work per sample, the raw
+// values are scattered back to their dense positions, compositing reads them through the mask).  S = 1 (point lists,
+// th_compact_mask) degenerates to the ascending order.
 #define CMP_ITEMS 4096   // per block (256 threads x 16)
+#define CMP_G 16
 
 // Optional small-frame rule (if_clight_renderer.py:551) evaluated on the fly: when rule.ray_hit != nullptr and the
 // number of hit rays info[0] is <= thr, the effective mask of sample i is "ray i / S was hit" (every sample of a hit
@@ -386,23 +396,34 @@ struct CmpRule {
     const int32_t* ray_hit;
     int32_t* info;
     int S, thr;
+    int R;          // rays (points when S == 1)
 };
 __device__ __forceinline__ bool cmp_rule_on(const CmpRule& r) { return r.ray_hit != nullptr && r.info[0] <= r.thr; }
+// a thread's 16 consecutive positions: ray group g, depth s -> dense indices (g * 16 + k) * S + s, k = 0 .. 15
+__device__ __forceinline__ void cmp_thread_span(const CmpRule& r, long long e0, long long& ray0, int& s) {
+    const long long gs = (long long)CMP_G * r.S;
+    const long long g = e0 / gs;
+    s = (int)((e0 - g * gs) >> 4);
+    ray0 = g * CMP_G;
+}
 
 __global__ __launch_bounds__(256) void cmp_count_kernel(const uint8_t* __restrict__ mask, long long P,
                                                         int* __restrict__ bcount, CmpRule rule) {
     __shared__ int ws[4];
-    long long base = (long long)blockIdx.x * CMP_ITEMS + threadIdx.x * 16;
+    long long e0 = (long long)blockIdx.x * CMP_ITEMS + threadIdx.x * 16;
+    long long ray0;
+    int sd;
+    cmp_thread_span(rule, e0, ray0, sd);
     int c = 0;
     if (cmp_rule_on(rule)) {
         for (int k = 0; k < 16; ++k)
-            if (base + k < P) c += rule.ray_hit[(int)((base + k) / rule.S)] != 0;
-    } else if (base + 16 <= P) {
-        uint4 v = *reinterpret_cast<const uint4*>(mask + base);
+            if (ray0 + k < rule.R) c += rule.ray_hit[ray0 + k] != 0;
+    } else if (rule.S == 1 && ray0 + 16 <= rule.R) {
+        uint4 v = *reinterpret_cast<const uint4*>(mask + ray0);
         c = __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) +
             __popc(v.w & 0x01010101u);
     } else {
-        for (int k = 0; k < 16; ++k) if (base + k < P) c += mask[base + k] != 0;
+        for (int k = 0; k < 16; ++k) if (ray0 + k < rule.R) c += mask[(ray0 + k) * rule.S + sd] != 0;
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = c;
@@ -438,19 +459,23 @@ __global__ __launch_bounds__(256) void cmp_write_kernel(uint8_t* __restrict__ ma
                                                         const int* __restrict__ boff, int32_t* __restrict__ idx,
                                                         CmpRule rule) {
     __shared__ int ws[4];
-    long long base = (long long)blockIdx.x * CMP_ITEMS + threadIdx.x * 16;
+    long long e0 = (long long)blockIdx.x * CMP_ITEMS + threadIdx.x * 16;
+    long long ray0;
+    int sd;
+    cmp_thread_span(rule, e0, ray0, sd);
     uint8_t m[16];
     int c = 0;
     if (cmp_rule_on(rule)) {
         if (blockIdx.x == 0 && threadIdx.x == 0) rule.info[1] = 1;
         for (int k = 0; k < 16; ++k) {
-            m[k] = (base + k < P && rule.ray_hit[(int)((base + k) / rule.S)] != 0) ? 1 : 0;
-            if (base + k < P) mask[base + k] = m[k];
+            const bool in = ray0 + k < rule.R;
+            m[k] = (in && rule.ray_hit[ray0 + k] != 0) ? 1 : 0;
+            if (in) mask[(ray0 + k) * rule.S + sd] = m[k];
             c += m[k] != 0;
         }
     } else
     for (int k = 0; k < 16; ++k) {
-        m[k] = (base + k < P) ? mask[base + k] : 0;
+        m[k] = (ray0 + k < rule.R) ? mask[(ray0 + k) * rule.S + sd] : 0;
         c += m[k] != 0;
     }
     int x = c;
@@ -464,15 +489,19 @@ __global__ __launch_bounds__(256) void cmp_write_kernel(uint8_t* __restrict__ ma
     for (int w = 0; w < (threadIdx.x >> 6); ++w) woff += ws[w];
     int pos = boff[blockIdx.x] + woff + x - c;
     for (int k = 0; k < 16; ++k)
-        if (m[k]) idx[pos++] = (int32_t)(base + k);
+        if (m[k]) idx[pos++] = (int32_t)((ray0 + k) * rule.S + sd);
 }
 
-size_t th_compact_ws(long long P) { return th_align((size_t)(th_cdiv(P, CMP_ITEMS) + 1) * sizeof(int)); }
+// blocks over the permuted index space: ceil(R / 16) ray groups x 16 S positions
+static long long cmp_space(long long R, int S) { return (R + CMP_G - 1) / CMP_G * CMP_G * S; }
+// (P + 16 S covers the padded last ray group of any (R, S) factorisation of P with S <= 1024)
+size_t th_compact_ws(long long P) { return th_align((size_t)(th_cdiv(P + 16 * 1024, CMP_ITEMS) + 2) * sizeof(int)); }
 
 static int compact_launch(uint8_t* mask, long long P, int32_t* idx_out, int32_t* dev_count, void* ws, size_t ws_bytes,
                           const CmpRule& rule, hipStream_t s) {
     TH_REQUIRE(P < (1LL << 31), "too many points for int32 indices");
-    int nb = th_cdiv(P, CMP_ITEMS);
+    TH_REQUIRE(rule.S >= 1 && rule.S <= 1024 && (long long)rule.R * rule.S == P, "compaction: P must be R x S, S <= 1024");
+    int nb = th_cdiv(cmp_space(rule.R, rule.S), CMP_ITEMS);
     TH_REQUIRE(ws_bytes >= th_compact_ws(P), "workspace too small");
     int* bcount = (int*)ws;
     hipLaunchKernelGGL(cmp_count_kernel, dim3(nb), dim3(256), 0, s, mask, P, bcount, rule);
@@ -484,7 +513,7 @@ static int compact_launch(uint8_t* mask, long long P, int32_t* idx_out, int32_t*
 
 int th_compact_mask(const uint8_t* mask, long long P, int32_t* idx_out, int32_t* dev_count, void* ws,
                     size_t ws_bytes, hipStream_t s) {
-    return compact_launch(const_cast<uint8_t*>(mask), P, idx_out, dev_count, ws, ws_bytes, CmpRule{nullptr, nullptr, 1, 0}, s);
+    return compact_launch(const_cast<uint8_t*>(mask), P, idx_out, dev_count, ws, ws_bytes, CmpRule{nullptr, nullptr, 1, 0, (int)P}, s);
 }
 
 // hit-ray count -> info[0]; then the compaction with the small-frame rule applied on the fly (info[1] = mode)
@@ -492,5 +521,5 @@ int th_compact_mask_rule(uint8_t* mask, long long P, const int32_t* ray_hit, int
                          int32_t* idx_out, int32_t* dev_count, void* ws, size_t ws_bytes, hipStream_t s) {
     // dev_info[0..1] must be zero on entry
     hipLaunchKernelGGL(count_hits_kernel, dim3(R >= 65536 ? 256 : th_cdiv(R, 256)), dim3(256), 0, s, ray_hit, R, dev_info);
-    return compact_launch(mask, P, idx_out, dev_count, ws, ws_bytes, CmpRule{ray_hit, dev_info, S, thr}, s);
+    return compact_launch(mask, P, idx_out, dev_count, ws, ws_bytes, CmpRule{ray_hit, dev_info, S, thr, R}, s);
 }

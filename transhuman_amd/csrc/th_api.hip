@@ -552,6 +552,14 @@ int th_pixel_gather(th_ctx* c, const float* map, int V, int C, int H, int W, con
                                (hipStream_t)stream);
 }
 
+int th_pixel_gather_split(th_ctx* c, const float* map_split, int V, int H, int W, const float* pts, const int32_t* sel, int P,
+                          const float* cams, const float* scale, void* out_rows, int ldo, th_stream stream) {
+    TH_REQUIRE(c && map_split && pts && cams && scale && out_rows, "null argument");
+    TH_REQUIRE(ldo == 272, "split rows of the compact map are 272 wide (256 latents | r g b 0 | zeros)");
+    return th_pixgather_launch(map_split, V, TH_MAP_SPLIT, H, W, pts, nullptr, sel, P, cams, scale, (float*)out_rows, ldo,
+                               TH_ROWS_SPLIT, (hipStream_t)stream, nullptr);
+}
+
 int th_composite(th_ctx* c, const float* raw, const float* z, const th_points* rays, int white, float* rgb,
                  float* acc, float* depth, float* wout, th_stream stream) {
     TH_REQUIRE(c && raw && rays && rgb && acc && depth, "null argument");

@@ -112,6 +112,8 @@ SYMBOLS = {
                                   C.c_void_p]),
     "th_pixel_gather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "th_pixel_gather_split": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "th_network_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "th_network_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                      C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -762,6 +764,21 @@ def pixel_gather(map_nhwc, pts_world, cams, scale_xy, sel=None, row_floats=None)
     _check(lib.th_pixel_gather(ctx(p.device), _p(map_nhwc), V, Cc, H, W, _p(p), _p(sel), P, _p(cams), _p(scale_xy),
                                _p(out), ldo, _stream()))
     return out
+
+
+def pixel_gather_split(split_map, pts_world, cams, scale_xy, sel=None):
+    """th_pixel_gather_split: the split-row form of the pixel-aligned gather (what the frame-level entry points run) ->
+    (hi, lo) fp16 tensors [P, V, 272] (x = hi + lo), decoded from the [8 hi | 8 lo] groups of the rows."""
+    lib = load_library()
+    assert isinstance(split_map, SplitMap)
+    V, H, W = split_map.V, split_map.H, split_map.W
+    p = _f32(pts_world).reshape(-1, 3)
+    P = p.shape[0] if sel is None else sel.numel()
+    out = torch.zeros((P, V, 272 * 2), dtype=torch.float16, device=p.device)
+    _check(lib.th_pixel_gather_split(ctx(p.device), _p(split_map), V, H, W, _p(p), _p(sel), P, _p(cams), _p(scale_xy),
+                                     _p(out), 272, _stream()))
+    g = out.view(P, V, 34, 2, 8)
+    return g[:, :, :, 0].reshape(P, V, 272), g[:, :, :, 1].reshape(P, V, 272)
 
 
 def network_forward(net, pixel_feat, viewdir, pts_smpl, centres, rot, tokens, mask=None):
