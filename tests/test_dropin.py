@@ -200,7 +200,9 @@ def test_trainer_wrapper_validation_step(reference_env, gpu):
         out, loss, stats, _ = wrapper(b)
         out2, loss2, _, _ = wrapper(b)
     assert out["rgb_map"].shape == (1, R, 3) and torch.isfinite(out["rgb_map"]).all() and torch.isfinite(loss)
-    assert torch.equal(out["rgb_map"], out2["rgb_map"]) and float(loss) == float(loss2)       # eval mode: no state changes
+    # eval mode: no state changes between two calls (the stem runs through torch's stock convolutions here, and MIOpen is not
+    # bit-reproducible from call to call: compare to 1e-6, not torch.equal)
+    assert float((out["rgb_map"] - out2["rgb_map"]).abs().max()) < 1e-6 and abs(float(loss) - float(loss2)) < 1e-6
     assert float(out["acc_map"].max()) > 0.0
     # the same call with the network in train() (run.py:29's state): batch statistics in the stem, HIP kernels end to end
     wrapper.train()

@@ -562,8 +562,10 @@ def test_generated_rays_render(hip, gpu, net):
     dense = r.render_fast(bd, frame=frame, small_frame_rays=-1)
     m = dense_rays["mask_at_box"]
     assert torch.equal(m, rays["mask_at_box"]) and 0 < int(m.sum()) < m.numel()
+    # (equal to fp32 rounding, not bit for bit: the sample list groups 16 CONSECUTIVE rays, so a ray has other tile mates in the
+    # dense list than in the masked one and the token blend on the matrix pipe sums its seven terms in another order, DESIGN 5 iv)
     for k in ("rgb_map", "acc_map", "depth_map"):
-        assert torch.equal(dense[k][0][m], sparse[k][0])
+        assert float((dense[k][0][m] - sparse[k][0]).abs().max()) < 4e-6
         assert float(dense[k][0][~m].abs().max()) == 0.0
 
 

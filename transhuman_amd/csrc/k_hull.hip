@@ -277,24 +277,33 @@ __global__ __launch_bounds__(256) void hull_mask_kernel(ThPointSrc ps, long long
         int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.dim[1] - 1);
         int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.dim[2] - 1);
         // a cell is skipped when the sample is farther than the threshold (+ a rounding margin: never a false skip)
-        // from the bounding box of its vertices; the per-vertex predicate below is unchanged
+        // from the bounding box of its vertices; the per-vertex predicate is the reference's, sqrt(d2) < thresh
+        // (:440-442), evaluated exactly: sqrt is monotone, so d2 below / above a band of +-4e-6 relative around
+        // thresh^2 decides without it (fp32 sqrt is correctly rounded: 6e-8) and only the band takes the square root.
         const float rej = thresh * 1.001f + 1e-6f, rej2 = rej * rej;
+        const float t2 = thresh * thresh, t2lo = t2 * (1.0f - 4e-6f), t2hi = t2 * (1.0f + 4e-6f);
+        auto cell = [&](int c) {
+            const float* bb = bbox + 6 * c;
+            float ex = fmaxf(fmaxf(bb[0] - px, px - bb[3]), 0.f), ey = fmaxf(fmaxf(bb[1] - py, py - bb[4]), 0.f),
+                  ez = fmaxf(fmaxf(bb[2] - pz, pz - bb[5]), 0.f);
+            if (!(ex * ex + ey * ey + ez * ez <= rej2)) return;     // (also skips empty cells: inverted box)
+            for (int v = starts[c], e = starts[c + 1]; v < e; ++v) {
+                float dx = px - sorted[3 * v], dy = py - sorted[3 * v + 1], dz = pz - sorted[3 * v + 2];
+                float d2 = dx * dx + dy * dy;
+                d2 = d2 + dz * dz;
+                if (d2 < t2hi && (d2 < t2lo || __fsqrt_rn(d2) < thresh)) { hit = true; break; }
+            }
+        };
+        // the sample's own cell first: a sample inside the hull (2 of 3 samples that get this far) usually finds its
+        // vertex there and leaves after ~40 tests instead of walking up to 13 neighbour cells first
+        const bool own = cx >= 0 && cx < g.dim[0] && cy >= 0 && cy < g.dim[1] && cz >= 0 && cz < g.dim[2];
+        const int c0 = own ? (cz * g.dim[1] + cy) * g.dim[0] + cx : -1;
+        if (own) cell(c0);
         for (int zz = z0; zz <= z1 && !hit; ++zz)
             for (int yy = y0; yy <= y1 && !hit; ++yy) {
                 int rowbase = (zz * g.dim[1] + yy) * g.dim[0];
-                for (int xx = x0; xx <= x1 && !hit; ++xx) {
-                    const int c = rowbase + xx;
-                    const float* bb = bbox + 6 * c;
-                    float ex = fmaxf(fmaxf(bb[0] - px, px - bb[3]), 0.f), ey = fmaxf(fmaxf(bb[1] - py, py - bb[4]), 0.f),
-                          ez = fmaxf(fmaxf(bb[2] - pz, pz - bb[5]), 0.f);
-                    if (!(ex * ex + ey * ey + ez * ez <= rej2)) continue;     // (also skips empty cells: inverted box)
-                    for (int v = starts[c], e = starts[c + 1]; v < e; ++v) {
-                        float dx = px - sorted[3 * v], dy = py - sorted[3 * v + 1], dz = pz - sorted[3 * v + 2];
-                        float d2 = dx * dx + dy * dy;
-                        d2 = d2 + dz * dz;
-                        if (__fsqrt_rn(d2) < thresh) { hit = true; break; }
-                    }
-                }
+                for (int xx = x0; xx <= x1 && !hit; ++xx)
+                    if (rowbase + xx != c0) cell(rowbase + xx);
             }
     }
     mask[i] = hit ? 1 : 0;
