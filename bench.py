@@ -82,7 +82,7 @@ def hbm_traffic():
         return None
 
 
-def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_step=None):
+def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_step=None, n_valid=0):
     """Dominant kernel = the per-point MLP.  `achieved` counts ALGORITHMIC fp32 FLOPs (the reference's
     layer shapes).  mode 1 (default): the fused kernel evaluates every fp32 MAC as three fp16 MFMA MACs
     (hi*hi + hi*lo + lo*hi, fp32 accumulate), so the pipe it is bound by is the fp16 MFMA pipe at one third
@@ -94,11 +94,14 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
         peak = MFMA_F32_PEAK
         kernel = "per-point MLP stage (gemm_f32_mfma_kernel x14 + glue kernels), rank 0"
     t = hbm_traffic() if mlp_mode == 1 else None
-    traffic = t["mlp_fused_bytes_per_launch"] if t else None
+    # the committed PMC pass measured launches of t["launch_samples"] samples: bytes per sample x this run's samples per launch
+    per_launch = (float(n_valid) / max(launches, 1.0) / t["launch_samples"]) if t else 0.0
+    traffic = t["mlp_fused_bytes_per_launch"] * per_launch if t else None
     return {"bound": "mfma", "kernel": kernel, "achieved": achieved / 1e12, "peak": peak / 1e12,
             "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-            "traffic_note": ("HBM bytes per 524288-sample launch, rocprofv3 PMC (" + t["source"] + "); algorithmic " +
-                             f"{t['mlp_fused_algorithmic_bytes_per_launch']:.3g} (" + t["algorithmic_note"] + ")") if t else
+            "traffic_note": (f"HBM bytes per launch ({n_valid / max(launches, 1.0):.0f} samples), rocprofv3 PMC (" + t["source"] +
+                             f", measured on a launch of {t['launch_samples']} samples); algorithmic " +
+                             f"{t['mlp_fused_algorithmic_bytes_per_launch'] * per_launch:.3g} (" + t["algorithmic_note"] + ")") if t else
                             "no committed PMC pass (profiles/hbm_traffic.json absent)",
             "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK,
             # the same ALGORITHMIC number against the raw dense fp16 MFMA peak (what a reader who does not accept the /3 sees)
@@ -106,11 +109,11 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
             # executed MFMA work (3 fp16 products per executed fp32 MAC) / time / raw fp16 peak: how busy the matrix pipe is
             "mfma_pipe_util": (3.0 * executed_step / max(stage_ms * 1e-3, 1e-12) / MFMA_F16_PEAK) if (executed_step and mlp_mode == 1) else None,
             "traffic_per_frame": ({"measured_K4_K5_K6_bytes": (t["mlp_fused_bytes_per_launch"] + t["pixgather_bytes_per_launch"] +
-                                                               t["dparf_bytes_per_launch"]) * launches,
+                                                               t["dparf_bytes_per_launch"]) * float(n_valid) / t["launch_samples"],
                                    "survey_8d_algorithmic_bytes": 1.22e9,
-                                   "note": "PMC bytes per full launch x launches of this frame (partial last launch counted as "
-                                           "full: upper bound) against SURVEY 8d's unique-footprint figure; the gap is the "
-                                           "K5 -> HBM -> K6 row round trip (rows written once, read twice)"} if t else None),
+                                   "note": "PMC bytes per sample x this frame's valid samples against SURVEY 8d's "
+                                           "unique-footprint figure; the gap is the K5 -> HBM -> K6 row round trip (rows "
+                                           "written once, read twice)"} if t else None),
             "algorithmic_flop_per_step": flops_step, "kernel_ms_per_step": stage_ms,
             "launches_per_step": launches,
             # what the matrix pipes really did (after the algebraic folds): executed FLOPs / time / peak
@@ -627,7 +630,7 @@ def main():
                 "map_crop": os.environ.get("TH_MAP_CROP") != "0",      # pixel map written inside the hull's texel box only
             },
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
-                                       mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos)),
+                                       mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos), n_valid=n_valid),
             "gather": gather_block(V, n_valid, prof["gather"][0] / max(args.steps, 1)),
             # what the range guard of the fp16 hi/lo split has switched on this device (every entry false = the fast paths
             # ran; a tripped MLP guard means per-layer fp32 launches, ~7x slower frames) + the last table read (fp16 bit

@@ -263,6 +263,12 @@ size_t th_bn_workspace_bytes(int N, int C, int HW);
 int th_bn_act(th_ctx* ctx, const float* x, const float* residual, int N, int C, int HW, const float* gamma,
               const float* beta, float eps, float momentum, float* running_mean, float* running_var, int relu,
               float* y, void* workspace, size_t workspace_bytes, th_stream stream);
+/* The same sites with the module in eval() mode (the reference's Trainer.val, lib/train/trainers/trainer.py:131-150, runs
+ * network.eval()): y = (x - running_mean) / sqrt(running_var + eps) * gamma + beta [+ residual] [relu]; ONE launch, no
+ * statistics pass, nothing updated. */
+int th_bn_act_eval(th_ctx* ctx, const float* x, const float* residual, int N, int C, int HW, const float* gamma,
+                   const float* beta, float eps, const float* running_mean, const float* running_var, int relu,
+                   float* y, th_stream stream);
 
 /* ---- K3: TransHE (ViT-tiny) ---------------------------------------------- */
 /* VisionTransformer.forward, vision_transformer.py:371-383.  x [V,N,dim]

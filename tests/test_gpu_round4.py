@@ -224,3 +224,26 @@ def test_split_row_gather_equals_fp32_gather(hip, gpu, net):
     assert bool(((rec[:, :, :260] - ref).abs() <= tol).all()), float((rec[:, :, :260] - ref).abs().max())
     assert float(rec[:, :, 259:].abs().max()) == 0.0                                            # the 0 of r g b 0 + the pad
     assert torch.equal(hi, hip.pixel_gather_split(frame.map, world, frame.cams, frame.scale)[0])
+
+
+def test_stem_in_eval_mode_runs_the_hip_kernels(hip, gpu):
+    """network.eval() (the reference's Trainer.val, trainer.py:131): BatchNorm normalises with its running statistics -- the
+    ResNet stem still runs K12 / K11 (th_bn_act_eval: one launch per site) and equals torch's stock modules; the running
+    statistics and batch counters do not move."""
+    net2 = make_net(12).to(gpu)
+    enc = net2.encoder
+    g = torch.Generator(device=gpu).manual_seed(3)
+    x = torch.rand(3, 3, 128, 96, device=gpu, generator=g)
+    enc.train()
+    with torch.no_grad():
+        enc.trunk(x)                                       # a training-mode pass: non-trivial running statistics
+        enc.eval()
+        assert enc._bn_sites_fusable()
+        before = [(b.running_mean.clone(), b.running_var.clone(), int(b.num_batches_tracked)) for b in enc._bn_sites()]
+        a = enc.trunk(x)
+        ref = enc.trunk(x, fused_bn=False)
+    assert len(a) == 3 and [t.shape for t in a] == [t.shape for t in ref]
+    for u, v in zip(a, ref):
+        assert torch.isfinite(u).all() and maxdiff(u, v) < 2e-5 * max(1.0, float(v.abs().max()))
+    for b, (m0, v0, n0) in zip(enc._bn_sites(), before):
+        assert torch.equal(b.running_mean, m0) and torch.equal(b.running_var, v0) and int(b.num_batches_tracked) == n0

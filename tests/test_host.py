@@ -201,7 +201,12 @@ def test_bench_reads_the_committed_hbm_traffic():
     import os
     import bench
     t = bench.hbm_traffic()
-    assert t is not None and t["mlp_fused_bytes_per_launch"] > 1e9 and t["launch_samples"] == 524288
+    assert t is not None and t["mlp_fused_bytes_per_launch"] > 1e9 and t["launch_samples"] >= 524288
     assert t["source"].startswith("profiles/") and os.path.exists(os.path.join(os.path.dirname(bench.__file__), t["source"]))
-    blk = bench.roofline_block(1, 5.0e14, 9.4e12, 17.9, 4.0)
-    assert blk["traffic"] == t["mlp_fused_bytes_per_launch"] and "mlp_fused_kernel<3,1>" in blk["kernel"]
+    # bytes per launch scale with the samples of a launch: one launch over n samples = n / launch_samples of the measured one
+    n = 2 * t["launch_samples"]
+    blk = bench.roofline_block(1, 5.0e14, 9.4e12, 17.9, 1.0, n_valid=n)
+    assert abs(blk["traffic"] - 2 * t["mlp_fused_bytes_per_launch"]) < 1.0 and "mlp_fused_kernel<3,1>" in blk["kernel"]
+    blk4 = bench.roofline_block(1, 5.0e14, 9.4e12, 17.9, 4.0, n_valid=n)
+    assert abs(blk4["traffic"] - 0.5 * t["mlp_fused_bytes_per_launch"]) < 1.0
+    assert blk["traffic_per_frame"]["measured_K4_K5_K6_bytes"] > 2 * t["mlp_fused_bytes_per_launch"]

@@ -26,7 +26,7 @@ def main():
     w = load(f"{d}/pmc_WRITE_SIZE_counter_collection.csv", "WRITE_SIZE")
     if not as_json:            # (the --json form prints the JSON object only: bench.py json.load()s the file)
         print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1")
-        print("# KB per launch = MAX over the launches of a kernel (the full 262144-sample chunks); hbm = 2*FETCH + WRITE")
+        print("# KB per launch = MAX over the launches of a kernel (one launch covers the frame's valid samples); hbm = 2*FETCH + WRITE")
         print(f"{'kernel':62s} {'launches':>8s} {'FETCH_KB':>12s} {'WRITE_KB':>12s} {'HBM_GB(2F+W)':>13s}")
     rows = []
     for k in f:
@@ -41,7 +41,14 @@ def main():
             m = [r for r in rows if sub in r[1]]
             return max(m)[0] * 1024 if m else None
         src = sys.argv[sys.argv.index("--json") + 1] if len(sys.argv) > sys.argv.index("--json") + 1 else d
+        # samples of the (one) launch per kernel and frame: the valid-sample count of the profiled frame, from the JSON
+        # line bench.py printed under the profiler (ABI 6: one launch of K4 / K5 / K6 covers the whole frame)
         ch, V = 524288, 3
+        try:
+            line = [l for l in open(f"{d}/pmc_FETCH_SIZE.log").read().splitlines() if l.startswith("{")][-1]
+            ch = int(json.loads(line)["config"]["valid_samples_rank0"])
+        except (OSError, IndexError, KeyError, ValueError):
+            pass
         print(json.dumps({"source": src, "launch_samples": ch,
                           "mlp_fused_bytes_per_launch": of("mlp_fused"), "pixgather_bytes_per_launch": of("pixgather_kernel<true>"),
                           "dparf_bytes_per_launch": of("dparf_kernel"),

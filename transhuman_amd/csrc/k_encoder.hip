@@ -278,7 +278,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        int relu, float* __restrict__ y) {
     const int c = blockIdx.x, ns = blockIdx.y, n = ns / splits, sp = ns - n * splits;
     __shared__ float ss[2];
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && part == nullptr) {
+        // eval mode (nn.BatchNorm2d.eval(): the reference's Trainer.val, trainer.py:131): the running statistics ARE the
+        // statistics, nothing is updated
+        const float g = gamma ? gamma[c] : 1.f;
+        ss[0] = (float)(1.0 / sqrt((double)run_var[c] + (double)eps)) * g;
+        ss[1] = run_mean[c];
+    } else if (threadIdx.x == 0) {
         double s = 0.0, q = 0.0;
         for (int k = 0; k < NS; ++k) { s += part[((long long)c * NS + k) * 2]; q += part[((long long)c * NS + k) * 2 + 1]; }
         const double mean = s / (double)count;
@@ -335,15 +341,16 @@ size_t th_bn_ws(int N, int C, int HW) {
 
 int th_bn_act_launch(const float* x, const float* res, int N, int C, int HW, const float* gamma, const float* beta,
                      float eps, float momentum, float* run_mean, float* run_var, int relu, float* y, void* ws,
-                     size_t ws_bytes, hipStream_t s) {
+                     size_t ws_bytes, hipStream_t s, int eval) {
     TH_REQUIRE(N > 0 && C > 0 && HW > 0, "empty tensor");
-    TH_REQUIRE(ws_bytes >= th_bn_ws(N, C, HW), "workspace too small");
+    TH_REQUIRE(eval || ws_bytes >= th_bn_ws(N, C, HW), "workspace too small");
+    TH_REQUIRE(!eval || (run_mean && run_var), "eval-mode BatchNorm needs the running statistics");
     TH_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0, "tensors must be 16-byte aligned");
     const int splits = (HW + BN_SPLIT_ELEMS - 1) / BN_SPLIT_ELEMS;
     const int NS = N * splits;
     TH_REQUIRE(NS <= 65535, "too many plane slices");
-    double* part = (double*)ws;
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(C, NS), dim3(256), 0, s, x, C, HW, splits, part, NS);
+    double* part = eval ? nullptr : (double*)ws;
+    if (!eval) hipLaunchKernelGGL(bn_stats_kernel, dim3(C, NS), dim3(256), 0, s, x, C, HW, splits, part, NS);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(C, NS), dim3(256), 0, s, x, res, C, HW, splits, part, NS,
                        (long long)N * HW, gamma, beta, eps, momentum, run_mean, run_var, relu, y);
     TH_LAUNCH_CHECK();

@@ -490,6 +490,13 @@ int th_paint_group_nhwc(th_ctx* c, const float* map_nhwc, int V, int H, int W, i
     return th_segmean_masked_launch(r, V, out_f, viz, nv, off, mem, nc, tokens, s);
 }
 
+int th_bn_act_eval(th_ctx* c, const float* x, const float* residual, int N, int C, int HW, const float* gamma, const float* beta,
+                   float eps, const float* running_mean, const float* running_var, int relu, float* y, th_stream stream) {
+    TH_REQUIRE(c && x && y && running_mean && running_var, "null argument");
+    return th_bn_act_launch(x, residual, N, C, HW, gamma, beta, eps, 0.f, const_cast<float*>(running_mean),
+                            const_cast<float*>(running_var), relu, y, nullptr, 0, (hipStream_t)stream, 1);
+}
+
 size_t th_vit_workspace_bytes(int V, int N, int dim, int heads) { return th_vit_ws(V, N, dim, heads); }
 
 size_t th_conv_pack_bytes(int cout, int cin, int ks) { return th_conv_pack_size(cout, cin, ks); }

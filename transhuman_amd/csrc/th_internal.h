@@ -459,7 +459,7 @@ int th_maxpool3x3s2_launch(const float* x, int planes, int H, int W, float* y, h
 size_t th_bn_ws(int N, int C, int HW);
 int th_bn_act_launch(const float* x, const float* res, int N, int C, int HW, const float* gamma, const float* beta,
                      float eps, float momentum, float* run_mean, float* run_var, int relu, float* y, void* ws,
-                     size_t ws_bytes, hipStream_t s);
+                     size_t ws_bytes, hipStream_t s, int eval = 0);
 int th_fold_color_launch(const float* W /*[N,384]*/, const float* b, const float* wc /*[128,3]*/, const float* bc,
                          int N, float* Wo /*[N,260]*/, float* bo /*[N]*/, hipStream_t s);
 int th_segmean_masked_launch(const float* rows, int V, int width, const uint8_t* viz, int nv, const int32_t* off,

@@ -156,6 +156,8 @@ SYMBOLS = {
     "th_bn_act": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                             C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t,
                             C.c_void_p]),
+    "th_bn_act_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "th_render_prepass_cancel": (C.c_int, [C.c_void_p]),
     "th_render_prepass_drop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_sigma_grid_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int]),
@@ -195,15 +197,33 @@ def _check(rc):
         raise HipError(_lib.th_last_error().decode())
 
 
+_ctx_by_device = {}      # torch.device with an explicit index -> handle (the per-call path: no torch.cuda queries)
+_have_gpu = None
+
+
+def _gpu_visible():
+    """torch.cuda.is_available(), asked once (it reads environment variables on every call: ~70 calls per frame showed up
+    in the host profile, tools/host_cost.py)"""
+    global _have_gpu
+    if _have_gpu is None:
+        _have_gpu = bool(torch.cuda.is_available())
+    return _have_gpu
+
+
 def ctx(device=None):
+    h = _ctx_by_device.get(device) if device is not None else None
+    if h is not None:
+        return h
     lib = load_library()
-    if not torch.cuda.is_available():
+    if not _gpu_visible():
         raise HipError("no HIP device visible: the TransHuman hot path needs an MI355X (gfx950)")
     dev = torch.cuda.current_device() if device is None else torch.device(device).index or 0
     if dev not in _ctx:
         h = C.c_void_p()
         _check(lib.th_ctx_create(dev, C.byref(h)))
         _ctx[dev] = h
+    if isinstance(device, torch.device) and device.index is not None:
+        _ctx_by_device[device] = _ctx[dev]
     return _ctx[dev]
 
 
@@ -290,7 +310,7 @@ def _sync_weights(mod, kind):
     parameter list and the addresses of its first / last tensor are read (25 us instead of 0.9 ms for the
     310-tensor Network: the walk used to leave the GPU idle in front of the per-sample stage)."""
     import weakref
-    if not torch.cuda.is_available():
+    if not _gpu_visible():
         raise HipError("no HIP device visible: the TransHuman hot path needs an MI355X (gfx950); there is no CPU fallback")
     ent = _param_lists.get(id(mod))
     if ent is None or ent[0]() is not mod or ent[2] >= 256:
@@ -685,10 +705,19 @@ def maxpool3x3s2(x):
 
 def bn_act(x, bn, residual=None, relu=True):
     """th_bn_act: train-mode nn.BatchNorm2d `bn` on x [N,C,H,W] (+ residual) (+ ReLU) in two launches; updates
-    bn.running_mean / running_var like the module (num_batches_tracked is left to the caller)."""
+    bn.running_mean / running_var like the module (num_batches_tracked is left to the caller).  A module in eval() mode
+    normalises with its running statistics in one launch (th_bn_act_eval)."""
     lib = load_library()
-    assert bn.training and x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
+    assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
     N, Cc, H, W = x.shape
+    r = None if residual is None else residual.contiguous()
+    if not bn.training:             # eval(): running statistics, one launch (th_bn_act_eval)
+        assert bn.track_running_stats and bn.running_mean is not None, "eval-mode BatchNorm without running statistics"
+        y = torch.empty_like(x)
+        _check(lib.th_bn_act_eval(ctx(x.device), _p(x), None if r is None else _p(r), N, Cc, H * W,
+                                  None if bn.weight is None else _p(bn.weight), None if bn.bias is None else _p(bn.bias),
+                                  float(bn.eps), _p(bn.running_mean), _p(bn.running_var), int(relu), _p(y), _stream()))
+        return y
     ws = _ws(lib.th_bn_workspace_bytes(N, Cc, H * W), x.device)
     y = torch.empty_like(x)
     track = bn.track_running_stats and bn.running_mean is not None

@@ -123,7 +123,10 @@ class SpatialEncoder(nn.Module):
         return sites
 
     def _bn_sites_fusable(self):
-        return all(isinstance(b, nn.BatchNorm2d) and b.training and b.momentum is not None for b in self._bn_sites())
+        """train(): batch statistics (momentum given); eval(): running statistics -- both have a HIP form"""
+        return all(isinstance(b, nn.BatchNorm2d) and ((b.training and b.momentum is not None) or
+                                                      (not b.training and b.track_running_stats and b.running_mean is not None))
+                   for b in self._bn_sites())
 
     def _trunk_fused_bn(self, x):
         from .. import hip
@@ -145,7 +148,7 @@ class SpatialEncoder(nn.Module):
                 x = hip.bn_act(conv(blk.conv2, y), blk.bn2, residual=idt, relu=True)
             lat.append(x)
         counters = [b.num_batches_tracked for b in self._bn_sites()
-                    if b.track_running_stats and b.num_batches_tracked is not None]
+                    if b.training and b.track_running_stats and b.num_batches_tracked is not None]
         if counters:
             torch._foreach_add_(counters, 1)            # one launch for the ten counters
         return lat
