@@ -161,9 +161,9 @@ def test_trainer_wrapper_validation_step(reference_env, gpu):
     ``if_clight_renderer.Renderer(self.net)`` directly (module import at :4, not through the YAML path), :45 calls
     ``self.renderer.render(batch)`` and :83-86 forms the image loss on ``batch['mask_at_box']``; Trainer.val
     (trainer.py:131-150) runs that wrapper with ``network.eval()`` under ``torch.no_grad()`` -- evaluation during
-    training.  With the renderer module swapped for this repository's the validation step runs (eval-mode BatchNorm:
-    the stem goes through the stock modules' running statistics, everything behind it through the HIP kernels) and
-    the train step is refused with a message that says why (Renderer.render carries no autograd)."""
+    training.  With the renderer module swapped for this repository's both run: the train step through the differentiable
+    form of Renderer.render (transhuman_amd.networks.autograd_path: loss.backward() reaches every trained parameter), the
+    validation step on the HIP kernels (eval-mode BatchNorm included: th_bn_act_eval)."""
     from transhuman_amd import synth
     from util import make_sd
     cfg = reference_env
@@ -190,10 +190,17 @@ def test_trainer_wrapper_validation_step(reference_env, gpu):
     bc["rgb"] = torch.rand(1, R, 3)
     bc["mask_at_box"] = torch.ones(1, R, dtype=torch.bool)
     b = synth.batch_to(bc, gpu)
-    # Trainer.train (trainer.py:79-86): gradients on -> refused, loudly
+    # Trainer.train (trainer.py:79-86): forward, loss.backward(), gradient clipping, optimizer.step()
     wrapper.train()
-    with pytest.raises(RuntimeError, match="inference-only"):
-        wrapper(b)
+    opt = torch.optim.Adam(wrapper.parameters(), lr=1e-4)
+    out_t, loss_t, _, _ = wrapper(b)
+    opt.zero_grad()
+    loss_t.mean().backward()
+    torch.nn.utils.clip_grad_value_(wrapper.parameters(), 40)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in network.named_parameters()
+               if n.startswith(("fc_", "alpha_", "rgb_", "view_fc", "feature_fc", "spatial_key_value", "encoder.model.conv1",
+                                "encoder.model.layer1", "encoder.model.layer2", "ViT.blocks", "ViT.norm")))
+    opt.step()
     # Trainer.val (trainer.py:131-150)
     wrapper.eval()
     with torch.no_grad():

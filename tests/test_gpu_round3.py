@@ -126,17 +126,22 @@ def test_stale_range_snapshot_is_reported(hip, gpu, net):
     assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")   # ... without switching any path
 
 
-def test_training_entry_refuses_autograd(hip, gpu, net):
-    """Renderer.render is the reference trainer's entry (if_nerf_clight.py:45): with gradients enabled it raises
-    instead of handing back graph-less tensors; under no_grad it renders."""
+def test_training_entry_serves_autograd(hip, gpu, net):
+    """Renderer.render is the reference trainer's entry (if_nerf_clight.py:45): with gradients enabled it runs the
+    differentiable form (transhuman_amd.networks.autograd_path; round 3 refused the call) and the result equals the HIP
+    path's under no_grad within the parity bar."""
     r = _renderer(net, 300, samples=32)
     b = synth.batch_to(synth.make_batch(16, 16, 3, seed=0), gpu)
     assert any(p.requires_grad for p in net.parameters())
-    with pytest.raises(RuntimeError, match="inference-only"):
-        r.render(b)
+    out = r.render(b)
+    assert out["rgb_map"].requires_grad and out["rgb_map"].shape == (1, 256, 3)
+    out["rgb_map"].sum().backward()
+    assert net.fc_0.weight.grad is not None and torch.isfinite(net.fc_0.weight.grad).all()
+    net.zero_grad(set_to_none=True)
     with torch.no_grad():
-        out = r.render(b)
-    assert out["rgb_map"].shape == (1, 256, 3) and torch.isfinite(out["rgb_map"]).all()
+        fast = r.render(b)
+    assert not fast["rgb_map"].requires_grad and torch.isfinite(fast["rgb_map"]).all()
+    assert maxdiff(fast["rgb_map"], out["rgb_map"].detach()) < 1e-4 and maxdiff(fast["acc_map"], out["acc_map"].detach()) < 1e-4
 
 
 def _texel_use(b, frame, pts_world, H, W):

@@ -162,16 +162,19 @@ def test_evaluator_psnr_images_and_files(tmp_path):
         cfg.white_bkgd = old
 
 
-def test_training_entry_is_refused_before_any_device_work():
-    """Renderer.render with gradients enabled (the reference trainer's call, if_nerf_clight.py:45) raises an explicit
-    inference-only error -- on any host, before a HIP call is made."""
+def test_training_entry_needs_a_device_too():
+    """Renderer.render with gradients enabled (the reference trainer's call, if_nerf_clight.py:45) is served by the
+    differentiable torch form of the path -- which is plain torch and WOULD run on a CPU batch; the method refuses that
+    loudly like every inference entry does (no CPU path behind the boundary; tests/test_train_path.py drives the module
+    directly for its CPU pin against the reference)."""
     import pytest
     from transhuman_amd.config import get_cfg
     from transhuman_amd.networks.renderer.if_clight_renderer import Renderer
     from util import can64
     get_cfg().num_class = 300
     r = Renderer(make_net(2), vertex_can=can64().numpy(), pc2voxel_ind=synth_assign(300))
-    with pytest.raises(RuntimeError, match="inference-only"):
+    from transhuman_amd import hip
+    with pytest.raises(hip.HipError, match="MI355X"):
         r.render(synth.make_batch(8, 8, 1, seed=0))
 
 

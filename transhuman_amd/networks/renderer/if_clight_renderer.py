@@ -276,7 +276,8 @@ class Renderer:
         if float(getattr(cfg, "perturb", 0.0)) > 0.0 and self.net.training:
             raise NotImplementedError("cfg.perturb > 0 with the network in train() mode asks for stratified depth jitter "
                                       "(if_clight_renderer.py:276-283): training-time sampling is outside this inference "
-                                      "path -- set cfg.perturb = 0 like run.py:22,68,123 do")
+                                      "path (Renderer.render serves it through its autograd form) -- set cfg.perturb = 0 "
+                                      "like run.py:22,68,123 do")
         if float(getattr(cfg, "raw_noise_std", 0.0)) > 0.0:
             raise NotImplementedError("cfg.raw_noise_std > 0 (density noise, nerf_net_utils.py:39-46) is a training option")
 
@@ -439,15 +440,25 @@ class Renderer:
 
     def render(self, batch, is_train=True):
         """:486-498 -- no hull mask, every sample shaded, RGB everywhere.
-        Forward only: the HIP kernels carry no autograd.  The reference's trainer calls this entry with gradients
-        enabled and back-propagates through it (lib/train/trainers/if_nerf_clight.py:45, trainer.py:79-86); that use
-        is refused here instead of returning graph-less tensors whose loss.backward() dies with a generic message."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters()):
-            raise RuntimeError("inference-only: transhuman_amd's Renderer.render runs hand-written HIP kernels without "
-                               "autograd -- wrap the call in torch.no_grad() (evaluation), or train with the reference "
-                               "renderer and load the checkpoint here (state_dict keys are identical)")
+        Inference (``torch.no_grad()``, the reference's ``Trainer.val``): the HIP path, forward only.
+        Training (the reference's trainer calls this entry with gradients enabled and back-propagates through it,
+        lib/train/trainers/if_nerf_clight.py:45, trainer.py:79-86; ``cfg.perturb`` / ``cfg.raw_noise_std`` are its
+        randomisations): the HIP kernels carry no autograd, so such a call is served by
+        ``transhuman_amd.networks.autograd_path`` -- the same forward composed from differentiable torch operators on
+        the batch's device.  It is a separate entry for training, not a fallback of the rendering hot path: without a GPU
+        this method raises like every other."""
         cfg = get_cfg()
-        self._check_sampling_options(cfg)
+        wants_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.net.parameters())
+        randomised = (float(getattr(cfg, "perturb", 0.0)) > 0.0 and self.net.training) or \
+            float(getattr(cfg, "raw_noise_std", 0.0)) > 0.0
+        if wants_grad or randomised:
+            if not batch["ray_o"].is_cuda:
+                raise hip.HipError("Renderer.render needs the batch on an MI355X (there is no CPU path)")
+            from transhuman_amd.networks import autograd_path
+            out = autograd_path.render(self, batch)
+            self.last_stats = dict(hit_rays=int(batch["ray_o"].shape[1]), valid_samples=int(batch["ray_o"].shape[1]) * int(cfg.N_samples),
+                                   unmasked=1)
+            return out
         frame = self.prepare_frame(batch, hull_thresh=-1.0)
         pts = hip.Points(batch["ray_o"][0], batch["ray_d"][0], batch["near"][0], batch["far"][0],
                          n_samples=cfg.N_samples)
