@@ -365,6 +365,8 @@ def run_extras(dev, net, args, H, W, V):
     centre = 0.5 * (bounds[0] + bounds[1]).astype(np.float64)
     w2c = gen_path_virt(synthetic_rig(centre=tuple(centre.tolist())), render_views=60)
 
+    px = shard_ray_indices(H, W, 1, 0, tile=8, tile_major=True).to(dev)      # 8 x 8 pixel tiles (the sample list's unit)
+
     def frames():
         i = 0
         while True:
@@ -373,7 +375,7 @@ def run_extras(dev, net, args, H, W, V):
                                 compact=False)
             sh = dict(b)
             for k in ("ray_o", "ray_d", "near", "far"):
-                sh[k] = rays[k][None]
+                sh[k] = rays[k][px][None]
             yield sh
             i += 1
     seq = r.render_sequence(frames())
@@ -430,8 +432,8 @@ def run_extras(dev, net, args, H, W, V):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="real", choices=["real", "dense", "orbit", "mesh"],
                     help="real/dense: the headline frame (SURVEY 8d C2); orbit: C3, a new target camera every step, rays "
                          "made on device (th_gen_rays); mesh: C5, sigma on a --grid^3 voxel grid (voxels/s)")
@@ -739,7 +741,8 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
         # they come out as background exactly like the pixels the reference never renders): no per-frame compaction of
         # the ray list, hence no host round trip and no index arithmetic per frame; pixel tiles are dealt to the ranks
         # like in the headline workload, layout exchanged once
-        my_px = shard_ray_indices(H, W, world, rank, tile=8, tile_major=True).to(dev) if world > 1 else None
+        # (also on one GPU: 8 x 8 pixel tiles make 16 consecutive rays an 8 x 2 block -- the unit of the sample list)
+        my_px = shard_ray_indices(H, W, world, rank, tile=8, tile_major=True).to(dev)
         gatherer = ImageGatherer(my_px, H * W, world) if dist_on and world > 1 else None
 
         def frames():
@@ -750,7 +753,7 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
                 rays = hip.gen_rays(*camera(i), bounds, H, W, device=dev, compact=False)
                 sh = dict(batch)
                 for k in ("ray_o", "ray_d", "near", "far"):
-                    sh[k] = (rays[k] if my_px is None else rays[k][my_px])[None]
+                    sh[k] = rays[k][my_px][None]
                 yield sh
                 i += 1
 
@@ -761,6 +764,10 @@ def run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_c
             img = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
             if gatherer is not None:
                 img = gatherer(img)
+            else:
+                full = torch.empty((H * W, 5), dtype=img.dtype, device=dev)
+                full[my_px] = img
+                img = full
             return img, H * W
         units, unit_name = H * W, "rays/sec (512x512 orbit, 64 samples/ray, rays generated on device)"
     else:
