@@ -537,6 +537,7 @@ def main():
     # mode.  The all-reduce has its own communicator and stream and is checked AFTER the frame's work is queued, so the
     # host never waits for the shading before it can queue the next frame.
     whole_frame_hits = DeferredSum(dev) if dist_on else None
+    dist_wait = [0.0]
 
     def step():
         # per frame: ray-only stage (hull mask, compaction) -> [per-frame constants] -> shading + compositing.
@@ -549,7 +550,10 @@ def main():
         local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
         if dist_on:
             img = gatherer(local)
-            if whole_frame_hits.result() <= 2400:
+            tw = time.perf_counter()
+            total_hits = whole_frame_hits.result()            # (host wait for the 8-byte all-reduce: not the host's own cost)
+            dist_wait[0] += time.perf_counter() - tw
+            if total_hits <= 2400:
                 fr = renderer.last_frame if seq is not None else None
                 out = renderer.render_fast(shard, frame=fr, small_frame_rays=1 << 30)
                 local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
@@ -573,7 +577,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     hip.host_wait_read(dev)
-    dist_wait = 0.0
+    dist_wait[0] = 0.0
     t0 = time.perf_counter()
     for i in range(args.steps):
         img, stats = step()
@@ -581,7 +585,8 @@ def main():
             with torch.cuda.stream(probe_stream):
                 hip.clock_probe(clk[i])
     host_dt = time.perf_counter() - t0             # the host is done queueing here (the device may still be working)
-    host_wait_ms = hip.host_wait_read(dev)         # ... of which it spent this long blocked on counts / guard snapshots
+    # ... of which it spent this long blocked on counts / guard snapshots / the whole-frame hit count of a multi-rank job
+    host_wait_ms = hip.host_wait_read(dev) + dist_wait[0] * 1e3
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()

@@ -29,7 +29,8 @@ PY
 }
 for n in ${RANKS:-1 2 4 8}; do
   avail=$(python -c "import torch; print(torch.cuda.device_count())" 2>/dev/null || echo 0)
-  if [ "$avail" -lt "$n" ]; then echo "n=$n: only $avail GPU(s) visible, skipped" | tee -a "$out/scale_summary.txt"; continue; fi
+  # SCALE_FORCE=1: rehearsal on a one-GPU box (with TH_DIST_BACKEND=gloo TH_ONE_GPU=1 every rank uses cuda:0)
+  if [ "$avail" -lt "$n" ] && [ "${SCALE_FORCE:-0}" != "1" ]; then echo "n=$n: only $avail GPU(s) visible, skipped" | tee -a "$out/scale_summary.txt"; continue; fi
   if [ "$n" = 1 ]; then
     python bench.py --gpus 1 --steps $steps --warmup $warmup --no-extras > "$out/scale_n1.json" 2> "$out/scale_n1.err"
     summarise "$out/scale_n1.json" "n=1" "$out/scale_n1.json"
