@@ -174,6 +174,12 @@ def test_stem_exchange_emulation_and_switch(monkeypatch):
         lat = sx.latents(lambda x, fr=fr: (calls.append(fr), [torch.zeros(sh) for sh in shapes])[1], torch.zeros(1, 3, 32, 32))
         assert [tuple(l.shape) for l in lat] == shapes
     assert calls == [0] + [fr for fr in range(1, 20) if (fr + 4) % 8 == 3]      # (frame 0: nothing to re-use yet)
+    assert sx.last_flag is not None and not bool(sx.last_flag)                  # finite latents: no flag
+    sx2 = StemExchange(emulate=(2, 1))
+    bad = [torch.zeros(sh) for sh in shapes]
+    bad[1][0, 0, 0, 0] = float("inf")                                           # an fp16 overflow on the owner shows up like this
+    sx2.latents(lambda x: bad, torch.zeros(1, 3, 32, 32))
+    assert bool(sx2.last_flag)                                                   # ... and every rank that uses the latents sees it
     monkeypatch.delenv("TH_STEM_EXCHANGE", raising=False)
     assert not StemExchange.wanted(2) and not StemExchange.wanted(4) and not StemExchange.wanted(8)   # default OFF (round 4)
     monkeypatch.setenv("TH_STEM_EXCHANGE", "0")

@@ -202,6 +202,7 @@ class StemExchange(TokenExchange):
             import torch.distributed as dist
             w = dist.get_world_size()
         super().__init__(world, rank, group, emulate, shift=w // 2)
+        self.last_flag = None
 
     @staticmethod
     def wanted(world):
@@ -226,6 +227,12 @@ class StemExchange(TokenExchange):
             assert [tuple(l.shape) for l in lat] == shapes, "unexpected latent shapes"
             return torch.cat([l.reshape(-1) for l in lat])
         flat = self(compute, (sum(sizes),), images.device)
+        # the stem's fp16-range word lives on the owner of the frame: a receiver would otherwise learn of an overflow (inf /
+        # NaN in the hi planes of the owner's convolutions) only through its own MLP guard and fall back to the 7x slower
+        # fp32 MLP for good.  Every rank looks at what it is about to use instead (one 69 MB reduction, asynchronous); the
+        # frame pipeline reads the flag when the frame is finished and rebuilds the frame locally through the stock
+        # convolutions (Renderer.render_sequence -> hip.force_conv_fallback).
+        self.last_flag = ~torch.isfinite(flat).all()
         out, o = [], 0
         for sh, n in zip(shapes, sizes):
             out.append(flat[o:o + n].view(sh))

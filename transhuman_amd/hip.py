@@ -418,6 +418,18 @@ def _enter_fallback(device, why):
     _range_epoch[d] = _range_epoch.get(d, 0) + 1
 
 
+def force_conv_fallback(device, why):
+    """Switch the stem convolutions of this device to the stock modules (what the range guard does when slot conv_in trips)
+    on evidence from outside the context's own range table -- e.g. non-finite stem latents received from another rank
+    (dist.StemExchange).  Bumps the epoch: frames built before are rebuilt."""
+    import warnings
+    d = _dev_index(device)
+    if not _conv_fallback.get(d):
+        warnings.warn("transhuman_amd: " + why + "; using the stock convolutions until new weights are uploaded", RuntimeWarning)
+        _conv_fallback[d] = True
+        _range_epoch[d] = _range_epoch.get(d, 0) + 1
+
+
 def range_epoch(device=None):
     return _range_epoch.get(_dev_index(device), 0)
 

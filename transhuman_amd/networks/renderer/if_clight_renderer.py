@@ -152,6 +152,7 @@ class Renderer:
             H, W = images.shape[2:]
             V = images.shape[0]
             lat = enc.trunk(images) if stem_exchange is None else stem_exchange.latents(enc.trunk, images)
+            stem_flag = None if stem_exchange is None else stem_exchange.last_flag
             cw, cb = enc.upsample_color.weight, enc.upsample_color.bias
             scale = hip.feat_scale(enc.feat_scale(H, W), image_shape, dev)
             thr = cfg_hull() if hull_thresh is None else hull_thresh
@@ -226,6 +227,8 @@ class Renderer:
         # input left the fp16 range)
         # (a rebuilt frame computes its own tokens: the exchange's frame counter must not advance twice)
         frame.rebuild = lambda: self.prepare_frame(batch, hull_thresh, fused_encoder_tail, compact_map, crop_map=crop_map)
+        # (device bool: the stem latents this frame was built from were not finite -- dist.StemExchange; read in finish())
+        frame.stem_flag = stem_flag if (fused_encoder_tail and hasattr(enc, "trunk")) else None
         return frame
 
     # ---- reference API -------------------------------------------------------------------
@@ -401,7 +404,11 @@ class Renderer:
 
         def finish(ent):
             rgb, acc, depth, stats, frame, cur, pts, check, epoch = ent
-            if not check() or epoch != hip.range_epoch(dev):
+            ok = check()
+            if getattr(frame, "stem_flag", None) is not None and bool(frame.stem_flag):
+                hip.force_conv_fallback(dev, "the stem latents received for this frame are not finite (fp16 overflow in "
+                                             "the owner rank's convolutions)")
+            if not ok or epoch != hip.range_epoch(dev):
                 if hip.conv_fallback(dev) or hip.vit_fallback(dev):
                     frame = frame.rebuild()                 # constants again, through the paths the guard switched to
                 rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
@@ -418,12 +425,12 @@ class Renderer:
             # this frame's shading is not
             fence = torch.cuda.Event()
             fence.record(main)
-            # two-phase shading: the texture-path-bound producers (pixel gather, neighbour records) of the frame's first
-            # TH_PRE_SETS = 5 chunks (2.6 M samples: the whole frame at the default sizes; each set costs V * 1536 B of
-            # workspace per sample of a chunk) first, then the fused MLP of all chunks (later chunks: producers and MLP
-            # alternate as in render_fast).  The side stream's front of the next frame starts with this frame's
-            # shading: its ~130 small launches share the chip with the producers (which leave LDS / registers / the
-            # matrix pipe free) instead of time-slicing with MLP tiles that own whole CUs.
+            # two-phase shading: the texture-path-bound producers (pixel gather, neighbour records: ONE launch each over the
+            # frame's valid samples, up to TH_PRE_SAMPLES = 2.6 M, into region A of the shading pool -- 3.6 KB per sample)
+            # first, then the fused MLP over the same samples in one launch (what lies beyond: producers and MLP alternate
+            # in 512 Ki-sample chunks as in render_fast).  The side stream's front of the next frame starts with this
+            # frame's shading: its ~130 small launches share the chip with the producers (which leave LDS / registers /
+            # the matrix pipe free) instead of time-slicing with MLP tiles that own whole CUs.
             if os.environ.get("TH_PREGATHER") != "0":
                 hip.render_pregather(self.net, frame, pts)
             rgb, acc, depth, stats, check = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
