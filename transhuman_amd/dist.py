@@ -181,6 +181,26 @@ class TokenExchange:
         return tok
 
 
+class _HostFlag:
+    """A device-side boolean on its way to the host: copied into pinned memory on the stream that computed it (the side
+    stream, frames ahead of its use) and read behind an event -- ``bool(flag)`` never waits for anything but that copy.
+    (``bool(device_tensor)`` would copy on the CURRENT stream and drain the whole shading queue first.)"""
+
+    def __init__(self, flag):
+        if flag.is_cuda:
+            self.host = torch.empty(1, dtype=torch.bool, pin_memory=True)
+            self.host.copy_(flag.reshape(1), non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(flag.device))
+        else:
+            self.host, self.event = flag.reshape(1).clone(), None
+
+    def __bool__(self):
+        if self.event is not None:
+            self.event.synchronize()
+        return bool(self.host[0])
+
+
 class StemExchange(TokenExchange):
     """The ResNet stem of SpatialEncoder (encoder.py:114-126: 31 GFLOP of convolutions + ten train-mode BatchNorms, 0.5 ms
     on one MI355X) computed by ONE rank per frame as well: its output, the three low-resolution latents ([V,64,H/2,W/2],
@@ -232,7 +252,7 @@ class StemExchange(TokenExchange):
         # fp32 MLP for good.  Every rank looks at what it is about to use instead (one 69 MB reduction, asynchronous); the
         # frame pipeline reads the flag when the frame is finished and rebuilds the frame locally through the stock
         # convolutions (Renderer.render_sequence -> hip.force_conv_fallback).
-        self.last_flag = ~torch.isfinite(flat).all()
+        self.last_flag = _HostFlag(~torch.isfinite(flat).all())
         out, o = [], 0
         for sh, n in zip(shapes, sizes):
             out.append(flat[o:o + n].view(sh))
