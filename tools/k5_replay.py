@@ -70,3 +70,19 @@ for name, o in orders.items():
                 big[k] += int((u > k).sum())
         print(f"{name:30s} B={B:3d}: distinct rows / corner reads = {tot / (12 * B):.3f}  per view " +
               " ".join(f"{x:.3f}" for x in per_view) + f"  batches with U > 48: {big[48] / (3 * n / B):.4f}, > 64: {big[64] / (3 * n / B):.4f}")
+
+# ---- pair sharing inside K5's waves (depth-major in 16-ray groups): rows 2k / 2k+1 of the list are the two half-waves of a
+# wave pass; how often can the second row take corner texels from the first row's registers?
+o = orders["depth-major in 16-ray groups"]
+n2 = len(o) // 2 * 2
+for v in range(3):
+    c = corner[v][o[:n2]].reshape(-1, 2, 4)            # [pair][A|B][i00 i01 i10 i11]
+    A, B = c[:, 0], c[:, 1]
+    same = (A == B).all(1)
+    plus = (B[:, 0] == A[:, 1]) & (B[:, 2] == A[:, 3]) & ~same
+    minus = (B[:, 1] == A[:, 0]) & (B[:, 3] == A[:, 2]) & ~same
+    down = (B[:, 0] == A[:, 2]) & (B[:, 1] == A[:, 3]) & ~same & ~plus & ~minus
+    up = (B[:, 2] == A[:, 0]) & (B[:, 3] == A[:, 1]) & ~same & ~plus & ~minus
+    saved = same.mean() * 0.5 + (plus.mean() + minus.mean() + down.mean() + up.mean()) * 0.25
+    print(f"view {v}: pairs with the same 4 texels {same.mean():.3f}, shifted by +1 / -1 in x {plus.mean():.3f} / {minus.mean():.3f}, "
+          f"by +1 / -1 in y {down.mean():.3f} / {up.mean():.3f} -> corner-load bytes saved {saved:.3f}")
