@@ -224,6 +224,13 @@ def test_split_row_gather_equals_fp32_gather(hip, gpu, net):
     assert bool(((rec[:, :, :260] - ref).abs() <= tol).all()), float((rec[:, :, :260] - ref).abs().max())
     assert float(rec[:, :, 259:].abs().max()) == 0.0                                            # the 0 of r g b 0 + the pad
     assert torch.equal(hi, hip.pixel_gather_split(frame.map, world, frame.cams, frame.scale)[0])
+    # the frame-level kernel of this input shape (pixgather_s256_kernel) and the generic split-row kernel: the same bits
+    os.environ["TH_K5_GENERIC"] = "1"
+    try:
+        hi_g, lo_g = hip.pixel_gather_split(frame.map, world, frame.cams, frame.scale)
+    finally:
+        del os.environ["TH_K5_GENERIC"]
+    assert torch.equal(hi, hi_g) and torch.equal(lo, lo_g)
 
 
 def test_stem_in_eval_mode_runs_the_hip_kernels(hip, gpu):

@@ -12,6 +12,8 @@
 // The map has C channels per pixel (384 full / 260 compact, see k_encoder.hip); output rows are ldo floats
 // wide (>= C; the tail is zero-filled so the row can feed a K-padded GEMM directly: compact rows are 272).
 // Bound: L2/HBM gather, 4 * 4C B per (sample, view) in, 4*ldo B out.
+#include <stdlib.h>
+
 #include "th_internal.h"
 
 #define PG_G 16
@@ -393,6 +395,168 @@ __global__ __launch_bounds__(256) void pixgather_kernel(const float* __restrict_
     if (SPLIT) pg_range_commit(range, rm);
 }
 
+
+// ---- the frame-level form: split map (C = 256 latents + the [V,H,W,4] colour plane) -> 272-wide split rows -------------------
+// Same rows, bit for bit, as pixgather_kernel<true> on that input; written after measuring what the launch costs when every
+// corner load hits L1 (tools/k5_locality.py: 1.72 ms of the frame's 2.5 ms -- instruction issue, not memory): 365 VALU
+// instructions and 20 + 5 vector-memory instructions per batch of 4 rows there, a third of them bookkeeping --
+//  * the two rows of a pair need DIFFERENT corner indices / weights in the two half-waves: v_readlane x 2 + v_mov +
+//    v_cndmask per value and 64-bit vector address arithmetic per load.  Here phase 1 runs on every lane (lane l sets up row
+//    l >> 2: same instruction count as on 16 lanes), a half-wave fetches its row's eight values with ds_bpermute_b32 (the LDS
+//    crossbar, no LDS memory) and the corner loads take a scalar base (the view's map) + a 32-bit lane offset;
+//  * the colour texels (channels 256..258) cost 4 load instructions + a blend + a store per BATCH for 16 bytes per row: with
+//    lane = (row, corner) the whole wave's 64 colour texels are ONE load instruction, the blend runs inside the quad
+//    (quad_perm broadcasts, same term order) and the 64-byte row tails (r g b 0 | zeros, hi | lo) are one store instruction;
+//  * blend on packed fp32 FMAs, hi / lo split by v_fma_mix (split_pair of k_mlp_fused_kernel.h: bit-identical to pg_split).
+typedef float pg_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pg_bperm(int byte_addr, int x) { return __builtin_amdgcn_ds_bpermute(byte_addr, x); }
+__device__ __forceinline__ float pg_bpermf(int byte_addr, float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, x)));
+}
+template <int CTRL>
+__device__ __forceinline__ float pg_quad(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+// two values -> packed hi pair + packed lo pair (lo = fp16(x - fp32(hi)); x - hi is exact in fp32: same bits as pg_split)
+__device__ __forceinline__ void pg_split2(float x0, float x1, unsigned& hi, unsigned& lo) {
+    typedef _Float16 pg_h2 __attribute__((ext_vector_type(2)));
+    pg_h2 h;
+    h[0] = (_Float16)x0;
+    h[1] = (_Float16)x1;
+    hi = __builtin_bit_cast(unsigned, h);
+    asm("" : "+v"(hi));
+    unsigned l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hi), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hi), "v"(x1));
+    lo = l;
+}
+__device__ __forceinline__ float4 pg_blend2(float4 a, float4 bb, float4 cc, float4 d, float w00, float w01, float w10, float w11) {
+    const pg_f2 W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
+    pg_f2 lo = (pg_f2){a.x, a.y} * W00, hi = (pg_f2){a.z, a.w} * W00;
+    lo = __builtin_elementwise_fma((pg_f2){bb.x, bb.y}, W01, lo);
+    hi = __builtin_elementwise_fma((pg_f2){bb.z, bb.w}, W01, hi);
+    lo = __builtin_elementwise_fma((pg_f2){cc.x, cc.y}, W10, lo);
+    hi = __builtin_elementwise_fma((pg_f2){cc.z, cc.w}, W10, hi);
+    lo = __builtin_elementwise_fma((pg_f2){d.x, d.y}, W11, lo);
+    hi = __builtin_elementwise_fma((pg_f2){d.z, d.w}, W11, hi);
+    return make_float4(lo[0], lo[1], hi[0], hi[1]);
+}
+
+__global__ __launch_bounds__(256) void pixgather_s256_kernel(const float* __restrict__ map, int V, int H, int W,
+                                                             const float* __restrict__ pts_world, ThPointSrc ps,
+                                                             const int32_t* __restrict__ sel, int P,
+                                                             const float* __restrict__ cams, const float* __restrict__ scale,
+                                                             float* __restrict__ out, unsigned* __restrict__ range) {
+    constexpr int LDO = 272;                        // floats per output row (1088 bytes: 34 groups of [8 hi | 8 lo] halves)
+    const int lane = threadIdx.x & 63;
+    unsigned rm = 0u;
+    const long long nb8 = ((long long)gridDim.x + 7) / 8;                   // XCD-aware remap: see pixgather_kernel
+    const long long lb = (long long)(blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
+    // the four waves of a workgroup take four CONSECUTIVE 16-sample groups of ONE view (adjacent depths of the same 16 rays in
+    // the depth-major list: their footprints in that view overlap), not one group in V views
+    const int v = (int)(lb % V);
+    const long long g16 = (lb / V) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (g16 >= (P + PG_G - 1) / PG_G) return;
+    const int p0 = (int)g16 * PG_G;
+    const int nrow = min(PG_G, P - p0);
+    const char* mb = reinterpret_cast<const char*>(map + (long long)v * H * W * 256);             // wave-uniform bases
+    const float4* rgbp = reinterpret_cast<const float4*>(map + (long long)V * H * W * 256) + (long long)v * H * W;
+    char* ob = reinterpret_cast<char*>(out + ((long long)p0 * V + v) * LDO);
+
+    // ---- phase 1: lane l sets up row l >> 2 (the four lanes of a quad hold the same row: the colour tail below uses them as
+    //      the row's four corners; the row pairs fetch their values from lane 4 * row)
+    Bilin b;
+    {
+        const int p = p0 + min(lane >> 2, nrow - 1);
+        long long s = sel ? sel[p] : p;
+        float x, y, z;
+        if (pts_world) { x = pts_world[3 * s]; y = pts_world[3 * s + 1]; z = pts_world[3 * s + 2]; }
+        else th_get_point(ps, s, x, y, z);
+        float uu, vv;
+        th_project(cams + 21 * v, x, y, z, uu, vv);
+        b = th_bilinear_setup(uu, vv, scale[0], scale[1], H, W);
+    }
+    // ---- colour tail of the 16 rows: lane = (row, corner)
+    float4 tq;
+    float tw[4] = {b.w00, b.w01, b.w10, b.w11};
+    {
+        const int c = lane & 3;
+        const int ti = c == 0 ? b.i00 : c == 1 ? b.i01 : c == 2 ? b.i10 : b.i11;
+        tq = rgbp[ti];
+    }
+    const int half = lane >> 5, gl = lane & 31;
+    const unsigned o00 = (unsigned)b.i00 << 10, o01 = (unsigned)b.i01 << 10, o10 = (unsigned)b.i10 << 10, o11 = (unsigned)b.i11 << 10;
+    for (int r0 = 0; r0 < nrow; r0 += PG_B) {
+        float4 q[PG_B / 2][4][2];
+        float w[PG_B / 2][4];
+#pragma unroll
+        for (int jj = 0; jj < PG_B / 2; ++jj) {
+            const int i = min(r0 + 2 * jj + half, nrow - 1);              // ragged tail: duplicate loads, no store
+            const int src = i << 4;                                        // byte address of lane 4 i for ds_bpermute
+            const unsigned oc[4] = {(unsigned)pg_bperm(src, (int)o00), (unsigned)pg_bperm(src, (int)o01),
+                                    (unsigned)pg_bperm(src, (int)o10), (unsigned)pg_bperm(src, (int)o11)};
+            w[jj][0] = pg_bpermf(src, b.w00); w[jj][1] = pg_bpermf(src, b.w01);
+            w[jj][2] = pg_bpermf(src, b.w10); w[jj][3] = pg_bpermf(src, b.w11);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // each half-wave reads 512 contiguous bytes per instruction (channels 4 gl .. and 128 + 4 gl ..)
+                const float4* sp = reinterpret_cast<const float4*>(mb + (size_t)(oc[c] + (unsigned)gl * 16u));
+                q[jj][c][0] = sp[0];
+                q[jj][c][1] = sp[32];
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < PG_B / 2; ++jj) {
+            const int i = r0 + 2 * jj + half;
+            const float4 ra = pg_blend2(q[jj][0][0], q[jj][1][0], q[jj][2][0], q[jj][3][0], w[jj][0], w[jj][1], w[jj][2], w[jj][3]);
+            const float4 rb = pg_blend2(q[jj][0][1], q[jj][1][1], q[jj][2][1], q[jj][3][1], w[jj][0], w[jj][1], w[jj][2], w[jj][3]);
+            unsigned ha[2], la[2], hb[2], lb2[2];
+            pg_split2(ra.x, ra.y, ha[0], la[0]); pg_split2(ra.z, ra.w, ha[1], la[1]);
+            pg_split2(rb.x, rb.y, hb[0], lb2[0]); pg_split2(rb.z, rb.w, hb[1], lb2[1]);
+            pg_range_acc(rm, ha[0]); pg_range_acc(rm, hb[0]); pg_range_acc(rm, ha[1]); pg_range_acc(rm, hb[1]);
+            // lanes (2k, 2k+1) trade halves (see pg_store_pair): lane 2k ends with the 8 hi halves, lane 2k+1 with the 8 lo halves
+            const bool odd = gl & 1;
+            unsigned xa[2], xb[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                xa[e] = pg_swap1(odd ? ha[e] : la[e]);
+                xb[e] = pg_swap1(odd ? hb[e] : lb2[e]);
+            }
+            uint4 s0, s1;
+            s0.x = odd ? xa[0] : ha[0]; s0.y = odd ? xa[1] : ha[1]; s0.z = odd ? la[0] : xa[0]; s0.w = odd ? la[1] : xa[1];
+            s1.x = odd ? xb[0] : hb[0]; s1.y = odd ? xb[1] : hb[1]; s1.z = odd ? lb2[0] : xb[0]; s1.w = odd ? lb2[1] : xb[1];
+            if (i < nrow) {
+                uint4* o = reinterpret_cast<uint4*>(ob + (size_t)((unsigned)i * (unsigned)(V * LDO * 4) + (unsigned)gl * 16u));
+                o[0] = s0;
+                o[32] = s1;
+            }
+        }
+    }
+    // ---- colour tail: blend inside the quad (corner values by quad_perm broadcast; pg_blend's term order), then lane c of a quad
+    //      writes 16-byte piece c of the row's last 64 bytes: hi halves of (r g b 0 0 0 0 0), their lo halves, zeros, zeros
+    {
+        float r3[4];
+        const float tv[4] = {tq.x, tq.y, tq.z, tq.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a = pg_quad<0x00>(tv[e]), bb = pg_quad<0x55>(tv[e]), cc = pg_quad<0xAA>(tv[e]), d = pg_quad<0xFF>(tv[e]);
+            r3[e] = fmaf(d, tw[3], fmaf(cc, tw[2], fmaf(bb, tw[1], a * tw[0])));
+        }
+        unsigned h01, l01, h23, l23;
+        pg_split2(r3[0], r3[1], h01, l01);
+        pg_split2(r3[2], r3[3], h23, l23);
+        pg_range_acc(rm, h01);
+        pg_range_acc(rm, h23);
+        const int c = lane & 3, row = lane >> 2;
+        uint4 t = make_uint4(0u, 0u, 0u, 0u);
+        if (c == 0) { t.x = h01; t.y = h23; }
+        if (c == 1) { t.x = l01; t.y = l23; }
+        if (row < nrow)
+            *reinterpret_cast<uint4*>(ob + (size_t)((unsigned)row * (unsigned)(V * LDO * 4) + 1024u + (unsigned)c * 16u)) = t;
+    }
+    pg_range_commit(range, rm);
+}
+
 int th_pixgather_launch(const float* map, int V, int C, int H, int W, const float* pts_world, const ThPointSrc* ps,
                         const int32_t* sel, int P, const float* cams, const float* scale, float* out, int ldo,
                         int fmt, hipStream_t s, unsigned int* range) {
@@ -403,7 +567,13 @@ int th_pixgather_launch(const float* map, int V, int C, int H, int W, const floa
     ThPointSrc src = ps ? *ps : ThPointSrc{};
     const long long groups = (long long)th_cdiv(P, PG_G) * V;
     const int nblk = 8 * th_cdiv(th_cdiv(groups, 4), 8);     // multiple of 8 so the XCD remap is onto
-    if (fmt == TH_ROWS_SPLIT)
+    const char* k5g = getenv("TH_K5_GENERIC");                       // developer / test switch: the generic kernel on the same input
+    const bool generic = k5g != nullptr && atoi(k5g) != 0;
+    const int nblk4 = 8 * th_cdiv((long long)th_cdiv(th_cdiv(P, PG_G), 4) * V, 8);      // workgroups of 4 groups x 1 view
+    if (fmt == TH_ROWS_SPLIT && C == 256 && ldo == 272 && (long long)H * W <= (1 << 21) && !generic)
+        hipLaunchKernelGGL(pixgather_s256_kernel, dim3(nblk4), dim3(256), 0, s, map, V, H, W, pts_world, src, sel, P, cams, scale,
+                           out, range);
+    else if (fmt == TH_ROWS_SPLIT)
         hipLaunchKernelGGL(pixgather_kernel<true>, dim3(nblk), dim3(256), 0, s, map, V, C, H, W, pts_world, src, sel, P,
                            cams, scale, out, ldo, range);
     else
