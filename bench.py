@@ -122,7 +122,7 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
 
 
 def gather_block(V, n_valid, gather_ms, n_cu=256, clock_hz=2.4e9):
-    """K5 (pixgather_kernel) against its own ceiling: bytes through the texture path per (sample, view) row = 4 corner
+    """K5 (pixgather_s256_kernel) against its own ceiling: bytes through the texture path per (sample, view) row = 4 corner
     texels of 1040 B (1 KiB of latents + 16 B colour) + one 1088-byte split row written; tools/ubench/load_rate.hip
     reaches ~50 B/clk/CU for 1 KiB row gathers out of L2."""
     rows = float(n_valid) * V
@@ -130,13 +130,16 @@ def gather_block(V, n_valid, gather_ms, n_cu=256, clock_hz=2.4e9):
     sec = max(gather_ms * 1e-3, 1e-12)
     t = hbm_traffic()
     hbm = (t["pixgather_bytes_per_launch"] * n_valid / t["launch_samples"]) if t else None
-    return {"kernel": "pixgather_kernel<true>", "texture_path_bytes_per_step": byts, "ms_per_step": gather_ms,
+    return {"kernel": "pixgather_s256_kernel", "texture_path_bytes_per_step": byts, "ms_per_step": gather_ms,
             # bytes through the TEXTURE path (L1 / L2 hits included) -- NOT HBM bytes: this figure can exceed the HBM peak
             "texture_path_TB_per_s": byts / sec / 1e12,
             "hbm_TB_per_s": (hbm / sec / 1e12) if hbm else None,
             "hbm_note": ("HBM bytes from the committed PMC pass (" + t["source"] + "), scaled to this frame's samples") if t else None,
             "B_per_clk_per_CU": byts / sec / clock_hz / n_cu, "ubench_ceiling_B_per_clk_per_CU": 50.0,
             "frac_of_ubench_ceiling": byts / sec / clock_hz / n_cu / 50.0,
+            # the same launch with every corner load hitting L1 (tools/k5_locality.py `one`, profiles/r04_e_k5_bound.txt): what the
+            # kernel's own instruction stream + its 6.8 GB of stores cost; the rest is the latency of the frame's L1 misses
+            "all_hit_floor_ms_standalone": 1.44,
             "note": f"at the nominal {clock_hz / 1e9:.1f} GHz, {n_cu} CUs; runs beside K4 (neighbour records) on a second stream"}
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""What bounds K5 (pixgather_kernel<true>)?  The same launch (the headline frame's 2.09 M valid samples x 3 views, split
+"""What bounds K5 (pixgather_s256_kernel; TH_K5_GENERIC=1: pixgather_kernel<true>)?  The same launch (the headline frame's 2.09 M valid samples x 3 views, split
 rows out) on the frame's own sample list and on lists with the SAME instruction stream but other footprints:
   rowmajor / tile8 / morton / ...: the depth-major list of the frame with its hit rays in that image order (bench.py: tile8)
   shuffled the same samples in random order                      (no locality between the rows of a wave)

@@ -50,7 +50,7 @@ def main():
         except (OSError, IndexError, KeyError, ValueError):
             pass
         print(json.dumps({"source": src, "launch_samples": ch,
-                          "mlp_fused_bytes_per_launch": of("mlp_fused"), "pixgather_bytes_per_launch": of("pixgather_kernel<true>"),
+                          "mlp_fused_bytes_per_launch": of("mlp_fused"), "pixgather_bytes_per_launch": of("pixgather_s256") or of("pixgather_kernel<true>"),
                           "dparf_bytes_per_launch": of("dparf_kernel"),
                           "mlp_fused_algorithmic_bytes_per_launch": ch * (V * 1088 + 256 + 64) + ch // 32 * 512,
                           "algorithmic_note": "pixel-feature rows once (3 x 1088 B), positional encoding 256 B, neighbour record "
