@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 6
+#define TH_ABI_VERSION 7
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -108,6 +108,15 @@ int th_set_mlp_mode(th_ctx* ctx, int mode);
  * sample; a ray shard then equals the whole frame bit for bit instead of to fp32 rounding).  Env TH_TOK_GATHER=0 makes
  * 0 the default of new contexts. */
 int th_set_tok_gather(th_ctx* ctx, int on);
+/* K5 -> K6 hand-over of the pixel-aligned features on the fused path (get_pixel_aligned_feature,
+ * if_clight_renderer.py:210-269, feeding alpha_res_0 / rgb_res_0 / rgb_res_1, cross_transformer.py:300-346), for frames
+ * whose map is TH_MAP_SPLIT: 1 (default) = per 32-sample tile the list of DISTINCT corner texels of its V x 32 rows
+ * (~79 of 384 on the headline frame) and per row four row numbers + bilinear weights + the blended colour (160 B per
+ * sample); the fused kernel copies those texels of the map into LDS and blends them itself, in K5's term order -- the
+ * operand it multiplies is K5's row, bit for bit, and nothing of it travels through HBM; 0 = K5 writes the rows (3.3 KB per
+ * sample, read back twice).  Env TH_ROWS_TEX=0 makes 0 the default of new contexts.  Ask th_shade_pool_bytes again
+ * after a change. */
+int th_set_tex_rows(th_ctx* ctx, int on);
 
 /* Range guard of the fp16 hi/lo split arithmetic (fused MLP kernel, its producer K5, the ResNet-stem convolutions).
  * The reference computes this path in fp32 (cross_transformer.py:291-353 has no autocast); the fused kernel is

@@ -254,3 +254,49 @@ def test_stem_in_eval_mode_runs_the_hip_kernels(hip, gpu):
         assert torch.isfinite(u).all() and maxdiff(u, v) < 2e-5 * max(1.0, float(v.abs().max()))
     for b, (m0, v0, n0) in zip(enc._bn_sites(), before):
         assert torch.equal(b.running_mean, m0) and torch.equal(b.running_var, v0) and int(b.num_batches_tracked) == n0
+
+
+def _tex_on_off(hip, r, b, **kw):
+    """the same frame with the texel hand-over (TH_ROWS_TEX, default) and with K5's rows through HBM"""
+    try:
+        hip.set_tex_rows(True)
+        o1 = r.render_fast(b, is_train=False, **kw)
+        st = dict(r.last_stats)
+        hip.set_tex_rows(False)
+        o0 = r.render_fast(b, is_train=False, **kw)
+    finally:
+        hip.set_tex_rows(True)
+    return o1, o0, st
+
+
+@pytest.mark.parametrize("case", ["headline", "dense", "v1_small", "v2_small", "ragged", "forced_passes"])
+def test_texel_handover_equals_row_handover_bitwise(hip, gpu, net, case):
+    """TH_ROWS_TEX: the fused kernel blends the distinct corner texels of a tile itself (k_pixtex.hip + fill_tex) instead of
+    reading K5's rows.  Same arithmetic in the same order -> the operand planes, and therefore the images, are bit-identical.
+    `dense` (every sample valid, focal 6000: footprints of a tile spread over many texels) exercises the 2- and 4-pass
+    tiles; the small frames the V = 1 / 2 instantiations and the ragged last tile."""
+    if case == "headline":
+        r = _renderer(net, 500)
+        b = synth.batch_to(synth.make_batch(512, 512, 3, seed=0, all_rays=True), gpu)
+    elif case == "dense":
+        r = _renderer(net, 500)
+        b = synth.batch_to(synth.make_batch(256, 256, 3, seed=0, all_rays=True, dense=True, focal=1500.0, dilate=64), gpu)
+    elif case == "forced_passes":       # a row budget of 40 per pass: nearly every tile takes the 2- or 4-pass form
+        os.environ["TH_TEX_CAP"] = "40"
+        r = _renderer(net, 300, samples=48)
+        b = synth.batch_to(synth.make_batch(128, 128, 3, seed=2, all_rays=True), gpu)
+    elif case == "ragged":
+        r = _renderer(net, 300, samples=37)
+        b = synth.batch_to(synth.make_batch(97, 61, 3, seed=3, all_rays=True), gpu)
+    else:
+        V = 1 if case == "v1_small" else 2
+        r = _renderer(net, 300, samples=32)
+        b = synth.batch_to(synth.make_batch(96, 96, V, seed=1, all_rays=True), gpu)
+    try:
+        o1, o0, st = _tex_on_off(hip, r, b)
+    finally:
+        os.environ.pop("TH_TEX_CAP", None)
+    assert st["valid_samples"] > 1000, st
+    for k in ("rgb_map", "acc_map", "depth_map"):
+        assert torch.equal(o1[k], o0[k]), (case, k, maxdiff(o1[k].cpu(), o0[k].cpu()))
+    assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")

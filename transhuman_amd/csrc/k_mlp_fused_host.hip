@@ -344,7 +344,7 @@ int th_tok_split(float* tprime, int rows, float* sc, unsigned int* range, hipStr
 
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all, float* raw_c,
-                         unsigned int* range, hipStream_t s, const void* tsplit, const float* t_inv, int t_nc) {
+                         unsigned int* range, hipStream_t s, const void* tsplit, const float* t_inv, int t_nc, const float* tex_map) {
     if (P <= 0) return 0;
     TH_REQUIRE(V >= 1 && V <= 3, "fused MLP supports 1..3 reference views");
     TH_REQUIRE(f_ld == 384 || (f_ld == 272 && base.compact_ready),
@@ -355,6 +355,15 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     p.alpha_w = heads.alpha_w; p.alpha_b = heads.alpha_b; p.rgb_w = heads.rgb_w; p.rgb_b = heads.rgb_b;
     TH_REQUIRE(tsplit == nullptr || (t_inv != nullptr && t_nc >= 7 && t_nc <= 4096), "split token table: scale word and 7 <= N_c <= 4096");
     p.tsplit = (const _Float16*)tsplit; p.t_inv = t_inv; p.t_nc = t_nc;
+    const bool tex = tex_map != nullptr;
+    TH_REQUIRE(!tex || (cf && f != nullptr), "texel hand-over: compact (272-wide) operand planes only");
+    p.tex_hdr = nullptr; p.tex_rec = nullptr; p.tex_map = nullptr;
+    if (tex) {          // `f` is K5t's block: tile headers, then the per-row records (th_pixtex_launch)
+        p.tex_hdr = (const unsigned*)f;
+        p.tex_rec = p.tex_hdr + (size_t)th_cdiv(P, FM_PTS) * 512;
+        p.tex_map = tex_map;
+        f = nullptr;
+    }
     p.stok = stok; p.pe = (const _Float16*)pe; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all; p.range = range;
     static bool attr = false;
     if (!attr) {
@@ -363,9 +372,14 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
                                FUSED_LDS_BYTES))
         FM_ATTR(1, 0); FM_ATTR(2, 0); FM_ATTR(3, 0); FM_ATTR(1, 1); FM_ATTR(2, 1); FM_ATTR(3, 1);
 #undef FM_ATTR
+#define FM_ATTR_T(V_)                                                                                              \
+    TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<V_, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                               FUSED_LDS_BYTES))
+        FM_ATTR_T(1); FM_ATTR_T(2); FM_ATTR_T(3);
+#undef FM_ATTR_T
         attr = true;
     }
-    dim3 grid(th_cdiv(P, FM_PTS));
+    dim3 grid(tex ? 8 * th_cdiv(th_cdiv(P, FM_PTS), 8) : th_cdiv(P, FM_PTS));     // (TEX: XCD-contiguous tile order)
     // developer experiment (timing only, results are wrong): alias every layer's weights onto fc_1's image
     // so the weight working set is 256 KB -> shows how much of a phase is L2-capacity/latency
     static int alias_w = getenv("TH_FUSED_ALIAS_W") ? 1 : 0;
@@ -384,6 +398,10 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
         p.dbg = dbg_dev;
     }
 #define FM_LAUNCH(V_, F_) hipLaunchKernelGGL((mlp_fused_kernel<V_, F_>), grid, dim3(256), FUSED_LDS_BYTES, s, p)
+#define FM_LAUNCH_T(V_) hipLaunchKernelGGL((mlp_fused_kernel<V_, 1, true>), grid, dim3(256), FUSED_LDS_BYTES, s, p)
+    if (tex) {
+        if (V == 1) FM_LAUNCH_T(1); else if (V == 2) FM_LAUNCH_T(2); else FM_LAUNCH_T(3);
+    } else
     switch (V * 2 + (cf ? 1 : 0)) {
         case 2: FM_LAUNCH(1, 0); break;
         case 3: FM_LAUNCH(1, 1); break;
@@ -393,6 +411,7 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
         default: FM_LAUNCH(3, 1); break;
     }
 #undef FM_LAUNCH
+#undef FM_LAUNCH_T
     TH_LAUNCH_CHECK();
     if (dbg_now) {
         long long st[64];

@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned fm_u4 __attribute__((ext_vector_type(4)));
 
 #define FM_PTS 32
 #define STR272 560   // bytes per LDS row = 2K + 16, K = 272 halves (compact pixel-feature rows)
@@ -578,20 +579,26 @@ __device__ __forceinline__ const uint4* wslice(const FusedLayer& L, int wave, in
 #else
 #define FM_VGPR_ATTR
 #endif
-template <int V, int FM>
+template <int V, int FM, bool TEX = false>
 __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedParams P) {
     using FL = FLay<FM>;
+    static_assert(!TEX || FM == 1, "the texel hand-over produces compact (272-wide) operand planes");
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* abuf = lds;
     char* mbuf = lds + ABUF_BYTES;
     float* misc = reinterpret_cast<float*>(lds + ABUF_BYTES + MBUF_BYTES);
     float* probs = misc;                  // [V*V][32]
-    float* sig = misc + 9 * 32;           // [32] (+ padding)
-    float* part = sig + 128;              // [4 waves][32][4]
-    int* flag = reinterpret_cast<int*>(part + 4 * 32 * 4);
+    float* part = misc + 9 * 32;          // [4 waves][32][4]   (TEX: probs + part take the tile's 3 KB of row records while
+    float* sig = part + 4 * 32 * 4;       // [32] (+ padding)    a filling runs: both are dead then, sig is not)
+    int* flag = reinterpret_cast<int*>(sig + 128);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pbase = blockIdx.x * FM_PTS;
+    // TEX: the tiles of an XCD (workgroups b, b + 8, b + 16 ... share an L2) are CONSECUTIVE tiles of the sample list -- their
+    // texel rows overlap (adjacent depths of the same rays, neighbouring ray groups), so a row missing in L2 is fetched
+    // once per XCD instead of once per tile.  (The launcher rounds the grid up to a multiple of 8.)
+    const int tile = TEX ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    const int pbase = tile * FM_PTS;
+    if (TEX && pbase >= P.P) return;
     const int npts = min(FM_PTS, P.P - pbase);
     constexpr int ROWS = 32 * V;
     const int myrow = lane & 31;
@@ -613,6 +620,187 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     char* a256_lo = abuf + ROWS * STR256;
     char* fa_lo = abuf + ROWS * FL::SA;      // lo planes of the two f fillings
     char* fb_lo = abuf + ROWS * FL::SB;
+
+    // ---- TEX (TH_ROWS_TEX): the pixel-feature operand is formed HERE from the texels of the map --------------------------
+    // K5t (k_pixtex.hip) hands over, per tile, the list of DISTINCT corner texels of its 32 x V (sample, view) rows (79 on
+    // average for the headline frame, at most 103 per pass) and per row four row numbers + four bilinear weights + the
+    // blended colour.  Every listed texel is one 1 KiB row of the map (256 fp32 latents, L2 / MALL resident):
+    //  1. a wave copies its share of the texel rows into ABUF (rows of 1040 bytes) -- plain 16-byte loads, all of a wave's
+    //     requests in flight, then ds_write_b128 (LDS-DMA lands ~12 B/clk/CU whatever the source: 11 k cycles for 80 KB);
+    //  2. a wave blends one operand row per step: lane l owns channels 4 l .. 4 l + 3, the four corner rows are read with one
+    //     conflict-free ds_read_b128 each (64 lanes = the whole 1 KiB row), row numbers and weights are wave-uniform (scalar
+    //     loads of the record), K5's packed-FMA term order -- the values are K5's, bit for bit -- and the split hi / lo halves
+    //     stay in registers (4 dwords per row, 8 V rows per wave) across the barrier that retires the texel rows;
+    //  3. the halves are written as the operand planes over the same buffer (512 contiguous bytes per instruction).
+    // Nothing of f travels through HBM; the second use (RGB branch) repeats the filling from rows that are L2-warm by then.
+    // `under` runs between the row requests and their arrival.
+    // (tex_fetch: the tile header and this thread's piece of the row records, requested a phase ahead of the filling that
+    // uses them -- an HBM round trip otherwise sits in front of the first texel-row request)
+    struct TexPre { unsigned h0, h1; fm_u4 rq; };
+    auto tex_fetch = [&]() __attribute__((always_inline)) {
+        int tl = tile;
+        asm volatile("" : "+s"(tl));        // (laundered per call: addresses derived from it are recomputed, not kept live)
+        TexPre t;
+        const unsigned* hb = P.tex_hdr + (long long)tl * 512;
+        t.h0 = hb[lane];
+        t.h1 = hb[64 + lane];
+        t.rq = (fm_u4){0u, 0u, 0u, 0u};
+        if (tid < 64 * V) t.rq = *reinterpret_cast<const fm_u4*>(P.tex_rec + (long long)tl * V * 32 * 8 + tid * 4);
+        return t;
+    };
+    auto fill_tex = [&](const TexPre& pre, auto&& under) __attribute__((always_inline)) {
+        constexpr int TSTR = 1040, TMAX = 103, NK = (TMAX + 3) / 4, NR = 8 * V;
+        static_assert(TMAX * TSTR <= ABUF_BYTES, "a pass of texel rows must fit the operand buffer");
+        int wv = __builtin_amdgcn_readfirstlane(wave), tl = tile;
+        asm volatile("" : "+s"(wv), "+s"(tl));
+        const unsigned seen_f = P.range ? P.range[TH_RANGE_F] : 0u;
+        const unsigned* hb = P.tex_hdr + (long long)tl * 512;
+        unsigned h0 = pre.h0, h1 = pre.h1;
+        const int npass = __builtin_amdgcn_readfirstlane((int)(h0 >> 16));
+        // the tile's row records ({rows, w00, w01, w10} {w11, r, g, b} per operand row, 32 V rows) go to LDS (MISC: free here)
+        char* recl = reinterpret_cast<char*>(misc);
+        static_assert(32 * V * 32 <= (9 * 32 + 4 * 32 * 4) * 4, "row records must fit probs + part");
+        unsigned fh[NR][2] = {}, fl[NR][2] = {};     // operand row wv + 4 k: hi / lo halves of channels 4 lane .. 4 lane + 3
+        for (int p = 0; p < npass; ++p) {
+            if (p > 0) {
+                FM_SYNCL();                                  // the previous pass's rows have been read
+                h0 = hb[p * 128 + lane];
+                h1 = hb[p * 128 + 64 + lane];
+            }
+            const int U = __builtin_amdgcn_readfirstlane((int)(h0 & 0xffffu));
+            {
+                // rows wv, wv + 4, ... of the list: the first 14 of a wave always (indices past the end clamped: the last
+                // row again, same bytes to the same place), the other 12 only for lists longer than 56 -- so that the header
+                // word of a request (8 + row) is always in h0 for the first group and always in h1 for the second (no
+                // branch between the loads).  Addresses are a scalar base + a 32-bit lane offset (map < 4 GiB: launcher).
+                constexpr int NA = 14;
+                const char* mbase = reinterpret_cast<const char*>(P.tex_map);
+                const unsigned loff = (unsigned)lane * 16u;
+                const int last = U - 1;
+                fm_u4 ta[NA], tb[NK - NA];
+#pragma unroll
+                for (int k = 0; k < NA; ++k) {
+                    const int i = min(wv + 4 * k, last);
+                    const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)h0, 8 + i);
+                    ta[k] = *reinterpret_cast<const fm_u4*>(mbase + (size_t)((id << 10) + loff));
+                }
+                const bool more = U > 4 * NA;
+                if (more) {
+#pragma unroll
+                    for (int k = NA; k < NK; ++k) {
+                        const int i = min(wv + 4 * k, last);
+                        const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)h1, i - 56);
+                        tb[k - NA] = *reinterpret_cast<const fm_u4*>(mbase + (size_t)((id << 10) + loff));
+                    }
+                }
+                if (p == 0) {
+                    under();
+                    if (tid < 64 * V) *reinterpret_cast<fm_u4*>(recl + tid * 16) = pre.rq;
+                }
+                int wv2 = wv;                               // (recomputed row numbers: no scalar lives across the loads)
+                asm volatile("" : "+s"(wv2));
+#pragma unroll
+                for (int k = 0; k < NA; ++k) *reinterpret_cast<fm_u4*>(abuf + min(wv2 + 4 * k, last) * TSTR + lane * 16) = ta[k];
+                if (more) {
+#pragma unroll
+                    for (int k = NA; k < NK; ++k) *reinterpret_cast<fm_u4*>(abuf + min(wv2 + 4 * k, last) * TSTR + lane * 16) = tb[k - NA];
+                }
+            }
+            FM_SYNCL();                                      // the texel rows (and the records) are in place
+            // One operand row per step and wave, software-pipelined by hand: the reads of row k + 1 (its record: the same address
+            // in every lane, a broadcast; its four corner rows) are issued before row k is blended -- written row by row the
+            // compiler waits for every row's record, then for its corners: two exposed LDS round trips per row, 8.7 k cycles.
+            // Operand row wv + 4 k is sample wv + 4 (k & 7): its pass is (k & 7) >> (sh - 2), known per k.
+            const int sh2 = npass == 1 ? 3 : npass == 2 ? 2 : 1;
+            const int cofs = lane * 16;
+            unsigned rwv[NR];                                // the `rows` words of this wave's operand rows
+#pragma unroll
+            for (int k = 0; k < NR; ++k) rwv[k] = *reinterpret_cast<const unsigned*>(recl + (wv + 4 * k) * 32);
+            struct RowIn { float4 a, b, c, d; fm_u4 q0, q1; };
+            auto issue = [&](int k, RowIn& r) __attribute__((always_inline)) {
+                const unsigned rw = (unsigned)__builtin_amdgcn_readfirstlane((int)rwv[k]);
+                const char* rc = recl + (wv + 4 * k) * 32;
+                r.q0 = *reinterpret_cast<const fm_u4*>(rc);
+                r.q1 = *reinterpret_cast<const fm_u4*>(rc + 16);
+                r.a = *reinterpret_cast<const float4*>(abuf + ((rw & 0xffu) * TSTR + cofs));
+                r.b = *reinterpret_cast<const float4*>(abuf + (((rw >> 8) & 0xffu) * TSTR + cofs));
+                r.c = *reinterpret_cast<const float4*>(abuf + (((rw >> 16) & 0xffu) * TSTR + cofs));
+                r.d = *reinterpret_cast<const float4*>(abuf + ((rw >> 24) * TSTR + cofs));
+            };
+            auto blend = [&](int k, const RowIn& r, auto sel) __attribute__((always_inline)) {
+                // (plain copies first: __builtin_bit_cast applied to a vector COMPONENT reads component 0)
+                const unsigned u01 = r.q0[1], u02 = r.q0[2], u03 = r.q0[3], u10 = r.q1[0];
+                const float w00 = __builtin_bit_cast(float, u01), w01 = __builtin_bit_cast(float, u02),
+                            w10 = __builtin_bit_cast(float, u03), w11 = __builtin_bit_cast(float, u10);
+                // (pg_blend2 of k_pixfeat.hip: a w00, then fused multiply-adds in the order ne, sw, se)
+                const f32x2 W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
+                f32x2 lo = (f32x2){r.a.x, r.a.y} * W00, hi = (f32x2){r.a.z, r.a.w} * W00;
+                lo = __builtin_elementwise_fma((f32x2){r.b.x, r.b.y}, W01, lo);
+                hi = __builtin_elementwise_fma((f32x2){r.b.z, r.b.w}, W01, hi);
+                lo = __builtin_elementwise_fma((f32x2){r.c.x, r.c.y}, W10, lo);
+                hi = __builtin_elementwise_fma((f32x2){r.c.z, r.c.w}, W10, hi);
+                lo = __builtin_elementwise_fma((f32x2){r.d.x, r.d.y}, W11, lo);
+                hi = __builtin_elementwise_fma((f32x2){r.d.z, r.d.w}, W11, hi);
+                unsigned nh0, nl0, nh1, nl1;
+                split_pair(lo[0], lo[1], nh0, nl0);
+                split_pair(hi[0], hi[1], nh1, nl1);
+                if constexpr (decltype(sel)::value) {        // multi-pass tile: a row is kept in its own pass only
+                    const bool mine = ((k & 7) >> sh2) == p;
+                    fh[k][0] = mine ? nh0 : fh[k][0]; fl[k][0] = mine ? nl0 : fl[k][0];
+                    fh[k][1] = mine ? nh1 : fh[k][1]; fl[k][1] = mine ? nl1 : fl[k][1];
+                } else {
+                    fh[k][0] = nh0; fl[k][0] = nl0; fh[k][1] = nh1; fl[k][1] = nl1;
+                }
+            };
+            auto rows_loop = [&](auto sel) __attribute__((always_inline)) {
+                RowIn in[2];
+                issue(0, in[0]);
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    if (k + 1 < NR) issue(k + 1, in[(k + 1) & 1]);
+                    FM_SB();
+                    blend(k, in[k & 1], sel);
+                    FM_SB();
+                }
+            };
+            if (npass == 1) rows_loop(std::false_type{});
+            else rows_loop(std::true_type{});
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            range_acc<false>(rmax, fh[k][0]);
+            range_acc<false>(rmax, fh[k][1]);
+        }
+        // lane k < 8 V: the blended colour of operand row wv + 4 k (the record is still in MISC)
+        fm_u4 qc = {0u, 0u, 0u, 0u};
+        if (lane < NR) qc = *reinterpret_cast<const fm_u4*>(recl + (wv + 4 * lane) * 32 + 16);
+        FM_SYNCL();                                          // every wave is done reading texel rows: ABUF takes the planes
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int row = wv + 4 * k;
+            *reinterpret_cast<uint2*>(abuf + row * STR272 + lane * 8) = make_uint2(fh[k][0], fh[k][1]);
+            *reinterpret_cast<uint2*>(fa_lo + row * STR272 + lane * 8) = make_uint2(fl[k][0], fl[k][1]);
+        }
+        // colour tail: channels 256..258 = the blended r g b, 259..271 = 0
+        if (lane < NR) {
+            const int row = wv + 4 * lane;
+            const unsigned ur = qc[1], ug = qc[2], ub = qc[3];
+            uint4 th = make_uint4(0u, 0u, 0u, 0u), tl4 = make_uint4(0u, 0u, 0u, 0u);
+            split_pair(__builtin_bit_cast(float, ur), __builtin_bit_cast(float, ug), th.x, tl4.x);
+            split_pair(__builtin_bit_cast(float, ub), 0.f, th.y, tl4.y);
+            range_acc<false>(rmax, th.x);
+            range_acc<false>(rmax, th.y);
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(abuf + row * STR272 + 512) = th;
+            *reinterpret_cast<uint4*>(abuf + row * STR272 + 528) = z4;
+            *reinterpret_cast<uint4*>(fa_lo + row * STR272 + 512) = tl4;
+            *reinterpret_cast<uint4*>(fa_lo + row * STR272 + 528) = z4;
+        }
+        range_commit(P.range, TH_RANGE_F, seen_f, rmax);
+    };
+
+    TexPre tex_pre{}, tex_pre2{};
+    if constexpr (TEX) tex_pre = tex_fetch();
 
     // ================= token branch: s = relu(fc_0 h); ks|vs = kv1(s) =================
     // fc_0 is linear and h = sum_k w_k [token_v[k] | PE_k]: the token part of fc_0(h) is sum_k w_k (W_tok token_v[k]),
@@ -677,7 +865,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             char* wsp_hi = mbuf + 16384;                                     // W [sample][slot] halves, K = 32 per pass
             char* wsp_lo = wsp_hi + 32 * STRVD;
             const unsigned* hdr = reinterpret_cast<const unsigned*>(P.stok) + (long long)((P.P + 31) / 32 * 32) * 16 +
-                                  (long long)blockIdx.x * 128;
+                                  (long long)tile * 128;
             const unsigned h0 = hdr[lane], h1 = hdr[64 + lane];
             const int ns = tid / 7, nk = tid - 7 * ns;
             int slot = -1;
@@ -887,13 +1075,19 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     // ================= pixel branch: p = relu(alpha_res_0 f); kp|vp = kv0(p) =================
     if (P.tsplit == nullptr) load_vd();      // (TH_ROWS_NBR: requested in the token branch, behind the tile header)
     FM_SB();
+    uint4 wk2[FM_RING_D2][2][2];
+    if constexpr (TEX) {
+        fill_tex(tex_pre, [] {});
+        ring_prefetch0<2, FM_RING_D2>(wslice(P.ar0, wave, 2, 0), lane, wk2);
+        FM_SYNCL();
+    } else {
     stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
 #ifdef FM_STAMPS
     FM_STAMP();
 #endif
-    uint4 wk2[FM_RING_D2][2][2];
     ring_prefetch0<2, FM_RING_D2>(wslice(P.ar0, wave, 2, 0), lane, wk2);
     FM_SYNC();
+    }
     gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 3, true>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2, wk2);
 #ifdef FM_STAMPS
     FM_STAMP();
@@ -1108,6 +1302,9 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     char* vd_lo = vd_hi + 32 * STRVD;
     // acc2[0] collects the three K ranges of the folded view_fc (this wave's 32 of its 128 outputs), acc2[1] is
     // rgb_res_1: the pass over f multiplies the stacked [Wa R0 ; R1] image as two column tiles.
+    if constexpr (TEX) {
+        if (P.rgb_all != 2) tex_pre2 = tex_fetch();      // (for the RGB branch's filling: the round trip runs under fc_3)
+    }
     f32x16 (&vf)[1][V] = *reinterpret_cast<f32x16 (*)[1][V]>(&acc2[0]);
     {
         f32x16 a1[2][1];
@@ -1177,6 +1374,17 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         uint4 wvd[FM_RING_D2][1][2];
         ring_prefetch<1, FM_RING_D2>(wslice(P.vfD, wave, 1, 0), 2, lane, wvd);
         FM_SB();
+        if constexpr (TEX) {
+            fill_tex(tex_pre2, [&]() __attribute__((always_inline)) {
+                gemm_phase_core<V, 1, STRVD, 0, FM_RING_D2, true, 0, true, false>(vd_hi, vd_lo, wslice(P.vfD, wave, 1, 0), 2, lane, vf, wvd);   // KB < D
+            });
+            ring_prefetch0<2, FM_RING_D2>(wslice(P.rst, wave, 2, 0), lane, wk2);
+#pragma unroll
+            for (int r = 0; r < V; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[1][r][e] = 0.f;
+            FM_SYNCL();
+        } else {
         stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
         ring_prefetch0<2, FM_RING_D2>(wslice(P.rst, wave, 2, 0), lane, wk2);
         FM_SB();
@@ -1186,6 +1394,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc2[1][r][e] = 0.f;
         FM_SYNC();
+        }
         gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 0, true>(abuf, fa_lo, wslice(P.rst, wave, 2, 0), FL::NA, lane, acc2, wk2);
 #ifdef FM_STAMPS
         FM_STAMP();

@@ -74,6 +74,7 @@ int th_ctx_create(int device, th_ctx** out) {
     c->device = device;
     c->n_cu = prop.multiProcessorCount;
     if (const char* e = getenv("TH_TOK_GATHER")) c->tok_gather = e[0] == '0' ? 0 : 1;
+    if (const char* e = getenv("TH_ROWS_TEX")) c->tex_rows = e[0] == '0' ? 0 : 1;
     TH_HIP(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(int32_t), hipHostMallocDefault));
     TH_HIP(hipMalloc((void**)&c->range_dev, TH_RANGE_SLOTS * sizeof(unsigned int)));
     TH_HIP(hipMemset(c->range_dev, 0, TH_RANGE_SLOTS * sizeof(unsigned int)));
@@ -311,6 +312,12 @@ int th_set_vit_mode(th_ctx* c, int mode) {
 int th_set_tok_gather(th_ctx* c, int on) {
     TH_REQUIRE(c && (on == 0 || on == 1), "th_set_tok_gather: 0 (blended rows from K4) or 1 (neighbour records, blend in the fused kernel)");
     c->tok_gather = on;
+    return 0;
+}
+
+int th_set_tex_rows(th_ctx* c, int on) {
+    TH_REQUIRE(c && (on == 0 || on == 1), "th_set_tex_rows: 0 (pixel-feature rows from K5) or 1 (texel lists, blend in the fused kernel)");
+    c->tex_rows = on;
     return 0;
 }
 
@@ -681,6 +688,11 @@ static int dparf_row_format(const th_ctx* c, int V) {                           
 
 // bytes of K4's TH_ROWS_NBR output for m samples: records rounded up to whole tiles + one 512-byte header per tile
 static size_t nbr_bytes(size_t m) { return (m + 32) * 16 * 4 + (m / 32 + 2) * 128 * 4; }
+// TH_ROWS_TEX: on the fused path a frame with a split map (TH_MAP_SPLIT) hands the fused kernel texel lists instead of
+// pixel-feature rows (k_pixtex.hip; th_set_tex_rows(ctx, 0) / TH_ROWS_TEX=0: K5's rows through HBM as before)
+static bool tex_rows(const th_ctx* c, int V, int map_channels) {
+    return mlp_is_fused(c, V) && c->tex_rows == 1 && map_channels == TH_MAP_SPLIT;
+}
 
 // ---- the shading pool -------------------------------------------------------------------------------------------
 // Everything the per-sample stage needs PER VALID SAMPLE lives in a second caller-supplied buffer, the shading pool,
@@ -703,7 +715,7 @@ struct PoolPlan {
     size_t a_f = 0, a_h = 0, a_pe = 0, b_h = 0, b_f = 0, b_vdc = 0, b_pe = 0, b_mlp = 0, raw_c = 0, total = 0;
     size_t b_mlp_bytes = 0;
 };
-static PoolPlan pool_plan(const th_ctx* c, int V, int f_ld, long long n, bool with_pre) {
+static PoolPlan pool_plan(const th_ctx* c, int V, int f_ld, long long n, bool with_pre, bool tex) {
     PoolPlan p;
     const bool fused = mlp_is_fused(c, V);
     const bool can_pre = fused && tok_gather(c, V);
@@ -714,7 +726,7 @@ static PoolPlan pool_plan(const th_ctx* c, int V, int f_ld, long long n, bool wi
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += th_align(bytes); return o; };
     if (p.pre_n > 0) {
-        p.a_f = take((size_t)p.pre_n * V * f_ld * 4);
+        p.a_f = take(tex ? th_pixtex_bytes(V, p.pre_n) : (size_t)p.pre_n * V * f_ld * 4);
         p.a_h = take(nbr_bytes((size_t)p.pre_n));
         p.a_pe = take((size_t)p.pre_n * 64 * 4);
     }
@@ -722,7 +734,7 @@ static PoolPlan pool_plan(const th_ctx* c, int V, int f_ld, long long n, bool wi
         const size_t rows = (size_t)V * p.ch;
         // h: fp32 rows / folded rows [rows][256], or the neighbour records of the chunk
         p.b_h = take(can_pre ? nbr_bytes((size_t)p.ch) : rows * 256 * 4);
-        p.b_f = take(rows * (fused ? f_ld : 384) * 4);
+        p.b_f = take(tex ? th_pixtex_bytes(V, p.ch) : rows * (fused ? f_ld : 384) * 4);
         p.b_vdc = take((size_t)p.ch * 27 * 4);
         p.b_pe = take((size_t)p.ch * 64 * 4);
         p.b_mlp_bytes = fused ? 0 : th_mlp_ws(V, p.ch);
@@ -756,13 +768,15 @@ static int token_table(th_ctx* c, const float* tokens, int V, int nc, float* tpr
 // addressed as vd_sel[p] / vd_div (vd_sel == nullptr: row p); the fused kernel reads the table in place, the
 // per-layer form wants them gathered into cb.vdc first.
 static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, const float* vd_table,
-                        const int32_t* vd_sel, int vd_div, int rgb_all, hipStream_t s, float* tprime = nullptr, int nc = 0) {
+                        const int32_t* vd_sel, int vd_div, int rgb_all, hipStream_t s, float* tprime = nullptr, int nc = 0,
+                        const float* tex_map = nullptr) {
     TH_REQUIRE(c->mlp.ready, "MLP weights not set (th_set_mlp_weights)");
     if (mlp_is_fused(c, V)) {
         const bool nbr = tok_gather(c, V);
         TH_REQUIRE(!nbr || tprime != nullptr, "the neighbour-record path needs the split token table");
         return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.pe, cb.f, f_ld, vd_table, vd_sel, vd_div, rgb_all,
-                                    cb.raw_c, c->range_dev, s, nbr ? tprime : nullptr, nbr ? tprime_scale(tprime, V) : nullptr, nc);
+                                    cb.raw_c, c->range_dev, s, nbr ? tprime : nullptr, nbr ? tprime_scale(tprime, V) : nullptr, nc,
+                                    tex_map);
     }
     const float* vd = vd_table;
     if (vd_sel != nullptr || vd_table != cb.vdc) {
@@ -878,6 +892,8 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     const bool compact = f->map_channels == TH_MAP_COMPACT || f->map_channels == TH_MAP_SPLIT;
     const int f_ld = frame_f_ld(f);
     const int fmt = mlp_row_format(c, V);
+    const bool tex = tex_rows(c, V, f->map_channels);
+    const float* tex_map = tex ? f->pixel_map_nhwc : nullptr;
     TH_REQUIRE(prepass == 1 || !compact || c->mlp.compact_ready,
                "compact pixel map needs th_mlp_weights.upsample_color (colour-folded layers) to be uploaded");
     uint8_t* mask = ar.take<uint8_t>((size_t)P);
@@ -958,7 +974,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         th_ctx::Prepass& t = c->prepass[slot];
         t.npre = 0;
         if (!can_pre || n <= 0) return 0;
-        const PoolPlan pl = pool_plan(c, V, f_ld, n, true);
+        const PoolPlan pl = pool_plan(c, V, f_ld, n, true, tex);
         TH_REQUIRE(pool != nullptr && pool_bytes >= pl.total, "shading pool too small (th_shade_pool_bytes)");
         const int m = (int)pl.pre_n;
         float* a_f = (float*)(pb + pl.a_f);
@@ -993,8 +1009,9 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
             }
             if (rc == 0) {
                 ProfScope ps2(pf, TH_PROF_GATHER, s);
-                rc = th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx, m, f->cams,
-                                         f->scale_xy, a_f, f_ld, fmt, s, c->range_dev);
+                rc = tex ? th_pixtex_launch(f->pixel_map_nhwc, V, f->H, f->W, &ps, idx, m, f->cams, f->scale_xy, a_f, s)
+                         : th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx, m, f->cams,
+                                               f->scale_xy, a_f, f_ld, fmt, s, c->range_dev);
             }
         }
         if (k4_side) {
@@ -1020,7 +1037,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         }
         t.npre = 0;
     }
-    const PoolPlan pl = pool_plan(c, V, f_ld, n, npre > 0);
+    const PoolPlan pl = pool_plan(c, V, f_ld, n, npre > 0, tex);
     TH_REQUIRE(n <= 0 || (pool != nullptr && pool_bytes >= pl.total), "shading pool too small (th_shade_pool_bytes)");
     TH_REQUIRE(npre == 0 || npre == pl.pre_n, "pre-gather stage and shading disagree on the pool layout");
     ChunkBufs cb{};
@@ -1043,7 +1060,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         pc.f = (float*)(pb + pl.a_f); pc.h = (float*)(pb + pl.a_h); pc.pe = (float*)(pb + pl.a_pe);
         {
             ProfScope ps3(pf, TH_PROF_MLP, s);
-            TH_TRY(mlp_dispatch(c, V, npre, pc, f_ld, vd_all, idx, S, unmasked, s, tprime, f->n_clusters));
+            TH_TRY(mlp_dispatch(c, V, npre, pc, f_ld, vd_all, idx, S, unmasked, s, tprime, f->n_clusters, tex_map));
         }
         ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, idx, npre, unmasked, raw, s));
@@ -1055,8 +1072,9 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         // last thing written before the fused kernel reads it at the start of every tile: MALL instead of HBM)
         {
             ProfScope ps2(pf, TH_PROF_GATHER, s);
-            TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, sel, m, f->cams,
-                                       f->scale_xy, cb.f, f_ld, fmt, s, c->range_dev));
+            if (tex) TH_TRY(th_pixtex_launch(f->pixel_map_nhwc, V, f->H, f->W, &ps, sel, m, f->cams, f->scale_xy, cb.f, s));
+            else TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, sel, m, f->cams,
+                                            f->scale_xy, cb.f, f_ld, fmt, s, c->range_dev));
         }
         {
             ProfScope ps1(pf, TH_PROF_DPARF, s);
@@ -1066,10 +1084,10 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         {
             ProfScope ps3(pf, TH_PROF_MLP, s);
             // ray mode: the [R,27] embedding table is indexed sample -> ray (sel / S); mesh mode: zero rows (cb.vdc)
-            if (ray_mode) TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, vd_all, sel, S, unmasked, s, tprime, f->n_clusters));
+            if (ray_mode) TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, vd_all, sel, S, unmasked, s, tprime, f->n_clusters, tex_map));
             // (the sigma grid never looks at colour: skip the RGB branch, which the reference evaluates and drops,
             // if_mesh_renderer.py:84-99)
-            else TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, cb.vdc, nullptr, 1, 2, s, tprime, f->n_clusters));
+            else TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, cb.vdc, nullptr, 1, 2, s, tprime, f->n_clusters, tex_map));
         }
         ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));
@@ -1087,9 +1105,10 @@ size_t th_render_workspace_bytes(const th_frame* f, int R, int S) {
 size_t th_shade_pool_bytes(th_ctx* c, const th_frame* f, long long n_valid, int with_pregather) {
     if (!c || !f || f->V < 1) return 0;
     const int f_ld = frame_f_ld(f);
-    size_t a = pool_plan(c, f->V, f_ld, n_valid, false).total;
+    const bool tex = tex_rows(c, f->V, f->map_channels);
+    size_t a = pool_plan(c, f->V, f_ld, n_valid, false, tex).total;
     if (with_pregather) {
-        const size_t b = pool_plan(c, f->V, f_ld, n_valid, true).total;
+        const size_t b = pool_plan(c, f->V, f_ld, n_valid, true, tex).total;
         if (b > a) a = b;
     }
     return a;

@@ -259,6 +259,11 @@ struct FusedParams {
     const _Float16* pe;     // [P][2][64]
     // split-f16 rows written by K5 (TH_ROWS_SPLIT): K / 8 groups of [8 hi | 8 lo] halves per (sample, view)
     const _Float16* f;  // [P][V][2][384] (full) or [P][V][2][272] (compact: 256 latent | r g b | 0...)
+    // TH_ROWS_TEX (k_pixtex.hip): instead of f, per tile the list of distinct corner texels and per (sample, view) four row
+    // numbers + bilinear weights + the blended colour; the kernel blends the rows of tex_map (TH_MAP_SPLIT latents) itself
+    const unsigned* tex_hdr;   // [tiles][4][128]
+    const unsigned* tex_rec;   // [tiles][V][32][8]
+    const float* tex_map;      // [V][H*W][256]
     const float* vd;    // view-direction rows [.][27]: row of compacted sample p = vd_sel ? vd_sel[p] / vd_div : p
     const int32_t* vd_sel;
     int vd_div;
@@ -282,7 +287,12 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all,
                          float* raw_c, unsigned int* range, hipStream_t s, const void* tsplit = nullptr,
-                         const float* t_inv = nullptr, int t_nc = 0);
+                         const float* t_inv = nullptr, int t_nc = 0, const float* tex_map = nullptr);
+// K5t (k_pixtex.hip): texel lists + records for P samples into `out` (th_pixtex_bytes); with tex_map != nullptr
+// th_mlp_fused_forward reads `f` as that block instead of rows
+size_t th_pixtex_bytes(int V, long long P);
+int th_pixtex_launch(const float* map, int V, int H, int W, const ThPointSrc* ps, const int32_t* sel, int P, const float* cams,
+                     const float* scale, void* out, hipStream_t s);
 // In place: the per-frame table T' [rows][256] fp32 -> [rows][256 hi | 256 lo] fp16 halves of T' * 2^k, k chosen on the
 // device so that max |T'| lands in [2^12, 2^13) (lo halves stay normal numbers); sc[0] = 2^-k, sc[1] scratch (the
 // maximum's bits).  A non-finite table raises the guard's TH_RANGE_VIT slot (its producer is the ViT).
@@ -295,6 +305,7 @@ struct th_ctx {
     int mlp_mode = 1;                 // 1: fused fp16x3-split MFMA kernel, 0: layer-by-layer fp32 MFMA
     int vit_mode = 1;                 // 1: TransHE dense layers on the fp16-split MFMA path (th_gemm_h3), 0: fp32 MFMA
     int tok_gather = 1;               // 1: TH_ROWS_NBR hand-over (token blend inside the fused kernel), 0: TH_ROWS_FOLDED
+    int tex_rows = 1;                 // 1: TH_ROWS_TEX hand-over of the pixel features (texel lists, blend inside the fused kernel)
     int device = 0;
     void* mlp_store = nullptr;
     void* vit_store = nullptr;

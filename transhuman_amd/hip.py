@@ -70,6 +70,7 @@ SYMBOLS = {
     "th_set_mlp_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_vit_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_tok_gather": (C.c_int, [C.c_void_p, C.c_int]),
+    "th_set_tex_rows": (C.c_int, [C.c_void_p, C.c_int]),
     "th_range_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_range_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "th_range_last_slot": (C.c_int, [C.c_void_p]),
@@ -186,7 +187,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 6:
+    if lib.th_abi_version() != 7:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -1199,6 +1200,13 @@ def set_tok_gather(on, device=None):
     rows of the per-frame token table on the matrix pipe; False = K4 blends them in fp32 (3.3 KB per sample through HBM;
     a ray shard then equals the whole frame bit for bit instead of to fp32 rounding)."""
     _check(load_library().th_set_tok_gather(ctx(device), 1 if on else 0))
+
+
+def set_tex_rows(on, device=None):
+    """Pixel-feature hand-over K5 -> K6 on the fused path (split map): True (default) = texel lists per tile, the fused kernel
+    copies the distinct texels into LDS and blends them itself (same operand bits, 160 B instead of 3.3 KB per sample through
+    HBM); False = K5 writes the rows.  The shading pool is sized per mode (cached pools are re-made on demand)."""
+    _check(load_library().th_set_tex_rows(ctx(device), 1 if on else 0))
 
 
 def set_mlp_mode(mode, device=None):
