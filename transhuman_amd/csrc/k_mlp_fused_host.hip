@@ -357,10 +357,11 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     p.tsplit = (const _Float16*)tsplit; p.t_inv = t_inv; p.t_nc = t_nc;
     const bool tex = tex_map != nullptr;
     TH_REQUIRE(!tex || (cf && f != nullptr), "texel hand-over: compact (272-wide) operand planes only");
-    p.tex_hdr = nullptr; p.tex_rec = nullptr; p.tex_map = nullptr;
+    p.tex_hdr = nullptr; p.tex_rec = nullptr; p.tex_col = nullptr; p.tex_map = nullptr;
     if (tex) {          // `f` is K5t's block: tile headers, then the per-row records (th_pixtex_launch)
         p.tex_hdr = (const unsigned*)f;
         p.tex_rec = p.tex_hdr + (size_t)th_cdiv(P, FM_PTS) * 512;
+        p.tex_col = p.tex_rec + (size_t)th_cdiv(P, FM_PTS) * V * 32 * 8;
         p.tex_map = tex_map;
         f = nullptr;
     }

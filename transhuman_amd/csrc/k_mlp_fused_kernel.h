@@ -657,10 +657,14 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         const unsigned* hb = P.tex_hdr + (long long)tl * 512;
         unsigned h0 = pre.h0, h1 = pre.h1;
         const int npass = __builtin_amdgcn_readfirstlane((int)(h0 >> 16));
-        // the tile's row records ({rows, w00, w01, w10} {w11, r, g, b} per operand row, 32 V rows) go to LDS (MISC: free here)
+        // the tile's row records ({w00, w01, w10, w11} {byte offsets of the four corner rows} per operand row, 32 V rows) go to
+        // LDS (MISC: free here)
         char* recl = reinterpret_cast<char*>(misc);
         static_assert(32 * V * 32 <= (9 * 32 + 4 * 32 * 4) * 4, "row records must fit probs + part");
         unsigned fh[NR][2] = {}, fl[NR][2] = {};     // operand row wv + 4 k: hi / lo halves of channels 4 lane .. 4 lane + 3
+        // lane k < 8 V: the blended colour {r g b 0} of operand row wv + 4 k (requested in front of the texel rows, used last)
+        fm_u4 qc = {0u, 0u, 0u, 0u};
+        if (lane < NR) qc = *reinterpret_cast<const fm_u4*>(P.tex_col + ((long long)tl * V * 32 + wv + 4 * lane) * 4);
         for (int p = 0; p < npass; ++p) {
             if (p > 0) {
                 FM_SYNCL();                                  // the previous pass's rows have been read
@@ -669,28 +673,37 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             }
             const int U = __builtin_amdgcn_readfirstlane((int)(h0 & 0xffffu));
             {
-                // rows wv, wv + 4, ... of the list: the first 14 of a wave always (indices past the end clamped: the last
-                // row again, same bytes to the same place), the other 12 only for lists longer than 56 -- so that the header
-                // word of a request (8 + row) is always in h0 for the first group and always in h1 for the second (no
-                // branch between the loads).  Addresses are a scalar base + a 32-bit lane offset (map < 4 GiB: launcher).
-                constexpr int NA = 14;
+                // rows wv, wv + 4, ... of the list in three groups: the first 14 of a wave always (indices past the end clamped:
+                // the last row again, same bytes to the same place), 6 more for lists longer than 56, the last 6 for lists longer
+                // than 80 -- the header word of a request (8 + row) is then always in h0 for the first group and always in h1
+                // for the others (no branch between the loads of a group; the average list of 79 rows has no clamped request).
+                // Addresses are a scalar base + a 32-bit lane offset (map < 4 GiB: launcher).
+                constexpr int NA = 14, NB = 20;
                 const char* mbase = reinterpret_cast<const char*>(P.tex_map);
                 const unsigned loff = (unsigned)lane * 16u;
                 const int last = U - 1;
-                fm_u4 ta[NA], tb[NK - NA];
+                fm_u4 ta[NA], tb[NB - NA], tc[NK - NB];
 #pragma unroll
                 for (int k = 0; k < NA; ++k) {
                     const int i = min(wv + 4 * k, last);
                     const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)h0, 8 + i);
                     ta[k] = *reinterpret_cast<const fm_u4*>(mbase + (size_t)((id << 10) + loff));
                 }
-                const bool more = U > 4 * NA;
+                const bool more = U > 4 * NA, most = U > 4 * NB;
                 if (more) {
 #pragma unroll
-                    for (int k = NA; k < NK; ++k) {
+                    for (int k = NA; k < NB; ++k) {
                         const int i = min(wv + 4 * k, last);
                         const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)h1, i - 56);
                         tb[k - NA] = *reinterpret_cast<const fm_u4*>(mbase + (size_t)((id << 10) + loff));
+                    }
+                }
+                if (most) {
+#pragma unroll
+                    for (int k = NB; k < NK; ++k) {
+                        const int i = min(wv + 4 * k, last);
+                        const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)h1, i - 56);
+                        tc[k - NB] = *reinterpret_cast<const fm_u4*>(mbase + (size_t)((id << 10) + loff));
                     }
                 }
                 if (p == 0) {
@@ -703,35 +716,38 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 for (int k = 0; k < NA; ++k) *reinterpret_cast<fm_u4*>(abuf + min(wv2 + 4 * k, last) * TSTR + lane * 16) = ta[k];
                 if (more) {
 #pragma unroll
-                    for (int k = NA; k < NK; ++k) *reinterpret_cast<fm_u4*>(abuf + min(wv2 + 4 * k, last) * TSTR + lane * 16) = tb[k - NA];
+                    for (int k = NA; k < NB; ++k) *reinterpret_cast<fm_u4*>(abuf + min(wv2 + 4 * k, last) * TSTR + lane * 16) = tb[k - NA];
+                }
+                if (most) {
+#pragma unroll
+                    for (int k = NB; k < NK; ++k) *reinterpret_cast<fm_u4*>(abuf + min(wv2 + 4 * k, last) * TSTR + lane * 16) = tc[k - NB];
                 }
             }
             FM_SYNCL();                                      // the texel rows (and the records) are in place
-            // One operand row per step and wave, software-pipelined by hand: the reads of row k + 1 (its record: the same address
-            // in every lane, a broadcast; its four corner rows) are issued before row k is blended -- written row by row the
-            // compiler waits for every row's record, then for its corners: two exposed LDS round trips per row, 8.7 k cycles.
+            // One operand row per step and wave, software-pipelined by hand: the reads of row k + 1, then the corner offsets of
+            // row k + 2 (its weights: the same address in every lane, a broadcast; its four corner rows) are issued before row k
+            // is blended -- written row by row the compiler waits for every row's record, then for its corners: two exposed LDS
+            // round trips per row, 8.7 k cycles.  With one wave per SIMD every instruction costs the wave an issue slot
+            // (4 cycles): the loop is bound by its instruction count, so the producer stores byte offsets, not row numbers.
             // Operand row wv + 4 k is sample wv + 4 (k & 7): its pass is (k & 7) >> (sh - 2), known per k.
             const int sh2 = npass == 1 ? 3 : npass == 2 ? 2 : 1;
             const int cofs = lane * 16;
-            unsigned rwv[NR];                                // the `rows` words of this wave's operand rows
-#pragma unroll
-            for (int k = 0; k < NR; ++k) rwv[k] = *reinterpret_cast<const unsigned*>(recl + (wv + 4 * k) * 32);
-            struct RowIn { float4 a, b, c, d; fm_u4 q0, q1; };
-            auto issue = [&](int k, RowIn& r) __attribute__((always_inline)) {
-                const unsigned rw = (unsigned)__builtin_amdgcn_readfirstlane((int)rwv[k]);
-                const char* rc = recl + (wv + 4 * k) * 32;
-                r.q0 = *reinterpret_cast<const fm_u4*>(rc);
-                r.q1 = *reinterpret_cast<const fm_u4*>(rc + 16);
-                r.a = *reinterpret_cast<const float4*>(abuf + ((rw & 0xffu) * TSTR + cofs));
-                r.b = *reinterpret_cast<const float4*>(abuf + (((rw >> 8) & 0xffu) * TSTR + cofs));
-                r.c = *reinterpret_cast<const float4*>(abuf + (((rw >> 16) & 0xffu) * TSTR + cofs));
-                r.d = *reinterpret_cast<const float4*>(abuf + ((rw >> 24) * TSTR + cofs));
+            struct RowIn { float4 a, b, c, d; fm_u4 q0; };
+            auto issue = [&](int k, const fm_u4& o, RowIn& r) __attribute__((always_inline)) {
+                r.q0 = *reinterpret_cast<const fm_u4*>(recl + (wv + 4 * k) * 32);     // the four weights: one broadcast read
+                r.a = *reinterpret_cast<const float4*>(abuf + (o[0] + cofs));
+                r.b = *reinterpret_cast<const float4*>(abuf + (o[1] + cofs));
+                r.c = *reinterpret_cast<const float4*>(abuf + (o[2] + cofs));
+                r.d = *reinterpret_cast<const float4*>(abuf + (o[3] + cofs));
+            };
+            auto offs = [&](int k) __attribute__((always_inline)) {                   // (a broadcast read as well)
+                return *reinterpret_cast<const fm_u4*>(recl + (wv + 4 * k) * 32 + 16);
             };
             auto blend = [&](int k, const RowIn& r, auto sel) __attribute__((always_inline)) {
                 // (plain copies first: __builtin_bit_cast applied to a vector COMPONENT reads component 0)
-                const unsigned u01 = r.q0[1], u02 = r.q0[2], u03 = r.q0[3], u10 = r.q1[0];
-                const float w00 = __builtin_bit_cast(float, u01), w01 = __builtin_bit_cast(float, u02),
-                            w10 = __builtin_bit_cast(float, u03), w11 = __builtin_bit_cast(float, u10);
+                const unsigned u0 = r.q0[0], u1 = r.q0[1], u2 = r.q0[2], u3 = r.q0[3];
+                const float w00 = __builtin_bit_cast(float, u0), w01 = __builtin_bit_cast(float, u1),
+                            w10 = __builtin_bit_cast(float, u2), w11 = __builtin_bit_cast(float, u3);
                 // (pg_blend2 of k_pixfeat.hip: a w00, then fused multiply-adds in the order ne, sw, se)
                 const f32x2 W00 = {w00, w00}, W01 = {w01, w01}, W10 = {w10, w10}, W11 = {w11, w11};
                 f32x2 lo = (f32x2){r.a.x, r.a.y} * W00, hi = (f32x2){r.a.z, r.a.w} * W00;
@@ -753,11 +769,15 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 }
             };
             auto rows_loop = [&](auto sel) __attribute__((always_inline)) {
-                RowIn in[2];
-                issue(0, in[0]);
+                RowIn in[2];                                 // the reads of row k + 1 in flight under the blend of row k
+                fm_u4 of[2];                                 // (a second row of look-ahead changes nothing: issue-bound)
+                of[0] = offs(0);
+                of[1] = offs(1);
+                issue(0, of[0], in[0]);
 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
-                    if (k + 1 < NR) issue(k + 1, in[(k + 1) & 1]);
+                    if (k + 1 < NR) issue(k + 1, of[(k + 1) & 1], in[(k + 1) & 1]);
+                    if (k + 2 < NR) of[k & 1] = offs(k + 2);
                     FM_SB();
                     blend(k, in[k & 1], sel);
                     FM_SB();
@@ -771,9 +791,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             range_acc<false>(rmax, fh[k][0]);
             range_acc<false>(rmax, fh[k][1]);
         }
-        // lane k < 8 V: the blended colour of operand row wv + 4 k (the record is still in MISC)
-        fm_u4 qc = {0u, 0u, 0u, 0u};
-        if (lane < NR) qc = *reinterpret_cast<const fm_u4*>(recl + (wv + 4 * lane) * 32 + 16);
+
         FM_SYNCL();                                          // every wave is done reading texel rows: ABUF takes the planes
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
@@ -784,7 +802,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         // colour tail: channels 256..258 = the blended r g b, 259..271 = 0
         if (lane < NR) {
             const int row = wv + 4 * lane;
-            const unsigned ur = qc[1], ug = qc[2], ub = qc[3];
+            const unsigned ur = qc[0], ug = qc[1], ub = qc[2];
             uint4 th = make_uint4(0u, 0u, 0u, 0u), tl4 = make_uint4(0u, 0u, 0u, 0u);
             split_pair(__builtin_bit_cast(float, ur), __builtin_bit_cast(float, ug), th.x, tl4.x);
             split_pair(__builtin_bit_cast(float, ub), 0.f, th.y, tl4.y);

@@ -13,8 +13,9 @@
 // Output (per launch of P samples, T = ceil(P / 32) tiles):
 //   hdr  [T][4 passes][128 words]   word 0 = U | npass << 16 (U = texel rows of this pass, npass = 1, 2 or 4),
 //                                   words 8 .. 8 + U - 1 = global texel index (view * H * W + y * W + x) of row 0 .. U - 1
-//   rec  [T][V][32 samples][8 words] {rows (4 bytes: nw ne sw se), w00, w01, w10, w11, r, g, b}  (r g b: the blended colour
-//                                   texels, channels 256..258 of the row, fp32)
+//   rec  [T][V][32 samples][8 words] {w00, w01, w10, w11} {byte offsets of the nw, ne, sw, se texel rows in the fused kernel's
+//                                   row buffer: row number x 1040}
+//   col  [T][V][32 samples][4 words] {r, g, b, 0}: the blended colour texels (channels 256..258 of the row), fp32
 // A pass holds at most TX_CAP rows (what the fused kernel's operand buffer takes).  5.8 % of the headline frame's tiles need
 // more: their samples are split into halves (2 passes) or quarters (4 passes: 8 samples x 4 corners x 3 views = 96 rows
 // always fit), each with its own row list; sample s belongs to pass s / (32 / npass).
@@ -24,6 +25,7 @@
 #define TX_CAP 103
 #define TX_HDR_WORDS 512
 #define TX_MAXV 3
+#define TX_ROW_STRIDE 1040     // bytes per texel row in the fused kernel's row buffer (fill_tex: TSTR)
 
 // distinct texels of corner registers c[0..3] over the lanes of `M` (a mask over the 32 samples): slot[k] = number of the
 // texel of corner k in order of first appearance, starting at `base`; the texel of row `base + u` is left in lane
@@ -58,7 +60,7 @@ template <int V>
 __global__ __launch_bounds__(256) void pixtex_kernel(const float* __restrict__ map, int H, int W, ThPointSrc ps,
                                                      const int32_t* __restrict__ sel, int P, const float* __restrict__ cams,
                                                      const float* __restrict__ scale, unsigned* __restrict__ hdr,
-                                                     unsigned* __restrict__ rec, int cap) {
+                                                     unsigned* __restrict__ rec, unsigned* __restrict__ col, int cap) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pbase = tile * 32;
@@ -88,11 +90,10 @@ __global__ __launch_bounds__(256) void pixtex_kernel(const float* __restrict__ m
             const float bl = fmaf(d.z, b.w11, fmaf(cc.z, b.w10, fmaf(bb.z, b.w01, a.z * b.w00)));
             if (lane < 32) {
                 unsigned* o = rec + ((long long)(tile * V + v) * 32 + smp) * 8;
-                *reinterpret_cast<uint4*>(o + 4) = make_uint4(__builtin_bit_cast(unsigned, b.w11), __builtin_bit_cast(unsigned, r),
-                                                              __builtin_bit_cast(unsigned, g), __builtin_bit_cast(unsigned, bl));
-                o[1] = __builtin_bit_cast(unsigned, b.w00);
-                o[2] = __builtin_bit_cast(unsigned, b.w01);
-                o[3] = __builtin_bit_cast(unsigned, b.w10);
+                *reinterpret_cast<uint4*>(o) = make_uint4(__builtin_bit_cast(unsigned, b.w00), __builtin_bit_cast(unsigned, b.w01),
+                                                          __builtin_bit_cast(unsigned, b.w10), __builtin_bit_cast(unsigned, b.w11));
+                *reinterpret_cast<uint4*>(col + ((long long)(tile * V + v) * 32 + smp) * 4) =
+                    make_uint4(__builtin_bit_cast(unsigned, r), __builtin_bit_cast(unsigned, g), __builtin_bit_cast(unsigned, bl), 0u);
             }
         }
     }
@@ -105,13 +106,14 @@ __global__ __launch_bounds__(256) void pixtex_kernel(const float* __restrict__ m
             const unsigned M = per == 32 ? 0xffffffffu : (((1u << per) - 1u) << (p * per));
             const bool inM = ((M >> smp) & 1u) != 0u;
             unsigned ir0 = 0u, ir1 = 0u;
-            int rows[V];
+            int rows[V][4];
             int U = 0;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 int slot[4] = {0, 0, 0, 0};
                 U += tx_dedup(cid[v], M, inM, U, v * HW, lane, slot, ir0, ir1);
-                rows[v] = slot[0] | (slot[1] << 8) | (slot[2] << 16) | (slot[3] << 24);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) rows[v][j] = slot[j] * TX_ROW_STRIDE;
                 if (U > cap && np < 4) break;
             }
             if (U > cap && np < 4) { ok = false; break; }
@@ -120,7 +122,9 @@ __global__ __launch_bounds__(256) void pixtex_kernel(const float* __restrict__ m
             hb[p * 128 + 64 + lane] = ir1;
             if (inM && lane < 32) {
 #pragma unroll
-                for (int v = 0; v < V; ++v) rec[((long long)(tile * V + v) * 32 + smp) * 8] = (unsigned)rows[v];
+                for (int v = 0; v < V; ++v)
+                    *reinterpret_cast<uint4*>(rec + ((long long)(tile * V + v) * 32 + smp) * 8 + 4) =
+                        make_uint4((unsigned)rows[v][0], (unsigned)rows[v][1], (unsigned)rows[v][2], (unsigned)rows[v][3]);
             }
         }
         if (ok) break;
@@ -129,10 +133,10 @@ __global__ __launch_bounds__(256) void pixtex_kernel(const float* __restrict__ m
 
 size_t th_pixtex_bytes(int V, long long P) {
     const long long T = (P + 31) / 32;
-    return (size_t)T * TX_HDR_WORDS * 4 + (size_t)T * V * 32 * 8 * 4;
+    return (size_t)T * TX_HDR_WORDS * 4 + (size_t)T * V * 32 * (8 + 4) * 4;
 }
 
-// hdr = out, rec = out + T * TX_HDR_WORDS (words); map: TH_MAP_SPLIT ([V][H*W][256] latents, then [V][H*W][4] colours)
+// hdr = out, rec = hdr + T * TX_HDR_WORDS (words), col = rec + T * V * 256; map: TH_MAP_SPLIT ([V][H*W][256] latents, then [V][H*W][4] colours)
 int th_pixtex_launch(const float* map, int V, int H, int W, const ThPointSrc* ps, const int32_t* sel, int P, const float* cams,
                      const float* scale, void* out, hipStream_t s) {
     if (P <= 0) return 0;
@@ -140,6 +144,7 @@ int th_pixtex_launch(const float* map, int V, int H, int W, const ThPointSrc* ps
     const int T = th_cdiv(P, 32);
     unsigned* hdr = reinterpret_cast<unsigned*>(out);
     unsigned* rec = hdr + (size_t)T * TX_HDR_WORDS;
+    unsigned* col = rec + (size_t)T * V * 32 * 8;
     const dim3 grid(th_cdiv(T, 4)), block(256);
     // developer / test switch: a smaller row budget per pass sends more tiles down the 2- and 4-pass forms (same results)
     // (read per launch: a test flips it between two renders of one process)
@@ -147,9 +152,9 @@ int th_pixtex_launch(const float* map, int V, int H, int W, const ThPointSrc* ps
     const int cv = e ? atoi(e) : TX_CAP;
     const int cap = cv >= 8 && cv <= TX_CAP ? cv : TX_CAP;
     switch (V) {
-        case 1: hipLaunchKernelGGL(pixtex_kernel<1>, grid, block, 0, s, map, H, W, *ps, sel, P, cams, scale, hdr, rec, cap); break;
-        case 2: hipLaunchKernelGGL(pixtex_kernel<2>, grid, block, 0, s, map, H, W, *ps, sel, P, cams, scale, hdr, rec, cap); break;
-        default: hipLaunchKernelGGL(pixtex_kernel<3>, grid, block, 0, s, map, H, W, *ps, sel, P, cams, scale, hdr, rec, cap); break;
+        case 1: hipLaunchKernelGGL(pixtex_kernel<1>, grid, block, 0, s, map, H, W, *ps, sel, P, cams, scale, hdr, rec, col, cap); break;
+        case 2: hipLaunchKernelGGL(pixtex_kernel<2>, grid, block, 0, s, map, H, W, *ps, sel, P, cams, scale, hdr, rec, col, cap); break;
+        default: hipLaunchKernelGGL(pixtex_kernel<3>, grid, block, 0, s, map, H, W, *ps, sel, P, cams, scale, hdr, rec, col, cap); break;
     }
     TH_LAUNCH_CHECK();
     return 0;

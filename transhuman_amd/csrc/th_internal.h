@@ -262,7 +262,8 @@ struct FusedParams {
     // TH_ROWS_TEX (k_pixtex.hip): instead of f, per tile the list of distinct corner texels and per (sample, view) four row
     // numbers + bilinear weights + the blended colour; the kernel blends the rows of tex_map (TH_MAP_SPLIT latents) itself
     const unsigned* tex_hdr;   // [tiles][4][128]
-    const unsigned* tex_rec;   // [tiles][V][32][8]
+    const unsigned* tex_rec;   // [tiles][V][32][8]  {w00 w01 w10 w11} {byte offsets of the four corner rows}
+    const unsigned* tex_col;   // [tiles][V][32][4]  {r g b 0}
     const float* tex_map;      // [V][H*W][256]
     const float* vd;    // view-direction rows [.][27]: row of compacted sample p = vd_sel ? vd_sel[p] / vd_div : p
     const int32_t* vd_sel;
