@@ -167,6 +167,7 @@ __device__ __forceinline__ void th_get_point(const ThPointSrc& ps, long long i, 
 struct Bilin {
     int i00, i01, i10, i11;     // linear y*W+x of nw, ne, sw, se (clamped)
     float w00, w01, w10, w11;   // weights (0 where the corner is out of range)
+    int x0, y0, x1, y1;         // the clamped texel coordinates behind the indices
 };
 
 // uv -> corner indices/weights exactly as torch's grid_sampler_2d does for
@@ -190,6 +191,7 @@ __device__ __forceinline__ Bilin th_bilinear_setup(float u, float v, float sx, f
     if (!bx1) { b.w01 = 0.f; b.w11 = 0.f; xi1 = W - 1; }
     if (!by1) { b.w10 = 0.f; b.w11 = 0.f; yi1 = H - 1; }
     b.i00 = yi0 * W + xi0; b.i01 = yi0 * W + xi1; b.i10 = yi1 * W + xi0; b.i11 = yi1 * W + xi1;
+    b.x0 = xi0; b.y0 = yi0; b.x1 = xi1; b.y1 = yi1;
     return b;
 }
 
