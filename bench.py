@@ -89,7 +89,10 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
     of its 2.5 PFLOP/s dense peak; mode 0: fp32 MFMA GEMM launches, peak 157.3 TFLOP/s."""
     if mlp_mode == 1:
         peak = MFMA_F16_PEAK / 3.0
-        kernel = "mlp_fused_kernel<3,1> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0"
+        from transhuman_amd import hip as _hip
+        kernel = ("mlp_fused_kernel<3,1,true> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16; TH_ROWS_TEX: the pixel-feature operand "
+                  "is blended inside the kernel from texels of the map), rank 0" if _hip.tex_rows_enabled() else
+                  "mlp_fused_kernel<3,1> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0")
     else:
         peak = MFMA_F32_PEAK
         kernel = "per-point MLP stage (gemm_f32_mfma_kernel x14 + glue kernels), rank 0"
@@ -111,14 +114,35 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
             "traffic_per_frame": ({"measured_K4_K5_K6_bytes": (t["mlp_fused_bytes_per_launch"] + t["pixgather_bytes_per_launch"] +
                                                                t["dparf_bytes_per_launch"]) * float(n_valid) / t["launch_samples"],
                                    "survey_8d_algorithmic_bytes": 1.22e9,
+                                   "gather_kernel": t.get("gather_kernel", "pixgather_s256_kernel"),
                                    "note": "PMC bytes per sample x this frame's valid samples against SURVEY 8d's "
-                                           "unique-footprint figure; the gap is the K5 -> HBM -> K6 row round trip (rows "
-                                           "written once, read twice)"} if t else None),
+                                           "unique-footprint figure.  With K5's rows (TH_ROWS_TEX=0) the gap was the K5 -> HBM -> "
+                                           "K6 row round trip (rows written once, read twice: 26 GB per frame); with the texel "
+                                           "hand-over what is left above the footprint are texel rows that miss L2 when a tile "
+                                           "of the fused kernel copies them (twice per tile) and the token-branch records"} if t else None),
             "algorithmic_flop_per_step": flops_step, "kernel_ms_per_step": stage_ms,
             "launches_per_step": launches,
             # what the matrix pipes really did (after the algebraic folds): executed FLOPs / time / peak
             "executed_flop_per_step": executed_step,
             "frac_executed": (executed_step / max(stage_ms * 1e-3, 1e-12) / peak) if (executed_step and mlp_mode == 1) else None}
+
+
+def texel_handover_block(V, n_valid, gather_ms):
+    """TH_ROWS_TEX (default on the fused path, split map): the producer of the pixel branch is K5t (k_pixtex.hip) -- it writes, per
+    32-sample tile, the list of distinct corner texels and per (sample, view) a 32-byte record + 16 bytes of colour; the rows
+    themselves are formed inside the fused kernel (fill_tex) from texels of the map and never reach HBM."""
+    tiles = (n_valid + 31) // 32
+    t = hbm_traffic()
+    hbm = (t["pixgather_bytes_per_launch"] * n_valid / t["launch_samples"]) if t and "pixtex" in t.get("gather_kernel", "") else None
+    return {"kernel": f"pixtex_kernel<{V}> (K5t: per-tile texel lists + per-row records; the rows are blended inside the fused kernel)",
+            "ms_per_step": gather_ms,
+            "bytes_written_per_step": float(n_valid) * V * 48 + tiles * 512.0,
+            "bytes_per_sample": V * 48 + 16,
+            "hbm_bytes_per_step_pmc": hbm,
+            "row_handover": "TH_ROWS_TEX",
+            "replaces": "pixgather_s256_kernel (K5): 3 x 1088 B per sample written to HBM and read back twice; TH_ROWS_TEX=0 "
+                        "switches back (then this block reports K5 against its texture-path ceiling)",
+            "note": "runs beside K4 (neighbour records) on a second stream"}
 
 
 def gather_block(V, n_valid, gather_ms, n_cu=256, clock_hz=2.4e9):
@@ -641,7 +665,7 @@ def main():
             },
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
                                        mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos), n_valid=n_valid),
-            "gather": gather_block(V, n_valid, prof["gather"][0] / max(args.steps, 1)),
+            "gather": (texel_handover_block if hip.tex_rows_enabled(dev) else gather_block)(V, n_valid, prof["gather"][0] / max(args.steps, 1)),
             # what the range guard of the fp16 hi/lo split has switched on this device (every entry false = the fast paths
             # ran; a tripped MLP guard means per-layer fp32 launches, ~7x slower frames) + the last table read (fp16 bit
             # patterns of max |x| per split tensor: f, s, p, n, inter, fc4_in; fp32 bits: conv_in; fp16: vit_in)

@@ -49,12 +49,28 @@ def main():
             ch = int(json.loads(line)["config"]["valid_samples_rank0"])
         except (OSError, IndexError, KeyError, ValueError):
             pass
+        tex = of("pixtex_kernel") is not None            # TH_ROWS_TEX: K5t instead of K5, no pixel-feature rows through HBM
+        hw = 512 * 512
+        try:
+            hw = int(json.loads(line)["config"]["rays"])
+        except (NameError, KeyError, ValueError):
+            pass
+        if tex:
+            alg = ch * (256 + 64 + V * 48) + ch // 32 * 1024 + V * hw * 1040
+            note = ("positional encoding 256 B, neighbour record 64 B, three 48-byte texel records per sample + a 512 B token header "
+                    "and a 512 B texel list per 32-sample tile + every texel of the map once (V x H x W x 1040 B: an upper bound, "
+                    "the map is cropped to the hull)")
+        else:
+            alg = ch * (V * 1088 + 256 + 64) + ch // 32 * 512
+            note = ("pixel-feature rows once (3 x 1088 B), positional encoding 256 B, neighbour record 64 B per sample + a 512 B "
+                    "header per 32-sample tile")
         print(json.dumps({"source": src, "launch_samples": ch,
-                          "mlp_fused_bytes_per_launch": of("mlp_fused"), "pixgather_bytes_per_launch": of("pixgather_s256") or of("pixgather_kernel<true>"),
+                          "mlp_fused_bytes_per_launch": of("mlp_fused"),
+                          "gather_kernel": "pixtex_kernel" if tex else "pixgather_s256_kernel",
+                          "pixgather_bytes_per_launch": of("pixtex_kernel") or of("pixgather_s256") or of("pixgather_kernel<true>"),
                           "dparf_bytes_per_launch": of("dparf_kernel"),
-                          "mlp_fused_algorithmic_bytes_per_launch": ch * (V * 1088 + 256 + 64) + ch // 32 * 512,
-                          "algorithmic_note": "pixel-feature rows once (3 x 1088 B), positional encoding 256 B, neighbour record "
-                                              "64 B per sample + a 512 B header per 32-sample tile"}, indent=1))
+                          "mlp_fused_algorithmic_bytes_per_launch": alg,
+                          "algorithmic_note": note}, indent=1))
         return
     for hbm, k, n, fk, wk in sorted(rows, reverse=True)[:16]:
         print(f"{k[:62]:62s} {n:8d} {fk:12.0f} {wk:12.0f} {hbm * 1024 / 1e9:13.3f}")

@@ -648,6 +648,15 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         if (tid < 64 * V) t.rq = *reinterpret_cast<const fm_u4*>(P.tex_rec + (long long)tl * V * 32 * 8 + tid * 4);
         return t;
     };
+    // timing builds only (wrong images): -DTX_EXP=1 every request reads texel 0 of the map (L1 / L2 hits: what the row
+    // requests cost without the memory system), -DTX_EXP=2 the texel of the first list entry (one row per tile)
+#if defined(TX_EXP) && TX_EXP == 1
+#define TX_ADDR(id) (size_t)(((id) & 0u) + loff)
+#elif defined(TX_EXP) && TX_EXP == 2
+#define TX_ADDR(id) (size_t)((((unsigned)__builtin_amdgcn_readlane((int)h0, 8) + ((id) & 0u)) << 10) + loff)
+#else
+#define TX_ADDR(id) (size_t)(((id) << 10) + loff)
+#endif
     auto fill_tex = [&](const TexPre& pre, auto&& under) __attribute__((always_inline)) {
         constexpr int TSTR = 1040, TMAX = 103, NK = (TMAX + 3) / 4, NR = 8 * V;
         static_assert(TMAX * TSTR <= ABUF_BYTES, "a pass of texel rows must fit the operand buffer");
@@ -687,7 +696,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 for (int k = 0; k < NA; ++k) {
                     const int i = min(wv + 4 * k, last);
                     const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)h0, 8 + i);
-                    ta[k] = *reinterpret_cast<const fm_u4*>(mbase + (size_t)((id << 10) + loff));
+                    ta[k] = *reinterpret_cast<const fm_u4*>(mbase + TX_ADDR(id));
                 }
                 const bool more = U > 4 * NA, most = U > 4 * NB;
                 if (more) {
@@ -695,7 +704,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                     for (int k = NA; k < NB; ++k) {
                         const int i = min(wv + 4 * k, last);
                         const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)h1, i - 56);
-                        tb[k - NA] = *reinterpret_cast<const fm_u4*>(mbase + (size_t)((id << 10) + loff));
+                        tb[k - NA] = *reinterpret_cast<const fm_u4*>(mbase + TX_ADDR(id));
                     }
                 }
                 if (most) {
@@ -703,7 +712,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                     for (int k = NB; k < NK; ++k) {
                         const int i = min(wv + 4 * k, last);
                         const unsigned id = (unsigned)__builtin_amdgcn_readlane((int)h1, i - 56);
-                        tc[k - NB] = *reinterpret_cast<const fm_u4*>(mbase + (size_t)((id << 10) + loff));
+                        tc[k - NB] = *reinterpret_cast<const fm_u4*>(mbase + TX_ADDR(id));
                     }
                 }
                 if (p == 0) {

@@ -1202,11 +1202,25 @@ def set_tok_gather(on, device=None):
     _check(load_library().th_set_tok_gather(ctx(device), 1 if on else 0))
 
 
+_tex_rows = {}                     # device index -> mode set through set_tex_rows (default: env TH_ROWS_TEX, else on)
+
+
+def tex_rows_enabled(device=None):
+    """Whether new frames of this device's context take the texel hand-over (include/transhuman_hip.h: th_set_tex_rows); it
+    applies to the fused path on frames with a split map (Renderer.prepare_frame's default)."""
+    if _tex_rows:                      # (only a set_tex_rows call needs the device: no CUDA call on a host without one)
+        d = _dev_index(device)
+        if d in _tex_rows:
+            return _tex_rows[d]
+    return os.environ.get("TH_ROWS_TEX", "1")[:1] != "0"
+
+
 def set_tex_rows(on, device=None):
     """Pixel-feature hand-over K5 -> K6 on the fused path (split map): True (default) = texel lists per tile, the fused kernel
     copies the distinct texels into LDS and blends them itself (same operand bits, 160 B instead of 3.3 KB per sample through
     HBM); False = K5 writes the rows.  The shading pool is sized per mode (cached pools are re-made on demand)."""
     _check(load_library().th_set_tex_rows(ctx(device), 1 if on else 0))
+    _tex_rows[_dev_index(device)] = bool(on)
 
 
 def set_mlp_mode(mode, device=None):
