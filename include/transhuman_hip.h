@@ -449,15 +449,15 @@ typedef struct {
  * Two caller-supplied buffers (ABI 6; one 25 GB worst-case workspace per frame in flight before):
  *  - `workspace` (th_render_workspace_bytes: ~25 B per SAMPLE of the ray list -- hull mask, sample list, dense raw, counts,
  *    view embeddings, the per-frame token table): one per frame in flight, it is what th_render_prepass writes;
- *  - `shade_pool` (th_shade_pool_bytes: ~3.6 KB per VALID sample on the fused path -- the pixel-feature rows K5 writes
- *    and K6 reads back (batchify_rays :607-656 / get_pixel_aligned_feature :210-269), the neighbour records and
- *    positional encodings of K4): ONE per context, shared by every workspace (the per-sample stage of a context runs
+ *  - `shade_pool` (th_shade_pool_bytes: ~0.5 KB per VALID sample on the fused path with the texel hand-over -- K5t's texel
+ *    lists and row records (get_pixel_aligned_feature :210-269), the neighbour records and positional encodings of K4;
+ *    ~3.6 KB with th_set_tex_rows(ctx, 0), when K5 writes the pixel-feature rows and K6 reads them back): ONE per context, shared by every workspace (the per-sample stage of a context runs
  *    on one stream at a time).  It is sized from the frame's valid-sample count, which th_render_prepass_wait puts on
  *    the host before the stage is queued; without a prepass size it for n_valid = R * S (then only the chunk buffers of
  *    th_set_chunk_samples samples are needed: the count bounds the chunk, not the pool). */
 size_t th_render_workspace_bytes(const th_frame* f, int R, int S);
-/* `f` needs V and map_channels; the result depends on the context's MLP / token-gather modes (ask again after
- * th_set_mlp_mode / th_set_tok_gather).  with_pregather = 1: large enough for th_render_pregather + th_render_rays. */
+/* `f` needs V, H, W and map_channels; the result depends on the context's MLP / token-gather / texel hand-over modes (ask
+ * again after th_set_mlp_mode / th_set_tok_gather / th_set_tex_rows).  with_pregather = 1: large enough for th_render_pregather + th_render_rays. */
 size_t th_shade_pool_bytes(th_ctx* ctx, const th_frame* f, long long n_valid, int with_pregather);
 int th_render_rays(th_ctx* ctx, const th_frame* f, const th_points* rays, float* rgb, float* acc,
                    float* depth, int white_bkgd, void* workspace, size_t workspace_bytes,

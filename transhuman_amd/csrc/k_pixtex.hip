@@ -207,7 +207,7 @@ size_t th_pixtex_bytes(int V, long long P) {
 int th_pixtex_launch(const float* map, int V, int H, int W, const ThPointSrc* ps, const int32_t* sel, int P, const float* cams,
                      const float* scale, void* out, hipStream_t s) {
     if (P <= 0) return 0;
-    TH_REQUIRE(V >= 1 && V <= TX_MAXV && (long long)V * H * W < (1LL << 31), "texel hand-over: 1..3 views, V*H*W < 2^31");
+    TH_REQUIRE(V >= 1 && V <= TX_MAXV && (long long)V * H * W < (1LL << 22), "texel hand-over: 1..3 views, V*H*W < 2^22 texels (4 GiB of map)");
     const int T = th_cdiv(P, 32);
     unsigned* hdr = reinterpret_cast<unsigned*>(out);
     unsigned* rec = hdr + (size_t)T * TX_HDR_WORDS;

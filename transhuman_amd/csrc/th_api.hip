@@ -690,8 +690,11 @@ static int dparf_row_format(const th_ctx* c, int V) {                           
 static size_t nbr_bytes(size_t m) { return (m + 32) * 16 * 4 + (m / 32 + 2) * 128 * 4; }
 // TH_ROWS_TEX: on the fused path a frame with a split map (TH_MAP_SPLIT) hands the fused kernel texel lists instead of
 // pixel-feature rows (k_pixtex.hip; th_set_tex_rows(ctx, 0) / TH_ROWS_TEX=0: K5's rows through HBM as before)
-static bool tex_rows(const th_ctx* c, int V, int map_channels) {
-    return mlp_is_fused(c, V) && c->tex_rows == 1 && map_channels == TH_MAP_SPLIT;
+// (the fused kernel addresses a texel row as a 32-bit byte offset into the map: V * H * W texels of 1 KiB must stay below 4 GiB --
+// three views of up to 1182 x 1182; larger maps keep K5's rows)
+static bool tex_rows(const th_ctx* c, const th_frame* f) {
+    return mlp_is_fused(c, f->V) && c->tex_rows == 1 && f->map_channels == TH_MAP_SPLIT &&
+           (long long)f->V * f->H * f->W < (1LL << 22);
 }
 
 // ---- the shading pool -------------------------------------------------------------------------------------------
@@ -892,7 +895,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     const bool compact = f->map_channels == TH_MAP_COMPACT || f->map_channels == TH_MAP_SPLIT;
     const int f_ld = frame_f_ld(f);
     const int fmt = mlp_row_format(c, V);
-    const bool tex = tex_rows(c, V, f->map_channels);
+    const bool tex = tex_rows(c, f);
     const float* tex_map = tex ? f->pixel_map_nhwc : nullptr;
     TH_REQUIRE(prepass == 1 || !compact || c->mlp.compact_ready,
                "compact pixel map needs th_mlp_weights.upsample_color (colour-folded layers) to be uploaded");
@@ -1105,7 +1108,7 @@ size_t th_render_workspace_bytes(const th_frame* f, int R, int S) {
 size_t th_shade_pool_bytes(th_ctx* c, const th_frame* f, long long n_valid, int with_pregather) {
     if (!c || !f || f->V < 1) return 0;
     const int f_ld = frame_f_ld(f);
-    const bool tex = tex_rows(c, f->V, f->map_channels);
+    const bool tex = tex_rows(c, f);
     size_t a = pool_plan(c, f->V, f_ld, n_valid, false, tex).total;
     if (with_pregather) {
         const size_t b = pool_plan(c, f->V, f_ld, n_valid, true, tex).total;
