@@ -312,6 +312,19 @@ int th_pixel_gather_split(th_ctx* ctx, const float* map_split, int V, int H, int
                           const int32_t* sel, int P, const float* cams, const float* scale_xy, void* out_rows,
                           int ldo, th_stream stream);
 
+/* K5t, the producer of the texel hand-over (th_set_tex_rows; k_pixtex.hip), on its own -- exposed for tests.  Samples are taken
+ * in tiles of 32 consecutive entries (of `sel`, or of the points when sel is NULL); out (th_pixel_texlist_bytes(V, P) bytes,
+ * T = ceil(P / 32) tiles) receives
+ *   lists   [T][4 passes][128] uint32: word 0 = U | npass << 16 (U <= 103 texel rows of this pass; npass = 1, 2 or 4: sample s of
+ *           the tile belongs to pass s / (32 / npass)), words 8 .. 8 + U - 1 = view * H * W + y * W + x of the pass's distinct
+ *           corner texels;
+ *   records [T][V][32][8]: {w00, w01, w10, w11} (float bits, grid_sample's bilinear weights, if_clight_renderer.py:210-269) and
+ *           {o00, o01, o10, o11} = 1040 * (number of the corner's texel in its pass's list);
+ *   colours [T][V][32][4]: the blended r g b of the sample (float bits), 0. */
+size_t th_pixel_texlist_bytes(int V, int P);
+int th_pixel_texlist(th_ctx* ctx, const float* map_split, int V, int H, int W, const float* pts_world, const int32_t* sel,
+                     int P, const float* cams, const float* scale_xy, void* out, size_t out_bytes, th_stream stream);
+
 /* ---- K6: per-point multi-view MLP ------------------------------------------ */
 /* Network.forward, cross_transformer.py:207-353, on already-gathered inputs.
  * pixel_feat [V,384,P] (the reference's channel-major layout); viewdir [P,27];

@@ -233,6 +233,80 @@ def test_split_row_gather_equals_fp32_gather(hip, gpu, net):
     assert torch.equal(hi, hi_g) and torch.equal(lo, lo_g)
 
 
+@pytest.mark.parametrize("cap", [None, 24])
+def test_texel_lists_rebuild_the_gathered_rows(hip, gpu, net, cap):
+    """K5t on its own (th_pixel_texlist): per 32-sample tile a list of DISTINCT corner texels (at most 103 per pass, 1 / 2 / 4
+    passes) and per (sample, view) four weights + four row offsets into its pass's list.  Rebuilding every row from the lists --
+    sum_c w_c * map[list[o_c / 1040]] -- must give the rows K5's fp32 kernel gathers (th_pixel_gather, golden-checked g9): to fp32
+    rounding for the latents (fused multiply-adds there, separate ones here), bit for bit for the colour tail (same term order).
+    On the frame's sample order, a ragged tail and points outside every image; cap = 24 (TH_TEX_CAP) forces 2- / 4-pass tiles."""
+    r = _renderer(net, 300)
+    b = synth.batch_to(synth.make_batch(128, 128, 3, seed=0, all_rays=True, focal=150.0), gpu)
+    frame = r.prepare_frame(b, crop_map=False)
+    pts = hip.Points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], n_samples=64)
+    mask, _ = hip.hull_mask(pts, b["tar_smpl_vertice"][0])
+    rr, ss = torch.nonzero(mask, as_tuple=True)
+    order = torch.argsort((rr // 16) * (64 * 16) + ss * 16 + (rr % 16))
+    rr, ss = rr[order], ss[order]
+    z = pts.near[rr] * pts.omt[ss] + pts.far[rr] * pts.t[ss]
+    world = pts.ray_o[rr] + pts.ray_d[rr] * z[:, None]
+    far_out = torch.randn(77, 3, device=gpu) * 5.0 + torch.tensor([0.0, 0.0, 3.0], device=gpu)      # mostly outside the images
+    world = torch.cat([world, far_out]).contiguous()
+    P, V = world.shape[0], 3
+    assert P > 20000 and P % 32 != 0
+    if cap is not None:
+        os.environ["TH_TEX_CAP"] = str(cap)
+    try:
+        t = hip.pixel_texlist(frame.map, world, frame.cams, frame.scale)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("TH_TEX_CAP", None)
+    lists, rec, col = t["lists"].long(), t["records"], t["colours"]
+    T = lists.shape[0]
+    U = lists[:, :, 0] & 0xffff                              # [T, 4]
+    npass = (lists[:, 0, 0] >> 16)                           # [T]
+    assert bool(((npass == 1) | (npass == 2) | (npass == 4)).all())
+    budget = 103 if cap is None else cap
+    for p_ in range(4):
+        live = npass > p_
+        assert bool((U[live, p_] >= 1).all()) and int(U[live, p_].max()) <= 103
+        # (a smaller budget only binds the 1- and 2-pass forms: quarters are taken whatever they need, at most 96)
+        assert bool((U[live & (npass < 4), p_] <= budget).all())
+    if cap is not None:
+        assert int((npass > 1).sum()) > T // 2
+    # distinct texels inside every pass
+    ids = lists[:, :, 8:8 + 103]                             # [T, 4, 103]
+    k = torch.arange(103, device=gpu)[None, None, :]
+    valid = (k < U[:, :, None]) & (torch.arange(4, device=gpu)[None, :, None] < npass[:, None, None])
+    srt = torch.where(valid, ids, torch.full_like(ids, -1)).sort(dim=2)[0]
+    dup = (srt[:, :, 1:] == srt[:, :, :-1]) & (srt[:, :, 1:] >= 0)
+    assert not bool(dup.any())
+    # rebuild the rows
+    H, W = frame.map.H, frame.map.W
+    lat = frame.map.interleaved()                            # [V, H, W, 260] fp32: 256 latents | r g b 0
+    lat = lat.reshape(V * H * W, 260)
+    smp = torch.arange(32, device=gpu)
+    pass_of = (smp[None, :] // (32 // npass[:, None]))       # [T, 32]
+    w = rec[:, :, :, 0:4].contiguous().view(torch.float32)   # [T, V, 32, 4]
+    off = rec[:, :, :, 4:8].long()
+    assert bool((off % 1040 == 0).all())
+    row = off // 1040
+    own_U = torch.gather(U, 1, pass_of)                      # [T, 32]
+    assert bool((row < own_U[:, None, :, None]).all())
+    tex = torch.gather(ids.reshape(T, 4 * 103), 1,
+                       (pass_of[:, None, :, None] * 103 + row).reshape(T, -1)).reshape(T, V, 32, 4)      # global texel index
+    view_of = tex // (H * W)
+    assert bool((view_of == torch.arange(V, device=gpu)[None, :, None, None]).all())
+    rows = (lat[tex.reshape(-1)].reshape(T, V, 32, 4, 260) * w[..., None]).sum(dim=3)                   # [T, V, 32, 260]
+    rows = rows.permute(0, 2, 1, 3).reshape(T * 32, V, 260)[:P]
+    ref = hip.pixel_gather(frame.map.interleaved(), world, frame.cams, frame.scale)                     # [P, V, 260] fp32
+    scale = ref.abs().amax().clamp(min=1.0)
+    assert float((rows[:, :, :256] - ref[:, :, :256]).abs().max()) < 4e-6 * float(scale)
+    # the colour tail is blended by K5t itself: K5's values
+    c = col.permute(0, 2, 1, 3).reshape(T * 32, V, 4)[:P]
+    assert torch.equal(c[:, :, :3], ref[:, :, 256:259]) and float(c[:, :, 3].abs().max()) == 0.0
+
+
 def test_stem_in_eval_mode_runs_the_hip_kernels(hip, gpu):
     """network.eval() (the reference's Trainer.val, trainer.py:131): BatchNorm normalises with its running statistics -- the
     ResNet stem still runs K12 / K11 (th_bn_act_eval: one launch per site) and equals torch's stock modules; the running

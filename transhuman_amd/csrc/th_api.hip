@@ -574,6 +574,17 @@ int th_pixel_gather_split(th_ctx* c, const float* map_split, int V, int H, int W
                                TH_ROWS_SPLIT, (hipStream_t)stream, nullptr);
 }
 
+size_t th_pixel_texlist_bytes(int V, int P) { return th_pixtex_bytes(V, P); }
+
+int th_pixel_texlist(th_ctx* c, const float* map_split, int V, int H, int W, const float* pts, const int32_t* sel, int P,
+                     const float* cams, const float* scale, void* out, size_t out_bytes, th_stream stream) {
+    TH_REQUIRE(c && map_split && pts && cams && scale && out, "null argument");
+    TH_REQUIRE(out_bytes >= th_pixtex_bytes(V, P), "output too small (th_pixel_texlist_bytes)");
+    ThPointSrc ps{};
+    ps.pts = pts;
+    return th_pixtex_launch(map_split, V, H, W, &ps, sel, P, cams, scale, out, (hipStream_t)stream);
+}
+
 int th_composite(th_ctx* c, const float* raw, const float* z, const th_points* rays, int white, float* rgb,
                  float* acc, float* depth, float* wout, th_stream stream) {
     TH_REQUIRE(c && raw && rays && rgb && acc && depth, "null argument");

@@ -71,6 +71,9 @@ SYMBOLS = {
     "th_set_vit_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_tok_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_tex_rows": (C.c_int, [C.c_void_p, C.c_int]),
+    "th_pixel_texlist_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "th_pixel_texlist": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "th_range_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_range_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint32)]),
     "th_range_last_slot": (C.c_int, [C.c_void_p]),
@@ -821,6 +824,24 @@ def pixel_gather_split(split_map, pts_world, cams, scale_xy, sel=None):
                                      _p(out), 272, _stream()))
     g = out.view(P, V, 34, 2, 8)
     return g[:, :, :, 0].reshape(P, V, 272), g[:, :, :, 1].reshape(P, V, 272)
+
+
+def pixel_texlist(split_map, pts_world, cams, scale_xy, sel=None):
+    """th_pixel_texlist: K5t on its own -> dict(lists [T,4,128] int32, records [T,V,32,8] int32 (float bits / byte offsets),
+    colours [T,V,32,4] float32), T = ceil(P / 32) tiles of 32 consecutive samples."""
+    lib = load_library()
+    assert isinstance(split_map, SplitMap)
+    V, H, W = split_map.V, split_map.H, split_map.W
+    p = _f32(pts_world).reshape(-1, 3)
+    P = p.shape[0] if sel is None else sel.numel()
+    T = (P + 31) // 32
+    nb = int(lib.th_pixel_texlist_bytes(V, P))
+    out = torch.zeros(nb // 4, dtype=torch.int32, device=p.device)
+    _check(lib.th_pixel_texlist(ctx(p.device), _p(split_map), V, H, W, _p(p), _p(sel), P, _p(cams), _p(scale_xy), _p(out), nb,
+                                _stream()))
+    a, b = T * 512, T * 512 + T * V * 32 * 8
+    return dict(lists=out[:a].view(T, 4, 128), records=out[a:b].view(T, V, 32, 8),
+                colours=out[b:b + T * V * 32 * 4].view(torch.float32).view(T, V, 32, 4))
 
 
 def network_forward(net, pixel_feat, viewdir, pts_smpl, centres, rot, tokens, mask=None):
