@@ -41,7 +41,8 @@ def _digest():
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
     for p in _sources() + headers + [os.path.join(INC, "transhuman_hip.h")]:
         h.update(open(p, "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    # (flags without the absolute -I paths: the same tree under another root -- the GPU box's snapshot -- is up to date)
+    h.update(" ".join(f for f in FLAGS if not f.startswith("-I")).encode())
     return h.hexdigest()
 
 
