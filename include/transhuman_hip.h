@@ -112,9 +112,10 @@ int th_set_tok_gather(th_ctx* ctx, int on);
  * if_clight_renderer.py:210-269, feeding alpha_res_0 / rgb_res_0 / rgb_res_1, cross_transformer.py:300-346), for frames
  * whose map is TH_MAP_SPLIT: 1 (default) = per 32-sample tile the list of DISTINCT corner texels of its V x 32 rows
  * (~79 of 384 on the headline frame) and per row four row numbers + bilinear weights + the blended colour (160 B per
- * sample); the fused kernel copies those texels of the map into LDS and blends them itself, in K5's term order -- the
- * operand it multiplies is K5's row, bit for bit, and nothing of it travels through HBM; 0 = K5 writes the rows (3.3 KB per
- * sample, read back twice).  Env TH_ROWS_TEX=0 makes 0 the default of new contexts.  Ask th_shade_pool_bytes again
+ * sample); the fused kernel copies those texels -- of the FOLDED maps, th_map_fold / th_frame.map_fold: the layers that read
+ * the features are applied to the map's texels once per frame -- into LDS and blends them itself with K5's weights; nothing of
+ * the rows travels through HBM and two of the kernel's GEMMs are gone; 0 (or a frame without map_fold) = K5 writes the rows
+ * (3.3 KB per sample, read back twice).  Env TH_ROWS_TEX=0 makes 0 the default of new contexts.  Ask th_shade_pool_bytes again
  * after a change. */
 int th_set_tex_rows(th_ctx* ctx, int on);
 
@@ -312,6 +313,14 @@ int th_pixel_gather_split(th_ctx* ctx, const float* map_split, int V, int H, int
                           const int32_t* sel, int P, const float* cams, const float* scale_xy, void* out_rows,
                           int ldo, th_stream stream);
 
+/* The layers that read the pixel-aligned features -- alpha_res_0, rgb_res_0 (under the folded view_fc) and rgb_res_1,
+ * cross_transformer.py:316, :334, :346 -- applied to the TEXELS of a TH_MAP_SPLIT map instead of to every (sample, view) row:
+ * they are linear and act directly on grid_sample's bilinear blends (if_clight_renderer.py:255-265), so they commute with the
+ * sampling.  fold [2][V,H,W,256] fp32: plane 0 = alpha_res_0' texel, plane 1 = [Wa rgb_res_0' (128) | rgb_res_1' (128)] texel
+ * (no biases; the colour lift is inside, th_mlp_weights.upsample_color).  box: device int32 [V][4] (th_map_box) -> only texels
+ * inside each view's box are computed, or NULL: the whole map.  Once per frame, after th_set_mlp_weights; th_frame.map_fold. */
+int th_map_fold(th_ctx* ctx, const float* map_split, int V, int H, int W, const int32_t* box, float* fold, th_stream stream);
+
 /* K5t, the producer of the texel hand-over (th_set_tex_rows; k_pixtex.hip), on its own -- exposed for tests.  Samples are taken
  * in tiles of 32 consecutive entries (of `sel`, or of the points when sel is NULL); out (th_pixel_texlist_bytes(V, P) bytes,
  * T = ceil(P / 32) tiles) receives
@@ -319,8 +328,8 @@ int th_pixel_gather_split(th_ctx* ctx, const float* map_split, int V, int H, int
  *           the tile belongs to pass s / (32 / npass)), words 8 .. 8 + U - 1 = view * H * W + y * W + x of the pass's distinct
  *           corner texels;
  *   records [T][V][32][8]: {w00, w01, w10, w11} (float bits, grid_sample's bilinear weights, if_clight_renderer.py:210-269) and
- *           {o00, o01, o10, o11} = 1040 * (number of the corner's texel in its pass's list);
- *   colours [T][V][32][4]: the blended r g b of the sample (float bits), 0. */
+ *           {o00, o01, o10, o11} = 1040 * (number of the corner's texel in its pass's list).
+ * (map_split is not read: the lists depend on the cameras only.) */
 size_t th_pixel_texlist_bytes(int V, int P);
 int th_pixel_texlist(th_ctx* ctx, const float* map_split, int V, int H, int W, const float* pts_world, const int32_t* sel,
                      int P, const float* cams, const float* scale_xy, void* out, size_t out_bytes, th_stream stream);
@@ -452,6 +461,8 @@ typedef struct {
     float        hull_thresh;      /* 0.1                                     */
     int          small_frame_rays; /* 2400: R' <= this -> un-masked branch    */
     const th_map_source* map_source; /* NULL: pixel_map_nhwc is complete; else it is cropped to map_source->box */
+    const float* map_fold;         /* NULL, or th_map_fold's output for pixel_map_nhwc (TH_MAP_SPLIT, same crop): [2][V,H,W,256];
+                                      with it (and th_set_tex_rows 1) the per-sample stage takes the texel hand-over */
 } th_frame;
 
 /* Renderer.render_fast :429-484 incl. _render/batchify_rays/raw2outputs for a

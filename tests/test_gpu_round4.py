@@ -238,7 +238,7 @@ def test_texel_lists_rebuild_the_gathered_rows(hip, gpu, net, cap):
     """K5t on its own (th_pixel_texlist): per 32-sample tile a list of DISTINCT corner texels (at most 103 per pass, 1 / 2 / 4
     passes) and per (sample, view) four weights + four row offsets into its pass's list.  Rebuilding every row from the lists --
     sum_c w_c * map[list[o_c / 1040]] -- must give the rows K5's fp32 kernel gathers (th_pixel_gather, golden-checked g9): to fp32
-    rounding for the latents (fused multiply-adds there, separate ones here), bit for bit for the colour tail (same term order).
+    rounding (fused multiply-adds there, separate ones here).
     On the frame's sample order, a ragged tail and points outside every image; cap = 24 (TH_TEX_CAP) forces 2- / 4-pass tiles."""
     r = _renderer(net, 300)
     b = synth.batch_to(synth.make_batch(128, 128, 3, seed=0, all_rays=True, focal=150.0), gpu)
@@ -261,7 +261,7 @@ def test_texel_lists_rebuild_the_gathered_rows(hip, gpu, net, cap):
         torch.cuda.synchronize()
     finally:
         os.environ.pop("TH_TEX_CAP", None)
-    lists, rec, col = t["lists"].long(), t["records"], t["colours"]
+    lists, rec = t["lists"].long(), t["records"]
     T = lists.shape[0]
     U = lists[:, :, 0] & 0xffff                              # [T, 4]
     npass = (lists[:, 0, 0] >> 16)                           # [T]
@@ -302,9 +302,6 @@ def test_texel_lists_rebuild_the_gathered_rows(hip, gpu, net, cap):
     ref = hip.pixel_gather(frame.map.interleaved(), world, frame.cams, frame.scale)                     # [P, V, 260] fp32
     scale = ref.abs().amax().clamp(min=1.0)
     assert float((rows[:, :, :256] - ref[:, :, :256]).abs().max()) < 4e-6 * float(scale)
-    # the colour tail is blended by K5t itself: K5's values
-    c = col.permute(0, 2, 1, 3).reshape(T * 32, V, 4)[:P]
-    assert torch.equal(c[:, :, :3], ref[:, :, 256:259]) and float(c[:, :, 3].abs().max()) == 0.0
 
 
 def test_stem_in_eval_mode_runs_the_hip_kernels(hip, gpu):
@@ -344,11 +341,12 @@ def _tex_on_off(hip, r, b, **kw):
 
 
 @pytest.mark.parametrize("case", ["headline", "dense", "v1_small", "v2_small", "ragged", "forced_passes"])
-def test_texel_handover_equals_row_handover_bitwise(hip, gpu, net, case):
-    """TH_ROWS_TEX: the fused kernel blends the distinct corner texels of a tile itself (k_pixtex.hip + fill_tex) instead of
-    reading K5's rows.  Same arithmetic in the same order -> the operand planes, and therefore the images, are bit-identical.
-    `dense` (every sample valid, focal 6000: footprints of a tile spread over many texels) exercises the 2- and 4-pass
-    tiles; the small frames the V = 1 / 2 instantiations and the ragged last tile."""
+def test_texel_handover_equals_row_handover(hip, gpu, net, case):
+    """TH_ROWS_TEX: the layers that read the pixel-aligned features are applied to the map's texels once per frame
+    (th_map_fold) and the fused kernel blends texel rows of the folded maps itself (k_pixtex.hip + fill_tex) instead of
+    multiplying K5's rows.  Same function, other order of the fp32 roundings: the images agree to a few 1e-6 (the bar of
+    the path is 1e-4).  `dense` exercises long texel lists, `forced_passes` the 2- and 4-pass tiles, the small frames the
+    V = 1 / 2 instantiations and the ragged last tile."""
     if case == "headline":
         r = _renderer(net, 500)
         b = synth.batch_to(synth.make_batch(512, 512, 3, seed=0, all_rays=True), gpu)
@@ -371,6 +369,37 @@ def test_texel_handover_equals_row_handover_bitwise(hip, gpu, net, case):
     finally:
         os.environ.pop("TH_TEX_CAP", None)
     assert st["valid_samples"] > 1000, st
-    for k in ("rgb_map", "acc_map", "depth_map"):
-        assert torch.equal(o1[k], o0[k]), (case, k, maxdiff(o1[k].cpu(), o0[k].cpu()))
+    ds = {k: maxdiff(o1[k].cpu(), o0[k].cpu()) for k in ("rgb_map", "acc_map", "depth_map")}
+    print(case, ds)
+    assert ds["rgb_map"] < 1e-5 and ds["acc_map"] < 1e-5 and ds["depth_map"] < 5e-5, (case, ds)
     assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")
+
+
+def test_map_fold_equals_the_layers_on_the_texels(hip, gpu, net):
+    """th_map_fold: alpha_res_0 / (view_fc[:, :256] rgb_res_0) / rgb_res_1 applied to every texel [latents | upsample_color(rgb)]
+    of the cropped split map, against the same products in float64 torch from the module's own weights (no biases)."""
+    r = _renderer(net, 300)
+    b = synth.batch_to(synth.make_batch(96, 96, 3, seed=1, all_rays=True), gpu)
+    frame = r.prepare_frame(b)
+    m = frame.map
+    assert m.fold is not None and m.fold.shape == (2, 3, 96, 96, 256)
+    box = m.box.cpu().numpy() if m.box is not None else None
+    lat = m.latents.double()                                   # [V,H,W,256]
+    rgb = m.rgb0[..., :3].double()
+    n = net
+    cw = n.encoder.upsample_color.weight.double().reshape(128, 3)
+    lift = rgb @ cw.t()                    # [V,H,W,128]: the reference's last 128 map channels less their bias (cb: W[:, 256:] cb
+    #                                        is a constant per output channel and sits in the folded layers' biases)
+    x = torch.cat([lat, lift], dim=-1)                         # [V,H,W,384]
+    w_ar0 = n.alpha_res_0.weight.double().reshape(256, 384)
+    wa = n.view_fc.weight.double().reshape(128, -1)[:, :256]
+    w_r0 = wa @ n.rgb_res_0.weight.double().reshape(256, 384)
+    w_r1 = n.rgb_res_1.weight.double().reshape(128, 384)
+    ref0 = x @ w_ar0.t()
+    ref12 = torch.cat([x @ w_r0.t(), x @ w_r1.t()], dim=-1)
+    for v in range(3):
+        x0, y0, x1, y1 = (0, 0, 95, 95) if box is None else box[v]
+        for got, ref in ((m.fold[0], ref0), (m.fold[1], ref12)):
+            g = got[v, y0:y1 + 1, x0:x1 + 1].double()
+            e = ref[v, y0:y1 + 1, x0:x1 + 1]
+            assert float((g - e).abs().max()) < 2e-5 * max(1.0, float(e.abs().max())), (v, float((g - e).abs().max()))

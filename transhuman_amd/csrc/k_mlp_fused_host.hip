@@ -342,9 +342,32 @@ int th_tok_split(float* tprime, int rows, float* sc, unsigned int* range, hipStr
     return 0;
 }
 
+// map_split: TH_MAP_SPLIT ([V][H*W][256] latents, then [V][H*W][4] colours); fold: [2][V][H*W][256] (fold0, then fold12)
+int th_map_fold_launch(const FusedParams& base, const float* map_split, int V, int H, int W, const int32_t* box, float* fold,
+                       unsigned int* range, hipStream_t s) {
+    TH_REQUIRE(base.compact_ready, "the map fold needs the colour-folded layers (th_mlp_weights.upsample_color)");
+    TH_REQUIRE(V >= 1 && H >= 1 && W >= 1 && map_split && fold, "bad argument");
+    MapFoldParams p;
+    p.ar0 = base.ar0c; p.rst = base.rstc;
+    p.lat = map_split; p.rgb = map_split + (size_t)V * H * W * 256;
+    p.box = box; p.V = V; p.H = H; p.W = W;
+    p.out0 = fold; p.out12 = fold + (size_t)V * H * W * 256;
+    p.range = range;
+    static bool attr = false;
+    if (!attr) {
+        TH_HIP(hipFuncSetAttribute((const void*)map_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 96 * STR272));
+        attr = true;
+    }
+    const int tpr = (W + 95) / 96;
+    hipLaunchKernelGGL(map_fold_kernel, dim3((unsigned)(V * H * tpr)), dim3(256), 2 * 96 * STR272, s, p);
+    TH_LAUNCH_CHECK();
+    return 0;
+}
+
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all, float* raw_c,
-                         unsigned int* range, hipStream_t s, const void* tsplit, const float* t_inv, int t_nc, const float* tex_map) {
+                         unsigned int* range, hipStream_t s, const void* tsplit, const float* t_inv, int t_nc, const float* tex_map,
+                         size_t tex_stride) {
     if (P <= 0) return 0;
     TH_REQUIRE(V >= 1 && V <= 3, "fused MLP supports 1..3 reference views");
     TH_REQUIRE(f_ld == 384 || (f_ld == 272 && base.compact_ready),
@@ -357,12 +380,12 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     p.tsplit = (const _Float16*)tsplit; p.t_inv = t_inv; p.t_nc = t_nc;
     const bool tex = tex_map != nullptr;
     TH_REQUIRE(!tex || (cf && f != nullptr), "texel hand-over: compact (272-wide) operand planes only");
-    p.tex_hdr = nullptr; p.tex_rec = nullptr; p.tex_col = nullptr; p.tex_map = nullptr;
+    p.tex_hdr = nullptr; p.tex_rec = nullptr; p.tex_map = nullptr; p.tex_map2 = nullptr;
     if (tex) {          // `f` is K5t's block: tile headers, then the per-row records (th_pixtex_launch)
         p.tex_hdr = (const unsigned*)f;
         p.tex_rec = p.tex_hdr + (size_t)th_cdiv(P, FM_PTS) * 512;
-        p.tex_col = p.tex_rec + (size_t)th_cdiv(P, FM_PTS) * V * 32 * 8;
-        p.tex_map = tex_map;
+        p.tex_map = tex_map;                                 // fold0, fold12 behind it (th_map_fold_launch)
+        p.tex_map2 = tex_map + tex_stride;
         f = nullptr;
     }
     p.stok = stok; p.pe = (const _Float16*)pe; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all; p.range = range;

@@ -657,12 +657,15 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
 #else
 #define TX_ADDR(id) (size_t)(((id) << 10) + loff)
 #endif
-    auto fill_tex = [&](const TexPre& pre, auto&& under) __attribute__((always_inline)) {
+    // `rgb` (a std::bool_constant): false = pixel branch: rows of fold0 (alpha_res_0 of the texels), p = relu(blend + bias) written
+    // as the hi / lo operand planes of kv0; true = RGB branch: rows of fold12 ([Wa rgb_res_0 | rgb_res_1] of the texels), the
+    // blended fp32 rows written to ABUF ([row][256], 1040-byte rows) for the accumulator-layout reads of the epilogue.
+    auto fill_tex = [&](const TexPre& pre, auto rgb, auto&& under) __attribute__((always_inline)) {
+        constexpr bool RGB = decltype(rgb)::value;
         constexpr int TSTR = 1040, TMAX = 103, NK = (TMAX + 3) / 4, NR = 8 * V;
         static_assert(TMAX * TSTR <= ABUF_BYTES, "a pass of texel rows must fit the operand buffer");
         int wv = __builtin_amdgcn_readfirstlane(wave), tl = tile;
         asm volatile("" : "+s"(wv), "+s"(tl));
-        const unsigned seen_f = P.range ? P.range[TH_RANGE_F] : 0u;
         const unsigned* hb = P.tex_hdr + (long long)tl * 512;
         unsigned h0 = pre.h0, h1 = pre.h1;
         const int npass = __builtin_amdgcn_readfirstlane((int)(h0 >> 16));
@@ -670,10 +673,15 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         // LDS (MISC: free here)
         char* recl = reinterpret_cast<char*>(misc);
         static_assert(32 * V * 32 <= (9 * 32 + 4 * 32 * 4) * 4, "row records must fit probs + part");
-        unsigned fh[NR][2] = {}, fl[NR][2] = {};     // operand row wv + 4 k: hi / lo halves of channels 4 lane .. 4 lane + 3
-        // lane k < 8 V: the blended colour {r g b 0} of operand row wv + 4 k (requested in front of the texel rows, used last)
-        fm_u4 qc = {0u, 0u, 0u, 0u};
-        if (lane < NR) qc = *reinterpret_cast<const fm_u4*>(P.tex_col + ((long long)tl * V * 32 + wv + 4 * lane) * 4);
+        // operand row wv + 4 k, channels 4 lane .. 4 lane + 3: packed hi / lo halves of relu(blend + bias) (pixel branch: fv[k][0..1]
+        // hi, [2..3] lo) or the four blended fp32 values (RGB branch)
+        unsigned fv[NR][4] = {};
+        f32x2 bias_lo = {0.f, 0.f}, bias_hi = {0.f, 0.f};
+        if constexpr (!RGB) {
+            const float4 b4 = *reinterpret_cast<const float4*>(P.ar0.bias + 4 * lane);
+            bias_lo = (f32x2){b4.x, b4.y};
+            bias_hi = (f32x2){b4.z, b4.w};
+        }
         for (int p = 0; p < npass; ++p) {
             if (p > 0) {
                 FM_SYNCL();                                  // the previous pass's rows have been read
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 // for the others (no branch between the loads of a group; the average list of 79 rows has no clamped request).
                 // Addresses are a scalar base + a 32-bit lane offset (map < 4 GiB: launcher).
                 constexpr int NA = 14, NB = 20;
-                const char* mbase = reinterpret_cast<const char*>(P.tex_map);
+                const char* mbase = reinterpret_cast<const char*>(RGB ? P.tex_map2 : P.tex_map);
                 const unsigned loff = (unsigned)lane * 16u;
                 const int last = U - 1;
                 fm_u4 ta[NA], tb[NB - NA], tc[NK - NB];
@@ -766,15 +774,23 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
                 hi = __builtin_elementwise_fma((f32x2){r.c.z, r.c.w}, W10, hi);
                 lo = __builtin_elementwise_fma((f32x2){r.d.x, r.d.y}, W11, lo);
                 hi = __builtin_elementwise_fma((f32x2){r.d.z, r.d.w}, W11, hi);
-                unsigned nh0, nl0, nh1, nl1;
-                split_pair(lo[0], lo[1], nh0, nl0);
-                split_pair(hi[0], hi[1], nh1, nl1);
+                unsigned n0, n1, n2, n3;
+                if constexpr (RGB) {
+                    const float l0 = lo[0], l1 = lo[1], h0f = hi[0], h1f = hi[1];      // (copies: bit_cast of a vector component reads [0])
+                    n0 = __builtin_bit_cast(unsigned, l0); n1 = __builtin_bit_cast(unsigned, l1);
+                    n2 = __builtin_bit_cast(unsigned, h0f); n3 = __builtin_bit_cast(unsigned, h1f);
+                } else {                                     // p = relu(alpha_res_0 f): + bias, relu, hi / lo split
+                    lo = __builtin_elementwise_max(lo + bias_lo, (f32x2){0.f, 0.f});
+                    hi = __builtin_elementwise_max(hi + bias_hi, (f32x2){0.f, 0.f});
+                    split_pair(lo[0], lo[1], n0, n2);
+                    split_pair(hi[0], hi[1], n1, n3);
+                }
                 if constexpr (decltype(sel)::value) {        // multi-pass tile: a row is kept in its own pass only
                     const bool mine = ((k & 7) >> sh2) == p;
-                    fh[k][0] = mine ? nh0 : fh[k][0]; fl[k][0] = mine ? nl0 : fl[k][0];
-                    fh[k][1] = mine ? nh1 : fh[k][1]; fl[k][1] = mine ? nl1 : fl[k][1];
+                    fv[k][0] = mine ? n0 : fv[k][0]; fv[k][1] = mine ? n1 : fv[k][1];
+                    fv[k][2] = mine ? n2 : fv[k][2]; fv[k][3] = mine ? n3 : fv[k][3];
                 } else {
-                    fh[k][0] = nh0; fl[k][0] = nl0; fh[k][1] = nh1; fl[k][1] = nl1;
+                    fv[k][0] = n0; fv[k][1] = n1; fv[k][2] = n2; fv[k][3] = n3;
                 }
             };
             auto rows_loop = [&](auto sel) __attribute__((always_inline)) {
@@ -795,35 +811,22 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             if (npass == 1) rows_loop(std::false_type{});
             else rows_loop(std::true_type{});
         }
+        FM_SYNCL();                                          // every wave is done reading texel rows: ABUF takes the result
+        if constexpr (RGB) {
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            range_acc<false>(rmax, fh[k][0]);
-            range_acc<false>(rmax, fh[k][1]);
-        }
-
-        FM_SYNCL();                                          // every wave is done reading texel rows: ABUF takes the planes
+            for (int k = 0; k < NR; ++k)
+                *reinterpret_cast<fm_u4*>(abuf + (wv + 4 * k) * TSTR + lane * 16) = (fm_u4){fv[k][0], fv[k][1], fv[k][2], fv[k][3]};
+        } else {
+            const unsigned seen_p = P.range ? P.range[TH_RANGE_P] : 0u;
 #pragma unroll
-        for (int k = 0; k < NR; ++k) {
-            const int row = wv + 4 * k;
-            *reinterpret_cast<uint2*>(abuf + row * STR272 + lane * 8) = make_uint2(fh[k][0], fh[k][1]);
-            *reinterpret_cast<uint2*>(fa_lo + row * STR272 + lane * 8) = make_uint2(fl[k][0], fl[k][1]);
+            for (int k = 0; k < NR; ++k) {
+                range_acc<true>(rmax, fv[k][0]);
+                range_acc<true>(rmax, fv[k][1]);
+                *reinterpret_cast<uint2*>(abuf + (wv + 4 * k) * STR256 + lane * 8) = make_uint2(fv[k][0], fv[k][1]);
+                *reinterpret_cast<uint2*>(a256_lo + (wv + 4 * k) * STR256 + lane * 8) = make_uint2(fv[k][2], fv[k][3]);
+            }
+            range_commit(P.range, TH_RANGE_P, seen_p, rmax);
         }
-        // colour tail: channels 256..258 = the blended r g b, 259..271 = 0
-        if (lane < NR) {
-            const int row = wv + 4 * lane;
-            const unsigned ur = qc[0], ug = qc[1], ub = qc[2];
-            uint4 th = make_uint4(0u, 0u, 0u, 0u), tl4 = make_uint4(0u, 0u, 0u, 0u);
-            split_pair(__builtin_bit_cast(float, ur), __builtin_bit_cast(float, ug), th.x, tl4.x);
-            split_pair(__builtin_bit_cast(float, ub), 0.f, th.y, tl4.y);
-            range_acc<false>(rmax, th.x);
-            range_acc<false>(rmax, th.y);
-            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
-            *reinterpret_cast<uint4*>(abuf + row * STR272 + 512) = th;
-            *reinterpret_cast<uint4*>(abuf + row * STR272 + 528) = z4;
-            *reinterpret_cast<uint4*>(fa_lo + row * STR272 + 512) = tl4;
-            *reinterpret_cast<uint4*>(fa_lo + row * STR272 + 528) = z4;
-        }
-        range_commit(P.range, TH_RANGE_F, seen_f, rmax);
     };
 
     TexPre tex_pre{}, tex_pre2{};
@@ -1104,9 +1107,8 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     FM_SB();
     uint4 wk2[FM_RING_D2][2][2];
     if constexpr (TEX) {
-        fill_tex(tex_pre, [] {});
-        ring_prefetch0<2, FM_RING_D2>(wslice(P.ar0, wave, 2, 0), lane, wk2);
-        FM_SYNCL();
+        // alpha_res_0 was applied to the texels of the map once per frame (map_fold_kernel below): p is the blend of fold0 rows
+        fill_tex(tex_pre, std::false_type{}, [] {});
     } else {
     stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
 #ifdef FM_STAMPS
@@ -1114,7 +1116,6 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
 #endif
     ring_prefetch0<2, FM_RING_D2>(wslice(P.ar0, wave, 2, 0), lane, wk2);
     FM_SYNC();
-    }
     gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 3, true>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2, wk2);
 #ifdef FM_STAMPS
     FM_STAMP();
@@ -1135,6 +1136,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             store_tile_h<STR256>(acc2[c][r], r * 32 + myrow, wave * 64 + c * 32, abuf, a256_lo, lane, rmax);
     }
     range_commit(P.range, TH_RANGE_P, seen_p, rmax);
+    }
     FM_SB();
     ring_prefetch0<3, FM_RING_D>(wslice(P.kv0, wave, 3, 0), lane, wk3);
     FM_SYNCL();
@@ -1402,14 +1404,10 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         ring_prefetch<1, FM_RING_D2>(wslice(P.vfD, wave, 1, 0), 2, lane, wvd);
         FM_SB();
         if constexpr (TEX) {
-            fill_tex(tex_pre2, [&]() __attribute__((always_inline)) {
+            // (Wa rgb_res_0) f and rgb_res_1 f are blends of fold12 rows ([128 | 128] channels per texel): fp32 rows in ABUF
+            fill_tex(tex_pre2, std::true_type{}, [&]() __attribute__((always_inline)) {
                 gemm_phase_core<V, 1, STRVD, 0, FM_RING_D2, true, 0, true, false>(vd_hi, vd_lo, wslice(P.vfD, wave, 1, 0), 2, lane, vf, wvd);   // KB < D
             });
-            ring_prefetch0<2, FM_RING_D2>(wslice(P.rst, wave, 2, 0), lane, wk2);
-#pragma unroll
-            for (int r = 0; r < V; ++r)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc2[1][r][e] = 0.f;
             FM_SYNCL();
         } else {
         stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
@@ -1422,6 +1420,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             for (int e = 0; e < 16; ++e) acc2[1][r][e] = 0.f;
         FM_SYNC();
         }
+        if constexpr (!TEX) {
         gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 0, true>(abuf, fa_lo, wslice(P.rst, wave, 2, 0), FL::NA, lane, acc2, wk2);
 #ifdef FM_STAMPS
         FM_STAMP();
@@ -1431,6 +1430,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
             stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
             FM_SYNC();
             gemm_phase<V, 2, FL::SB>(abuf, fb_lo, wslice(P.rst, wave, 2, FL::NA), FL::NB, lane, acc2);
+        }
         }
         // fc_4 weights (this wave's 8 k-blocks) and the rgb_fc rows of its channels: requested before the epilogue
         uint4 w4[8][1][2];
@@ -1449,8 +1449,31 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         {
             const BiasT bt = load_bias(P.rst.bias, wave * 32, lane), br = load_bias(P.rst.bias, 128 + wave * 32, lane);
             FM_SB();
+            if constexpr (TEX) {
+                // t = relu(vf 2^-s + b' + blend(fold12[:, :128])), tile 1 = blend(fold12[:, 128:]) + b_R1: the blended rows are read
+                // back in the accumulator layout (row = view * 32 + sample, this wave's 32 channels, 4 per group)
+                finish_tile_b<V>(acc2[0], bt, P.rst.inv_scale, false);
+                const char* mb = abuf + myrow * 1040 + 4 * (wave * 32 + 4 * (lane >> 5));
+#pragma unroll
+                for (int r = 0; r < V; ++r)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 m1 = *reinterpret_cast<const float4*>(mb + r * 32 * 1040 + 32 * g);
+                        const float4 m2 = *reinterpret_cast<const float4*>(mb + r * 32 * 1040 + 512 + 32 * g);
+                        const float4 b2 = br.g[g];
+                        acc2[0][r][4 * g] = fmaxf(acc2[0][r][4 * g] + m1.x, 0.f);
+                        acc2[0][r][4 * g + 1] = fmaxf(acc2[0][r][4 * g + 1] + m1.y, 0.f);
+                        acc2[0][r][4 * g + 2] = fmaxf(acc2[0][r][4 * g + 2] + m1.z, 0.f);
+                        acc2[0][r][4 * g + 3] = fmaxf(acc2[0][r][4 * g + 3] + m1.w, 0.f);
+                        acc2[1][r][4 * g] = m2.x + b2.x;
+                        acc2[1][r][4 * g + 1] = m2.y + b2.y;
+                        acc2[1][r][4 * g + 2] = m2.z + b2.z;
+                        acc2[1][r][4 * g + 3] = m2.w + b2.w;
+                    }
+            } else {
             finish_tile_b<V>(acc2[0], bt, P.rst.inv_scale, true);
             finish_tile_b<V>(acc2[1], br, P.rst.inv_scale2, false);
+            }
         }
         char* f4_hi = mbuf + MBUF_FC4_OFF;
         char* f4_lo = f4_hi + 32 * STR128;
@@ -1518,4 +1541,122 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     if (tid < npts)
         *reinterpret_cast<float4*>(P.raw_c + (long long)(pbase + tid) * 4) =
             make_float4(rgb_out[0], rgb_out[1], rgb_out[2], sig[tid]);
+}
+
+// ---- the f-consuming layers applied to the MAP (TH_ROWS_TEX, late round 4) ------------------------------------------------------
+// alpha_res_0, rgb_res_0 and rgb_res_1 (cross_transformer.py:316, :334, :346) are linear maps applied DIRECTLY to the bilinear
+// samples of the pixel map (grid_sample, if_clight_renderer.py:255-265), and bilinear sampling is linear in the map's texels:
+//   L(sum_c w_c texel_c) = sum_c w_c L(texel_c)          (the weights of a sample sum to 1: the bias is added after the blend)
+// so the three layers are evaluated ONCE PER TEXEL of the (cropped) map -- ~0.26 M texel rows per frame instead of 6.3 M
+// (sample, view) rows -- and the fused kernel blends texel rows of the two transformed maps where it used to blend the latents
+// and multiply: its alpha_res_0 and stacked [Wa R0 ; R1] GEMMs (26 k of 141 k cycles per tile) are gone.  Same packed weight
+// images, same fp16 hi/lo x 3 MFMA arithmetic, same power-of-two scales as in the fused kernel; outputs are the plain fp32
+// values (accumulator x 2^-scale, no bias):
+//   fold0 [V][H*W][256]  = alpha_res_0' [lat | rgb]                (K = 260 colour-folded form)
+//   fold12[V][H*W][256]  = [ (Wa rgb_res_0')  (128) | rgb_res_1' (128) ] [lat | rgb]
+// One workgroup = 96 consecutive texels of one image row inside the view's box (3 row tiles of 32: the fused kernel's operand
+// shape, so gemm_phase_core and the weight slices are used as they are).
+struct MapFoldParams {
+    FusedLayer ar0, rst;           // the colour-folded (K = 272) images
+    const float* lat;              // [V][H*W][256]
+    const float* rgb;              // [V][H*W][4]
+    const int32_t* box;            // device [V][4] x0 y0 x1 y1 inclusive, or nullptr: the whole map
+    int V, H, W;
+    float* out0;
+    float* out12;
+    unsigned int* range;           // TH_RANGE_F takes max |hi half| of the texels that are split
+};
+
+__global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char* hi_pl = lds;
+    char* lo_pl = lds + 96 * STR272;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tpr = (P.W + 95) / 96;
+    const int v = blockIdx.x / (P.H * tpr), rem = blockIdx.x - v * (P.H * tpr);
+    const int y = rem / tpr, xt = rem - y * tpr;
+    int x0 = 0, x1 = P.W - 1;
+    if (P.box != nullptr) {
+        x0 = P.box[4 * v];
+        x1 = P.box[4 * v + 2];
+        if (y < P.box[4 * v + 1] || y > P.box[4 * v + 3]) return;
+    }
+    const int xs = x0 + xt * 96;
+    if (xs > x1) return;
+    const long long trow = ((long long)v * P.H + y) * P.W;      // texel index of (v, y, 0)
+    unsigned rmax = 0u;
+    const unsigned seen_f = P.range ? P.range[TH_RANGE_F] : 0u;
+    // ---- the 96 texels as fp16 hi / lo planes [texel][272] (texels past the box's edge: the edge texel again, never stored)
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll 4
+        for (int k = 0; k < 24; ++k) {
+            const int r = wv + 4 * k;
+            const long long t = trow + min(xs + r, x1);
+            const float4 q = *reinterpret_cast<const float4*>(P.lat + t * 256 + 4 * lane);
+            uint2 h, l;
+            split_pair(q.x, q.y, h.x, l.x);
+            split_pair(q.z, q.w, h.y, l.y);
+            range_acc<false>(rmax, h.x);
+            range_acc<false>(rmax, h.y);
+            *reinterpret_cast<uint2*>(hi_pl + r * STR272 + lane * 8) = h;
+            *reinterpret_cast<uint2*>(lo_pl + r * STR272 + lane * 8) = l;
+        }
+        if (tid < 96) {                 // channels 256..258 = r g b, 259..271 = 0
+            const long long t = trow + min(xs + tid, x1);
+            const float4 c = *reinterpret_cast<const float4*>(P.rgb + t * 4);
+            uint4 th = make_uint4(0u, 0u, 0u, 0u), tl = make_uint4(0u, 0u, 0u, 0u);
+            split_pair(c.x, c.y, th.x, tl.x);
+            split_pair(c.z, 0.f, th.y, tl.y);
+            range_acc<false>(rmax, th.x);
+            range_acc<false>(rmax, th.y);
+            const uint4 z4 = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(hi_pl + tid * STR272 + 512) = th;
+            *reinterpret_cast<uint4*>(hi_pl + tid * STR272 + 528) = z4;
+            *reinterpret_cast<uint4*>(lo_pl + tid * STR272 + 512) = tl;
+            *reinterpret_cast<uint4*>(lo_pl + tid * STR272 + 528) = z4;
+        }
+        range_commit(P.range, TH_RANGE_F, seen_f, rmax);
+    }
+    __syncthreads();
+    const int myrow = lane & 31;
+    uint4 wk2[FM_RING_D2][2][2];
+    f32x16 acc[2][3];
+    // ---- alpha_res_0'
+    gemm_phase_core<3, 2, STR272, 32 * STR272, FM_RING_D2, true, 3, false>(hi_pl, lo_pl, wslice(P.ar0, wave, 2, 0), 17, lane, acc, wk2);
+    {
+        const float sc = P.ar0.inv_scale;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int x = xs + r * 32 + myrow;
+            if (x <= x1) {
+                float* o = P.out0 + (trow + x) * 256 + wave * 64 + 4 * (lane >> 5);
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4*>(o + c * 32 + 8 * g) =
+                            make_float4(acc[c][r][4 * g] * sc, acc[c][r][4 * g + 1] * sc, acc[c][r][4 * g + 2] * sc, acc[c][r][4 * g + 3] * sc);
+            }
+        }
+    }
+    // ---- stacked [Wa rgb_res_0' ; rgb_res_1']: column tile 0 = this wave's 32 of the 128 view_fc outputs, tile 1 = its 32 of rgb_res_1
+    gemm_phase_core<3, 2, STR272, 32 * STR272, FM_RING_D2, true, 3, false>(hi_pl, lo_pl, wslice(P.rst, wave, 2, 0), 17, lane, acc, wk2);
+    {
+        const float s0 = P.rst.inv_scale, s1 = P.rst.inv_scale2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int x = xs + r * 32 + myrow;
+            if (x <= x1) {
+                float* o = P.out12 + (trow + x) * 256 + wave * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    *reinterpret_cast<float4*>(o + 8 * g) =
+                        make_float4(acc[0][r][4 * g] * s0, acc[0][r][4 * g + 1] * s0, acc[0][r][4 * g + 2] * s0, acc[0][r][4 * g + 3] * s0);
+                    *reinterpret_cast<float4*>(o + 128 + 8 * g) =
+                        make_float4(acc[1][r][4 * g] * s1, acc[1][r][4 * g + 1] * s1, acc[1][r][4 * g + 2] * s1, acc[1][r][4 * g + 3] * s1);
+                }
+            }
+        }
+    }
 }

@@ -6,16 +6,16 @@
 // 2.4 ms kernel whose only product they are.  The 32 samples of a tile of the fused kernel are image neighbours in every
 // view (depth-major sample list inside 16-ray groups), so their 3 x 128 corner texels are only ~79 DISTINCT 1 KiB texel
 // rows of the map.  This kernel therefore hands over, per tile, the LIST of distinct texels (all views in one pool of rows)
-// and, per (sample, view), the four row numbers + the four bilinear weights + the blended colour; the fused kernel copies the
-// rows from the (L2-resident) map into LDS by LDS-DMA and blends them itself with K5's arithmetic, in K5's term order: the
-// operand planes it multiplies are bit-identical to K5's rows.
+// and, per (sample, view), the four row numbers + the four bilinear weights; the fused kernel copies the listed rows into LDS
+// and blends them itself (K5's weights and term order).  Since late round 4 the rows it copies are not the latents but
+// the texels of the two FOLDED maps (map_fold_kernel, k_mlp_fused_kernel.h: alpha_res_0 / rgb_res_0 / rgb_res_1 applied to the
+// map once per frame -- bilinear sampling commutes with linear layers), so this kernel needs no map at all: cameras only.
 //
 // Output (per launch of P samples, T = ceil(P / 32) tiles):
 //   hdr  [T][4 passes][128 words]   word 0 = U | npass << 16 (U = texel rows of this pass, npass = 1, 2 or 4),
 //                                   words 8 .. 8 + U - 1 = global texel index (view * H * W + y * W + x) of row 0 .. U - 1
 //   rec  [T][V][32 samples][8 words] {w00, w01, w10, w11} {byte offsets of the nw, ne, sw, se texel rows in the fused kernel's
 //                                   row buffer: row number x 1040}
-//   col  [T][V][32 samples][4 words] {r, g, b, 0}: the blended colour texels (channels 256..258 of the row), fp32
 // A pass holds at most TX_CAP rows (what the fused kernel's operand buffer takes).  5.8 % of the headline frame's tiles need
 // more: their samples are split into halves (2 passes) or quarters (4 passes: 8 samples x 4 corners x 3 views = 96 rows
 // always fit), each with its own row list; sample s belongs to pass s / (32 / npass).
@@ -126,10 +126,10 @@ __device__ __forceinline__ int tx_dedup(unsigned px, unsigned py, unsigned M, bo
 }
 
 template <int V>
-__global__ __launch_bounds__(256) void pixtex_kernel(const float* __restrict__ map, int H, int W, ThPointSrc ps,
+__global__ __launch_bounds__(256) void pixtex_kernel(int H, int W, ThPointSrc ps,
                                                      const int32_t* __restrict__ sel, int P, const float* __restrict__ cams,
                                                      const float* __restrict__ scale, unsigned* __restrict__ hdr,
-                                                     unsigned* __restrict__ rec, unsigned* __restrict__ col, int cap) {
+                                                     unsigned* __restrict__ rec, int cap) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int pbase = tile * 32;
@@ -137,14 +137,13 @@ __global__ __launch_bounds__(256) void pixtex_kernel(const float* __restrict__ m
     const int npts = min(32, P - pbase);
     const int smp = lane & 31;
     const int HW = H * W;
-    // ---- projection, corners, weights and the colour tail of this lane's sample in every view (K5's phase 1 + tail)
+    // ---- projection, corners and weights of this lane's sample in every view (K5's phase 1)
     unsigned px[V], py[V];
     {
         const int p = pbase + min(smp, npts - 1);          // ragged last tile: the last sample again (rows never stored)
         const long long s = sel ? sel[p] : p;
         float x, y, z;
         th_get_point(ps, s, x, y, z);
-        const float4* rgbp = reinterpret_cast<const float4*>(map + (long long)V * HW * 256);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
             float uu, vv;
@@ -152,19 +151,10 @@ __global__ __launch_bounds__(256) void pixtex_kernel(const float* __restrict__ m
             const Bilin b = th_bilinear_setup(uu, vv, scale[0], scale[1], H, W);
             px[v] = (unsigned)b.x0 | ((unsigned)b.x1 << 16);
             py[v] = (unsigned)b.y0 | ((unsigned)b.y1 << 16);
-            const float4 a = rgbp[(long long)v * HW + b.i00], bb = rgbp[(long long)v * HW + b.i01],
-                         cc = rgbp[(long long)v * HW + b.i10], d = rgbp[(long long)v * HW + b.i11];
-            // (pixgather_s256_kernel's colour tail: the same term order)
-            const float r = fmaf(d.x, b.w11, fmaf(cc.x, b.w10, fmaf(bb.x, b.w01, a.x * b.w00)));
-            const float g = fmaf(d.y, b.w11, fmaf(cc.y, b.w10, fmaf(bb.y, b.w01, a.y * b.w00)));
-            const float bl = fmaf(d.z, b.w11, fmaf(cc.z, b.w10, fmaf(bb.z, b.w01, a.z * b.w00)));
-            if (lane < 32) {
-                unsigned* o = rec + ((long long)(tile * V + v) * 32 + smp) * 8;
-                *reinterpret_cast<uint4*>(o) = make_uint4(__builtin_bit_cast(unsigned, b.w00), __builtin_bit_cast(unsigned, b.w01),
-                                                          __builtin_bit_cast(unsigned, b.w10), __builtin_bit_cast(unsigned, b.w11));
-                *reinterpret_cast<uint4*>(col + ((long long)(tile * V + v) * 32 + smp) * 4) =
-                    make_uint4(__builtin_bit_cast(unsigned, r), __builtin_bit_cast(unsigned, g), __builtin_bit_cast(unsigned, bl), 0u);
-            }
+            if (lane < 32)
+                *reinterpret_cast<uint4*>(rec + ((long long)(tile * V + v) * 32 + smp) * 8) =
+                    make_uint4(__builtin_bit_cast(unsigned, b.w00), __builtin_bit_cast(unsigned, b.w01),
+                               __builtin_bit_cast(unsigned, b.w10), __builtin_bit_cast(unsigned, b.w11));
         }
     }
     // ---- row lists: one pass if the tile's distinct texels fit, else halves, else quarters
@@ -200,18 +190,17 @@ __global__ __launch_bounds__(256) void pixtex_kernel(const float* __restrict__ m
 
 size_t th_pixtex_bytes(int V, long long P) {
     const long long T = (P + 31) / 32;
-    return (size_t)T * TX_HDR_WORDS * 4 + (size_t)T * V * 32 * (8 + 4) * 4;
+    return (size_t)T * TX_HDR_WORDS * 4 + (size_t)T * V * 32 * 8 * 4;
 }
 
-// hdr = out, rec = hdr + T * TX_HDR_WORDS (words), col = rec + T * V * 256; map: TH_MAP_SPLIT ([V][H*W][256] latents, then [V][H*W][4] colours)
-int th_pixtex_launch(const float* map, int V, int H, int W, const ThPointSrc* ps, const int32_t* sel, int P, const float* cams,
+// hdr = out, rec = hdr + T * TX_HDR_WORDS (words)
+int th_pixtex_launch(int V, int H, int W, const ThPointSrc* ps, const int32_t* sel, int P, const float* cams,
                      const float* scale, void* out, hipStream_t s) {
     if (P <= 0) return 0;
     TH_REQUIRE(V >= 1 && V <= TX_MAXV && (long long)V * H * W < (1LL << 22), "texel hand-over: 1..3 views, V*H*W < 2^22 texels (4 GiB of map)");
     const int T = th_cdiv(P, 32);
     unsigned* hdr = reinterpret_cast<unsigned*>(out);
     unsigned* rec = hdr + (size_t)T * TX_HDR_WORDS;
-    unsigned* col = rec + (size_t)T * V * 32 * 8;
     const dim3 grid(th_cdiv(T, 4)), block(256);
     // developer / test switch: a smaller row budget per pass sends more tiles down the 2- and 4-pass forms (same results)
     // (read per launch: a test flips it between two renders of one process)
@@ -219,9 +208,9 @@ int th_pixtex_launch(const float* map, int V, int H, int W, const ThPointSrc* ps
     const int cv = e ? atoi(e) : TX_CAP;
     const int cap = cv >= 8 && cv <= TX_CAP ? cv : TX_CAP;
     switch (V) {
-        case 1: hipLaunchKernelGGL(pixtex_kernel<1>, grid, block, 0, s, map, H, W, *ps, sel, P, cams, scale, hdr, rec, col, cap); break;
-        case 2: hipLaunchKernelGGL(pixtex_kernel<2>, grid, block, 0, s, map, H, W, *ps, sel, P, cams, scale, hdr, rec, col, cap); break;
-        default: hipLaunchKernelGGL(pixtex_kernel<3>, grid, block, 0, s, map, H, W, *ps, sel, P, cams, scale, hdr, rec, col, cap); break;
+        case 1: hipLaunchKernelGGL(pixtex_kernel<1>, grid, block, 0, s, H, W, *ps, sel, P, cams, scale, hdr, rec, cap); break;
+        case 2: hipLaunchKernelGGL(pixtex_kernel<2>, grid, block, 0, s, H, W, *ps, sel, P, cams, scale, hdr, rec, cap); break;
+        default: hipLaunchKernelGGL(pixtex_kernel<3>, grid, block, 0, s, H, W, *ps, sel, P, cams, scale, hdr, rec, cap); break;
     }
     TH_LAUNCH_CHECK();
     return 0;

@@ -574,15 +574,22 @@ int th_pixel_gather_split(th_ctx* c, const float* map_split, int V, int H, int W
                                TH_ROWS_SPLIT, (hipStream_t)stream, nullptr);
 }
 
+int th_map_fold(th_ctx* c, const float* map_split, int V, int H, int W, const int32_t* box, float* fold, th_stream stream) {
+    TH_REQUIRE(c && map_split && fold, "null argument");
+    TH_REQUIRE(c->fused_ready && c->fused.compact_ready, "th_map_fold needs the MLP weights incl. upsample_color (th_set_mlp_weights)");
+    return th_map_fold_launch(c->fused, map_split, V, H, W, box, fold, c->range_dev, (hipStream_t)stream);
+}
+
 size_t th_pixel_texlist_bytes(int V, int P) { return th_pixtex_bytes(V, P); }
 
 int th_pixel_texlist(th_ctx* c, const float* map_split, int V, int H, int W, const float* pts, const int32_t* sel, int P,
                      const float* cams, const float* scale, void* out, size_t out_bytes, th_stream stream) {
-    TH_REQUIRE(c && map_split && pts && cams && scale && out, "null argument");
+    TH_REQUIRE(c && pts && cams && scale && out, "null argument");
+    (void)map_split;               // (the lists depend on the cameras only; the argument is kept for the map's identity)
     TH_REQUIRE(out_bytes >= th_pixtex_bytes(V, P), "output too small (th_pixel_texlist_bytes)");
     ThPointSrc ps{};
     ps.pts = pts;
-    return th_pixtex_launch(map_split, V, H, W, &ps, sel, P, cams, scale, out, (hipStream_t)stream);
+    return th_pixtex_launch(V, H, W, &ps, sel, P, cams, scale, out, (hipStream_t)stream);
 }
 
 int th_composite(th_ctx* c, const float* raw, const float* z, const th_points* rays, int white, float* rgb,
@@ -704,7 +711,7 @@ static size_t nbr_bytes(size_t m) { return (m + 32) * 16 * 4 + (m / 32 + 2) * 12
 // (the fused kernel addresses a texel row as a 32-bit byte offset into the map: V * H * W texels of 1 KiB must stay below 4 GiB --
 // three views of up to 1182 x 1182; larger maps keep K5's rows)
 static bool tex_rows(const th_ctx* c, const th_frame* f) {
-    return mlp_is_fused(c, f->V) && c->tex_rows == 1 && f->map_channels == TH_MAP_SPLIT &&
+    return mlp_is_fused(c, f->V) && c->tex_rows == 1 && f->map_channels == TH_MAP_SPLIT && f->map_fold != nullptr &&
            (long long)f->V * f->H * f->W < (1LL << 22);
 }
 
@@ -783,14 +790,14 @@ static int token_table(th_ctx* c, const float* tokens, int V, int nc, float* tpr
 // per-layer form wants them gathered into cb.vdc first.
 static int mlp_dispatch(th_ctx* c, int V, int m, const ChunkBufs& cb, int f_ld, const float* vd_table,
                         const int32_t* vd_sel, int vd_div, int rgb_all, hipStream_t s, float* tprime = nullptr, int nc = 0,
-                        const float* tex_map = nullptr) {
+                        const float* tex_map = nullptr, size_t tex_stride = 0) {
     TH_REQUIRE(c->mlp.ready, "MLP weights not set (th_set_mlp_weights)");
     if (mlp_is_fused(c, V)) {
         const bool nbr = tok_gather(c, V);
         TH_REQUIRE(!nbr || tprime != nullptr, "the neighbour-record path needs the split token table");
         return th_mlp_fused_forward(c->fused, c->mlp, V, m, cb.h, cb.pe, cb.f, f_ld, vd_table, vd_sel, vd_div, rgb_all,
                                     cb.raw_c, c->range_dev, s, nbr ? tprime : nullptr, nbr ? tprime_scale(tprime, V) : nullptr, nc,
-                                    tex_map);
+                                    tex_map, tex_stride);
     }
     const float* vd = vd_table;
     if (vd_sel != nullptr || vd_table != cb.vdc) {
@@ -907,7 +914,8 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     const int f_ld = frame_f_ld(f);
     const int fmt = mlp_row_format(c, V);
     const bool tex = tex_rows(c, f);
-    const float* tex_map = tex ? f->pixel_map_nhwc : nullptr;
+    const float* tex_map = tex ? f->map_fold : nullptr;                  // fold0, fold12 one map size behind it
+    const size_t tex_stride = (size_t)f->V * f->H * f->W * 256;
     TH_REQUIRE(prepass == 1 || !compact || c->mlp.compact_ready,
                "compact pixel map needs th_mlp_weights.upsample_color (colour-folded layers) to be uploaded");
     uint8_t* mask = ar.take<uint8_t>((size_t)P);
@@ -978,6 +986,9 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         TH_REQUIRE(f->map_channels == TH_MAP_SPLIT && ms->img && ms->lat0 && ms->lat1 && ms->lat2, "map_source: split map only");
         TH_TRY(th_upsample_concat_launch(ms->img, ms->lat0, ms->lat1, ms->lat2, ms->dims, V, f->H, f->W, nullptr, nullptr,
                                          const_cast<float*>(f->pixel_map_nhwc), s, 1, nullptr));
+        // (the folded maps of the texel hand-over follow the map: alpha_res_0 / rgb_res_0 / rgb_res_1 of EVERY texel now)
+        if (tex) TH_TRY(th_map_fold_launch(c->fused, f->pixel_map_nhwc, V, f->H, f->W, nullptr, const_cast<float*>(f->map_fold),
+                                           c->range_dev, s));
         if (tk) tk->map_done = f->pixel_map_nhwc;
     }
     const bool can_pre = ray_mode && tok_gather(c, V) && fmt == TH_ROWS_SPLIT;
@@ -1023,7 +1034,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
             }
             if (rc == 0) {
                 ProfScope ps2(pf, TH_PROF_GATHER, s);
-                rc = tex ? th_pixtex_launch(f->pixel_map_nhwc, V, f->H, f->W, &ps, idx, m, f->cams, f->scale_xy, a_f, s)
+                rc = tex ? th_pixtex_launch(V, f->H, f->W, &ps, idx, m, f->cams, f->scale_xy, a_f, s)
                          : th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx, m, f->cams,
                                                f->scale_xy, a_f, f_ld, fmt, s, c->range_dev);
             }
@@ -1074,7 +1085,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         pc.f = (float*)(pb + pl.a_f); pc.h = (float*)(pb + pl.a_h); pc.pe = (float*)(pb + pl.a_pe);
         {
             ProfScope ps3(pf, TH_PROF_MLP, s);
-            TH_TRY(mlp_dispatch(c, V, npre, pc, f_ld, vd_all, idx, S, unmasked, s, tprime, f->n_clusters, tex_map));
+            TH_TRY(mlp_dispatch(c, V, npre, pc, f_ld, vd_all, idx, S, unmasked, s, tprime, f->n_clusters, tex_map, tex_stride));
         }
         ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, idx, npre, unmasked, raw, s));
@@ -1086,7 +1097,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         // last thing written before the fused kernel reads it at the start of every tile: MALL instead of HBM)
         {
             ProfScope ps2(pf, TH_PROF_GATHER, s);
-            if (tex) TH_TRY(th_pixtex_launch(f->pixel_map_nhwc, V, f->H, f->W, &ps, sel, m, f->cams, f->scale_xy, cb.f, s));
+            if (tex) TH_TRY(th_pixtex_launch(V, f->H, f->W, &ps, sel, m, f->cams, f->scale_xy, cb.f, s));
             else TH_TRY(th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, sel, m, f->cams,
                                             f->scale_xy, cb.f, f_ld, fmt, s, c->range_dev));
         }
@@ -1098,10 +1109,10 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         {
             ProfScope ps3(pf, TH_PROF_MLP, s);
             // ray mode: the [R,27] embedding table is indexed sample -> ray (sel / S); mesh mode: zero rows (cb.vdc)
-            if (ray_mode) TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, vd_all, sel, S, unmasked, s, tprime, f->n_clusters, tex_map));
+            if (ray_mode) TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, vd_all, sel, S, unmasked, s, tprime, f->n_clusters, tex_map, tex_stride));
             // (the sigma grid never looks at colour: skip the RGB branch, which the reference evaluates and drops,
             // if_mesh_renderer.py:84-99)
-            else TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, cb.vdc, nullptr, 1, 2, s, tprime, f->n_clusters, tex_map));
+            else TH_TRY(mlp_dispatch(c, V, m, cb, f_ld, cb.vdc, nullptr, 1, 2, s, tprime, f->n_clusters, tex_map, tex_stride));
         }
         ProfScope ps4(pf, TH_PROF_COMPOSITE, s);
         TH_TRY(th_scatter_raw_launch(cb.raw_c, sel, m, unmasked, raw, s));

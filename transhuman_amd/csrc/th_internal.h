@@ -265,8 +265,8 @@ struct FusedParams {
     // numbers + bilinear weights + the blended colour; the kernel blends the rows of tex_map (TH_MAP_SPLIT latents) itself
     const unsigned* tex_hdr;   // [tiles][4][128]
     const unsigned* tex_rec;   // [tiles][V][32][8]  {w00 w01 w10 w11} {byte offsets of the four corner rows}
-    const unsigned* tex_col;   // [tiles][V][32][4]  {r g b 0}
-    const float* tex_map;      // [V][H*W][256]
+    const float* tex_map;      // fold0  [V][H*W][256]: alpha_res_0' of the map's texels (map_fold_kernel)
+    const float* tex_map2;     // fold12 [V][H*W][256]: [Wa rgb_res_0' (128) | rgb_res_1' (128)] of the texels
     const float* vd;    // view-direction rows [.][27]: row of compacted sample p = vd_sel ? vd_sel[p] / vd_div : p
     const int32_t* vd_sel;
     int vd_div;
@@ -290,11 +290,14 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
 int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int V, int P, const float* stok,
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all,
                          float* raw_c, unsigned int* range, hipStream_t s, const void* tsplit = nullptr,
-                         const float* t_inv = nullptr, int t_nc = 0, const float* tex_map = nullptr);
+                         const float* t_inv = nullptr, int t_nc = 0, const float* tex_map = nullptr, size_t tex_stride = 0);
+// alpha_res_0 / rgb_res_0 / rgb_res_1 applied to the texels of the (cropped) split map: fold [2][V][H*W][256] (k_mlp_fused_kernel.h)
+int th_map_fold_launch(const FusedParams& base, const float* map_split, int V, int H, int W, const int32_t* box, float* fold,
+                       unsigned int* range, hipStream_t s);
 // K5t (k_pixtex.hip): texel lists + records for P samples into `out` (th_pixtex_bytes); with tex_map != nullptr
 // th_mlp_fused_forward reads `f` as that block instead of rows
 size_t th_pixtex_bytes(int V, long long P);
-int th_pixtex_launch(const float* map, int V, int H, int W, const ThPointSrc* ps, const int32_t* sel, int P, const float* cams,
+int th_pixtex_launch(int V, int H, int W, const ThPointSrc* ps, const int32_t* sel, int P, const float* cams,
                      const float* scale, void* out, hipStream_t s);
 // In place: the per-frame table T' [rows][256] fp32 -> [rows][256 hi | 256 lo] fp16 halves of T' * 2^k, k chosen on the
 // device so that max |T'| lands in [2^12, 2^13) (lo halves stay normal numbers); sc[0] = 2^-k, sc[1] scratch (the

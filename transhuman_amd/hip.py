@@ -48,7 +48,7 @@ class ThFrame(C.Structure):
                 ("cams", C.c_void_p), ("scale_xy", C.c_void_p), ("pixel_map_nhwc", C.c_void_p), ("V", C.c_int),
                 ("H", C.c_int), ("W", C.c_int), ("map_channels", C.c_int), ("tokens", C.c_void_p), ("centres", C.c_void_p),
                 ("rot", C.c_void_p), ("n_clusters", C.c_int), ("hull_thresh", C.c_float),
-                ("small_frame_rays", C.c_int), ("map_source", C.c_void_p)]
+                ("small_frame_rays", C.c_int), ("map_source", C.c_void_p), ("map_fold", C.c_void_p)]
 
 
 class ThMapSource(C.Structure):
@@ -71,6 +71,7 @@ SYMBOLS = {
     "th_set_vit_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_tok_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_tex_rows": (C.c_int, [C.c_void_p, C.c_int]),
+    "th_map_fold": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "th_pixel_texlist_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "th_pixel_texlist": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -584,6 +585,9 @@ class SplitMap:
         # cropped map (upsample_concat_split(box=...)): (ThMapSource, the tensors it points to); texels outside the
         # per-view box are NOT written until a frame-level call needs them (th_frame.map_source)
         self.source = source
+        # th_map_fold's output for this map ([2, V, H, W, 256] fp32; hip.map_fold), or None: frames built on the map then take
+        # the texel hand-over (th_frame.map_fold)
+        self.fold = None
 
     @property
     def box(self):
@@ -604,6 +608,18 @@ class SplitMap:
     def interleaved(self):
         """the same map as one [V,H,W,260] tensor (tests / A-B)"""
         return torch.cat([self.latents, self.rgb0], dim=-1).contiguous()
+
+
+def map_fold(net, split_map):
+    """th_map_fold: alpha_res_0 / rgb_res_0 (under the folded view_fc) / rgb_res_1 of ``net`` applied to the texels of
+    ``split_map`` (inside its crop box), on the current stream; the result is kept as ``split_map.fold``."""
+    assert isinstance(split_map, SplitMap)
+    _sync_weights(net, "mlp")
+    V, H, W = split_map.V, split_map.H, split_map.W
+    fold = torch.empty((2, V, H, W, 256), dtype=torch.float32, device=split_map.device)
+    _check(load_library().th_map_fold(ctx(split_map.device), _p(split_map), V, H, W, _p(split_map.box), _p(fold), _stream()))
+    split_map.fold = fold
+    return fold
 
 
 def map_box(verts_a, verts_b, cams, scale_xy, H, W, reach):
@@ -827,8 +843,8 @@ def pixel_gather_split(split_map, pts_world, cams, scale_xy, sel=None):
 
 
 def pixel_texlist(split_map, pts_world, cams, scale_xy, sel=None):
-    """th_pixel_texlist: K5t on its own -> dict(lists [T,4,128] int32, records [T,V,32,8] int32 (float bits / byte offsets),
-    colours [T,V,32,4] float32), T = ceil(P / 32) tiles of 32 consecutive samples."""
+    """th_pixel_texlist: K5t on its own -> dict(lists [T,4,128] int32, records [T,V,32,8] int32 (float bits / byte offsets)),
+    T = ceil(P / 32) tiles of 32 consecutive samples."""
     lib = load_library()
     assert isinstance(split_map, SplitMap)
     V, H, W = split_map.V, split_map.H, split_map.W
@@ -840,8 +856,7 @@ def pixel_texlist(split_map, pts_world, cams, scale_xy, sel=None):
     _check(lib.th_pixel_texlist(ctx(p.device), _p(split_map), V, H, W, _p(p), _p(sel), P, _p(cams), _p(scale_xy), _p(out), nb,
                                 _stream()))
     a, b = T * 512, T * 512 + T * V * 32 * 8
-    return dict(lists=out[:a].view(T, 4, 128), records=out[a:b].view(T, V, 32, 8),
-                colours=out[b:b + T * V * 32 * 4].view(torch.float32).view(T, V, 32, 4))
+    return dict(lists=out[:a].view(T, 4, 128), records=out[a:b].view(T, V, 32, 8))
 
 
 def network_forward(net, pixel_feat, viewdir, pts_smpl, centres, rot, tokens, mask=None):
@@ -1026,7 +1041,8 @@ class Frame:
         self.c = ThFrame(_p(self.verts), self.verts.shape[0], _p(self.Rh), _p(self.Th), _p(self.cams), _p(self.scale),
                          _p(self.map), V, H, W, Cc, _p(self.tokens), _p(self.centres), _p(self.rot),
                          self.centres.shape[0], hull_thresh, small_frame_rays,
-                         C.cast(C.pointer(src[0]), C.c_void_p).value if src is not None else None)
+                         C.cast(C.pointer(src[0]), C.c_void_p).value if src is not None else None,
+                         _p(getattr(pixel_map_nhwc, "fold", None)))
 
     def set_tokens(self, tokens):
         """TransHE output [V, N_c, 192] of a frame that was built without it (render_pregather runs beside TransHE)"""
@@ -1234,6 +1250,12 @@ def tex_rows_enabled(device=None):
         if d in _tex_rows:
             return _tex_rows[d]
     return os.environ.get("TH_ROWS_TEX", "1")[:1] != "0"
+
+
+def mlp_is_fused(device=None):
+    """the fused fp16-split kernel shades this device's frames (mode 1 requested and the range guard has not switched it off)"""
+    d = _dev_index(device)
+    return _user_mode.get(d, 1) == 1 and not _range_fallback.get(d)
 
 
 def set_tex_rows(on, device=None):

@@ -168,6 +168,11 @@ class Renderer:
                 map_nhwc = hip.upsample_concat_split(images, lat[0], lat[1], lat[2])
             else:
                 map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2], cw, cb)
+            # texel hand-over (hip.set_tex_rows, default): the layers that read the pixel-aligned features (cross_transformer.py
+            # :316, :334, :346) are applied to the map's texels here, once per frame -- bilinear sampling commutes with them
+            if (isinstance(map_nhwc, hip.SplitMap) and hip.tex_rows_enabled(dev) and V <= 3 and V * H * W < (1 << 22)
+                    and hip.mlp_is_fused(dev)):
+                hip.map_fold(self.net, map_nhwc)
 
             def group():
                 return hip.paint_group_nhwc(map_nhwc, batch["input_smpl_vertice"][t][0], cams, scale, viz,
