@@ -55,12 +55,17 @@ def algorithmic_mlp_flops(V, n_valid, n_pos):
     return 2.0 * (n_valid * mac_sigma + n_pos * mac_rgb)
 
 
-def executed_mlp_flops(V, n_valid, n_pos):
+def executed_mlp_flops(V, n_valid, n_pos, map_fold=False):
     """Dense MACs the fused kernel actually issues (per operand product triple counted once): the fc_0 token
     part and fc_1 are folded away, the f-consuming layers have K = 272 (260 real), and view_fc is folded over
-    feature_fc / rgb_res_0 (128-wide products on inter, f and the 32-wide view-direction rows)."""
-    row_sigma = 384 * 256 + 256 * 272 + 384 * 256 + 256 * 256            # kv1, alpha_res_0', kv0, fc_2
-    row_rgb = 128 * 256 + 128 * 32 + 256 * 272                          # (Wa F), Wd, stacked [Wa R0' ; rgb_res_1']
+    feature_fc / rgb_res_0 (128-wide products on inter, f and the 32-wide view-direction rows).  map_fold (TH_ROWS_TEX): the
+    three layers that read f (alpha_res_0', [Wa R0' ; rgb_res_1']) are applied to the map's texels once per frame
+    (map_fold_kernel: 512 x 272 MACs per texel of the cropped map -- not counted here, < 1 % of the frame) and the fused kernel
+    blends their outputs instead of multiplying."""
+    f_sigma = 0 if map_fold else 256 * 272
+    f_rgb = 0 if map_fold else 256 * 272
+    row_sigma = 384 * 256 + f_sigma + 384 * 256 + 256 * 256             # kv1, alpha_res_0', kv0, fc_2
+    row_rgb = 128 * 256 + 128 * 32 + f_rgb                              # (Wa F), Wd, stacked [Wa R0' ; rgb_res_1']
     mac_sigma = V * row_sigma + 256 * 64 + 256 * 256                      # + fc_0 PE part, fc_3 (per sample)
     mac_rgb = V * row_rgb + 128 * 128                                     # + fc_4
     return 2.0 * (n_valid * mac_sigma + n_pos * mac_rgb)
@@ -82,7 +87,7 @@ def hbm_traffic():
         return None
 
 
-def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_step=None, n_valid=0):
+def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_step=None, n_valid=0, folded_flops=0.0):
     """Dominant kernel = the per-point MLP.  `achieved` counts ALGORITHMIC fp32 FLOPs (the reference's
     layer shapes).  mode 1 (default): the fused kernel evaluates every fp32 MAC as three fp16 MFMA MACs
     (hi*hi + hi*lo + lo*hi, fp32 accumulate), so the pipe it is bound by is the fp16 MFMA pipe at one third
@@ -90,8 +95,9 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
     if mlp_mode == 1:
         peak = MFMA_F16_PEAK / 3.0
         from transhuman_amd import hip as _hip
-        kernel = ("mlp_fused_kernel<3,1,true> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16; TH_ROWS_TEX: the pixel-feature operand "
-                  "is blended inside the kernel from texels of the map), rank 0" if _hip.tex_rows_enabled() else
+        kernel = ("mlp_fused_kernel<3,1,true> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16; TH_ROWS_TEX: alpha_res_0 / rgb_res_0 / "
+                  "rgb_res_1 are applied to the map's texels once per frame (map_fold_kernel) and the kernel blends texel rows of "
+                  "the folded maps: the ALGORITHMIC FLOPs still count those layers per sample), rank 0" if _hip.tex_rows_enabled() else
                   "mlp_fused_kernel<3,1> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0")
     else:
         peak = MFMA_F32_PEAK
@@ -106,6 +112,11 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
                              f", measured on a launch of {t['launch_samples']} samples); algorithmic " +
                              f"{t['mlp_fused_algorithmic_bytes_per_launch'] * per_launch:.3g} (" + t["algorithmic_note"] + ")") if t else
                             "no committed PMC pass (profiles/hbm_traffic.json absent)",
+            # TH_ROWS_TEX: alpha_res_0 / rgb_res_0 / rgb_res_1 (cross_transformer.py:316, :334, :346; 98 304 + 147 456 MAC per (sample,
+            # view) in the reference) are evaluated per TEXEL by map_fold_kernel, not by this kernel: the same figure with their
+            # algorithmic FLOPs taken out of the numerator -- what the kernel achieves on the layers it still multiplies
+            "frac_without_folded_layers": ((flops_step - folded_flops) / max(stage_ms * 1e-3, 1e-12) / peak) if folded_flops else None,
+            "folded_flop_per_step": folded_flops or None,
             "frac_of_fp32_mfma_peak": achieved / MFMA_F32_PEAK,
             # the same ALGORITHMIC number against the raw dense fp16 MFMA peak (what a reader who does not accept the /3 sees)
             "frac_of_fp16_mfma_peak": achieved / MFMA_F16_PEAK,
@@ -136,8 +147,8 @@ def texel_handover_block(V, n_valid, gather_ms):
     hbm = (t["pixgather_bytes_per_launch"] * n_valid / t["launch_samples"]) if t and "pixtex" in t.get("gather_kernel", "") else None
     return {"kernel": f"pixtex_kernel<{V}> (K5t: per-tile texel lists + per-row records; the rows are blended inside the fused kernel)",
             "ms_per_step": gather_ms,
-            "bytes_written_per_step": float(n_valid) * V * 48 + tiles * 512.0,
-            "bytes_per_sample": V * 48 + 16,
+            "bytes_written_per_step": float(n_valid) * V * 32 + tiles * 512.0,
+            "bytes_per_sample": V * 32 + 16,
             "hbm_bytes_per_step_pmc": hbm,
             "row_handover": "TH_ROWS_TEX",
             "replaces": "pixgather_s256_kernel (K5): 3 x 1088 B per sample written to HBM and read back twice; TH_ROWS_TEX=0 "
@@ -664,7 +675,8 @@ def main():
                 "map_crop": os.environ.get("TH_MAP_CROP") != "0",      # pixel map written inside the hull's texel box only
             },
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
-                                       mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos), n_valid=n_valid),
+                                       mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos, map_fold=args.mlp_mode == 1 and hip.tex_rows_enabled(dev)), n_valid=n_valid,
+                                       folded_flops=(2.0 * V * (98304.0 * n_valid + 147456.0 * n_pos)) if (args.mlp_mode == 1 and hip.tex_rows_enabled(dev)) else 0.0),
             "gather": (texel_handover_block if hip.tex_rows_enabled(dev) else gather_block)(V, n_valid, prof["gather"][0] / max(args.steps, 1)),
             # what the range guard of the fp16 hi/lo split has switched on this device (every entry false = the fast paths
             # ran; a tripped MLP guard means per-layer fp32 launches, ~7x slower frames) + the last table read (fp16 bit

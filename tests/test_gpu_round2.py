@@ -450,16 +450,24 @@ def test_split_map_equals_interleaved_map(hip, gpu, net):
     assert isinstance(f_split.map, hip.SplitMap) and tuple(f_int.map.shape[-1:]) == (260,)
     assert torch.equal(f_split.map.interleaved(), f_int.map)
     assert torch.equal(g_split, r.last_grouped) and torch.equal(f_split.tokens, f_int.tokens)
+    # (row hand-over on both maps: the split map's default, the texel hand-over with folded maps, rounds in another order -- the
+    # last block compares it with the interleaved map's rows to 1e-5)
     for mode in (1, 0):
         hip.set_mlp_mode(mode)
+        hip.set_tex_rows(False)
         try:
             a = r.render_fast(b, frame=f_split)
             c = r.render_fast(b, frame=f_int)
         finally:
             hip.set_mlp_mode(1)
+            hip.set_tex_rows(True)
         assert r.last_stats["valid_samples"] > 5000
         for k in ("rgb_map", "acc_map", "depth_map"):
             assert torch.equal(a[k], c[k]), (mode, k)
+    assert f_split.map.fold is not None
+    a = r.render_fast(b, frame=f_split)
+    for k in ("rgb_map", "acc_map", "depth_map"):
+        assert maxdiff(a[k].cpu(), c[k].cpu()) < 1e-5, k
     # gathered rows: 260-wide rows from the split map == rows from the interleaved map (incl. border clamping)
     pts = torch.randn(500, 3, device=gpu) * 0.5 + torch.tensor([0.0, 0.1, 3.0], device=gpu)
     cams = hip.pack_cams(b["input_R"][0][0], b["input_T"][0][0], b["input_K"][0][0])

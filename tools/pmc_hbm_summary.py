@@ -56,10 +56,10 @@ def main():
         except (NameError, KeyError, ValueError):
             pass
         if tex:
-            alg = ch * (256 + 64 + V * 48) + ch // 32 * 1024 + V * hw * 1040
-            note = ("positional encoding 256 B, neighbour record 64 B, three 48-byte texel records per sample + a 512 B token header "
-                    "and a 512 B texel list per 32-sample tile + every texel of the map once (V x H x W x 1040 B: an upper bound, "
-                    "the map is cropped to the hull)")
+            alg = ch * (256 + 64 + V * 32) + ch // 32 * 1024 + 2 * V * hw * 1024
+            note = ("positional encoding 256 B, neighbour record 64 B, three 32-byte texel records per sample + a 512 B token header "
+                    "and a 512 B texel list per 32-sample tile + every texel of the two folded maps once (2 x V x H x W x 1 KiB: an "
+                    "upper bound, the maps are cropped to the hull)")
         else:
             alg = ch * (V * 1088 + 256 + 64) + ch // 32 * 512
             note = ("pixel-feature rows once (3 x 1088 B), positional encoding 256 B, neighbour record 64 B per sample + a 512 B "
