@@ -355,11 +355,11 @@ int th_map_fold_launch(const FusedParams& base, const float* map_split, int V, i
     p.range = range;
     static bool attr = false;
     if (!attr) {
-        TH_HIP(hipFuncSetAttribute((const void*)map_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 96 * STR272));
+        TH_HIP(hipFuncSetAttribute((const void*)map_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MF_TEX * STR272));
         attr = true;
     }
-    const int tpr = (W + 95) / 96;
-    hipLaunchKernelGGL(map_fold_kernel, dim3((unsigned)(V * H * tpr)), dim3(256), 2 * 96 * STR272, s, p);
+    const int tpr = (W + MF_TEX - 1) / MF_TEX;
+    hipLaunchKernelGGL(map_fold_kernel, dim3((unsigned)(V * H * tpr)), dim3(256), 2 * MF_TEX * STR272, s, p);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -1567,12 +1567,29 @@ struct MapFoldParams {
     unsigned int* range;           // TH_RANGE_F takes max |hi half| of the texels that are split
 };
 
+// MF_RT row tiles of 32 texels per workgroup.  Measured on the headline frame's boxes (342 k texels, tools/fold_time.py): 3 (96
+// texels, one workgroup per CU) 0.55 ms; 2 (64 texels, two workgroups per CU, meant to overlap one's staging with the other's
+// GEMMs) 0.65 ms -- the launch is bound by the weight stream, 557 KB per workgroup out of L2 whatever its row count (timing
+// builds -DMF_EXP: stores 0.20 ms, the two GEMMs 0.28 ms, staging + launch 0.17 ms, additive), so more rows per workgroup win.
+// timing builds only (wrong maps): -DMF_EXP=1 no stores, -DMF_EXP=2 four k-blocks instead of 17 in both GEMMs
+#if defined(MF_EXP) && MF_EXP == 1
+#define MF_STORE(c) ((c) && P.V > 1000)
+#else
+#define MF_STORE(c) (c)
+#endif
+#if defined(MF_EXP) && MF_EXP == 2
+#define MF_KB 4
+#else
+#define MF_KB 17
+#endif
+#define MF_RT 3
+#define MF_TEX (32 * MF_RT)
 __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* hi_pl = lds;
-    char* lo_pl = lds + 96 * STR272;
+    char* lo_pl = lds + MF_TEX * STR272;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tpr = (P.W + 95) / 96;
+    const int tpr = (P.W + MF_TEX - 1) / MF_TEX;
     const int v = blockIdx.x / (P.H * tpr), rem = blockIdx.x - v * (P.H * tpr);
     const int y = rem / tpr, xt = rem - y * tpr;
     int x0 = 0, x1 = P.W - 1;
@@ -1581,16 +1598,16 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
         x1 = P.box[4 * v + 2];
         if (y < P.box[4 * v + 1] || y > P.box[4 * v + 3]) return;
     }
-    const int xs = x0 + xt * 96;
+    const int xs = x0 + xt * MF_TEX;
     if (xs > x1) return;
     const long long trow = ((long long)v * P.H + y) * P.W;      // texel index of (v, y, 0)
     unsigned rmax = 0u;
     const unsigned seen_f = P.range ? P.range[TH_RANGE_F] : 0u;
-    // ---- the 96 texels as fp16 hi / lo planes [texel][272] (texels past the box's edge: the edge texel again, never stored)
+    // ---- the MF_TEX texels as fp16 hi / lo planes [texel][272] (texels past the box's edge: the edge texel again, never stored)
     {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll 4
-        for (int k = 0; k < 24; ++k) {
+        for (int k = 0; k < MF_TEX / 4; ++k) {
             const int r = wv + 4 * k;
             const long long t = trow + min(xs + r, x1);
             const float4 q = *reinterpret_cast<const float4*>(P.lat + t * 256 + 4 * lane);
@@ -1602,7 +1619,7 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
             *reinterpret_cast<uint2*>(hi_pl + r * STR272 + lane * 8) = h;
             *reinterpret_cast<uint2*>(lo_pl + r * STR272 + lane * 8) = l;
         }
-        if (tid < 96) {                 // channels 256..258 = r g b, 259..271 = 0
+        if (tid < MF_TEX) {             // channels 256..258 = r g b, 259..271 = 0
             const long long t = trow + min(xs + tid, x1);
             const float4 c = *reinterpret_cast<const float4*>(P.rgb + t * 4);
             uint4 th = make_uint4(0u, 0u, 0u, 0u), tl = make_uint4(0u, 0u, 0u, 0u);
@@ -1621,15 +1638,15 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
     __syncthreads();
     const int myrow = lane & 31;
     uint4 wk2[FM_RING_D2][2][2];
-    f32x16 acc[2][3];
+    f32x16 acc[2][MF_RT];
     // ---- alpha_res_0'
-    gemm_phase_core<3, 2, STR272, 32 * STR272, FM_RING_D2, true, 3, false>(hi_pl, lo_pl, wslice(P.ar0, wave, 2, 0), 17, lane, acc, wk2);
+    gemm_phase_core<MF_RT, 2, STR272, 32 * STR272, FM_RING_D2, true, 3, false>(hi_pl, lo_pl, wslice(P.ar0, wave, 2, 0), MF_KB, lane, acc, wk2);
     {
         const float sc = P.ar0.inv_scale;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < MF_RT; ++r) {
             const int x = xs + r * 32 + myrow;
-            if (x <= x1) {
+            if (MF_STORE(x <= x1)) {
                 float* o = P.out0 + (trow + x) * 256 + wave * 64 + 4 * (lane >> 5);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
@@ -1641,13 +1658,13 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
         }
     }
     // ---- stacked [Wa rgb_res_0' ; rgb_res_1']: column tile 0 = this wave's 32 of the 128 view_fc outputs, tile 1 = its 32 of rgb_res_1
-    gemm_phase_core<3, 2, STR272, 32 * STR272, FM_RING_D2, true, 3, false>(hi_pl, lo_pl, wslice(P.rst, wave, 2, 0), 17, lane, acc, wk2);
+    gemm_phase_core<MF_RT, 2, STR272, 32 * STR272, FM_RING_D2, true, 3, false>(hi_pl, lo_pl, wslice(P.rst, wave, 2, 0), MF_KB, lane, acc, wk2);
     {
         const float s0 = P.rst.inv_scale, s1 = P.rst.inv_scale2;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < MF_RT; ++r) {
             const int x = xs + r * 32 + myrow;
-            if (x <= x1) {
+            if (MF_STORE(x <= x1)) {
                 float* o = P.out12 + (trow + x) * 256 + wave * 32 + 4 * (lane >> 5);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
