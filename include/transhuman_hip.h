@@ -228,8 +228,11 @@ int th_upsample_concat_split(th_ctx* ctx, const float* img, const float* lat0, c
  * so their extrema over a cube in front of the camera sit at corners), in the texel coordinates of grid_sample
  * (align_corners=True, scale_xy as in th_pixel_gather), widened by two texels and clamped to the image (border padding
  * clamps monotonically); the whole image for a view with a cube corner at or behind its camera plane.
- * th_upsample_concat_split_box writes only the 64-texel spans of `out` that meet the box (box == NULL: everything); the
- * rest of `out` stays as it was.  No host synchronisation: the box lives on the device. */
+ * Behind the V boxes box_out also receives, per view and image row, the SPAN [x0, x1] (inclusive; x1 < x0: empty row) of
+ * the vertices' own projected boxes that touch the row -- the body's outline inside the box, about half of it: box_out holds
+ * V * 4 + V * H * 2 int32 (H <= 4096).  th_upsample_concat_split_box writes only the 64-texel runs of `out` that meet their
+ * row's span (box == NULL: everything), th_map_fold only the texels inside it; the rest of `out` stays as it was.  No host
+ * synchronisation: boxes and spans live on the device. */
 int th_map_box(th_ctx* ctx, const float* verts_a, int na, const float* verts_b, int nb, const float* cams, int V,
                const float* scale_xy, int H, int W, float reach, int32_t* box_out, th_stream stream);
 int th_upsample_concat_split_box(th_ctx* ctx, const float* img, const float* lat0, const float* lat1, const float* lat2,
@@ -317,8 +320,8 @@ int th_pixel_gather_split(th_ctx* ctx, const float* map_split, int V, int H, int
  * cross_transformer.py:316, :334, :346 -- applied to the TEXELS of a TH_MAP_SPLIT map instead of to every (sample, view) row:
  * they are linear and act directly on grid_sample's bilinear blends (if_clight_renderer.py:255-265), so they commute with the
  * sampling.  fold [2][V,H,W,256] fp32: plane 0 = alpha_res_0' texel, plane 1 = [Wa rgb_res_0' (128) | rgb_res_1' (128)] texel
- * (no biases; the colour lift is inside, th_mlp_weights.upsample_color).  box: device int32 [V][4] (th_map_box) -> only texels
- * inside each view's box are computed, or NULL: the whole map.  Once per frame, after th_set_mlp_weights; th_frame.map_fold. */
+ * (no biases; the colour lift is inside, th_mlp_weights.upsample_color).  box: th_map_box's output (boxes + row spans) -> only
+ * texels inside each row's span are computed, or NULL: the whole map.  Once per frame, after th_set_mlp_weights; th_frame.map_fold. */
 int th_map_fold(th_ctx* ctx, const float* map_split, int V, int H, int W, const int32_t* box, float* fold, th_stream stream);
 
 /* K5t, the producer of the texel hand-over (th_set_tex_rows; k_pixtex.hip), on its own -- exposed for tests.  Samples are taken
@@ -432,7 +435,7 @@ int th_view_embed(th_ctx* ctx, const float* ray_d, int R, int view_res, float* o
  * gather -- when a call leaves the crop's premise: the un-masked branch (R' <= small_frame_rays shades EVERY sample of
  * the hit rays), hull_thresh < 0 (no hull test) or hull_thresh > reach. */
 typedef struct {
-    const int32_t* box;            /* device [V][4], th_map_box                */
+    const int32_t* box;            /* device [V][4] + [V][H][2], th_map_box    */
     float          reach;          /* the reach the box was computed with      */
     const float*   img;            /* arguments of th_upsample_concat_split    */
     const float*   lat0;

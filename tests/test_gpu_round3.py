@@ -176,16 +176,25 @@ def test_cropped_map_holds_every_texel_the_frame_reads(hip, gpu, net, focal, hw)
     assert f_crop.map.box is not None and f_full.map.box is None and torch.equal(g_crop, r.last_grouped)
     assert torch.equal(f_crop.tokens, f_full.tokens)
     box = f_crop.map.box.cpu().numpy()
+    spans = hip.map_spans(f_crop.map.box, H).cpu()                  # [V,H,2]: the rows' own spans inside the box (round 4)
     lat_c, lat_f, rgb_c, rgb_f = f_crop.map.latents, f_full.map.latents, f_crop.map.rgb0, f_full.map.rgb0
-    area = 0
+    area, span_area = 0, 0
+    xs = torch.arange(W)[None, :]
     for v in range(3):
         x0, y0, x1, y1 = (int(t) for t in box[v])
         assert 0 <= x0 <= x1 <= W - 1 and 0 <= y0 <= y1 <= H - 1
-        assert torch.equal(lat_c[v, y0:y1 + 1, x0:x1 + 1], lat_f[v, y0:y1 + 1, x0:x1 + 1])
-        assert torch.equal(rgb_c[v, y0:y1 + 1, x0:x1 + 1], rgb_f[v, y0:y1 + 1, x0:x1 + 1])
+        inside = (xs >= spans[v, :, 0:1]) & (xs <= spans[v, :, 1:2])            # [H,W]
+        inside[:y0] = False
+        inside[y1 + 1:] = False
+        assert bool(inside.any()) and bool((inside[:, :x0] == False).all()) and bool((inside[:, x1 + 1:] == False).all())
+        m = inside.to(gpu)
+        assert torch.equal(lat_c[v][m], lat_f[v][m]) and torch.equal(rgb_c[v][m], rgb_f[v][m])
         area += (x1 - x0 + 1) * (y1 - y0 + 1)
+        span_area += int(inside.sum())
     if focal == 600.0:
         assert area < 0.6 * 3 * H * W                       # the crop is worth something on the headline frame
+        assert span_area < 0.8 * area                       # ... and the row spans on top of the box
+    print("box area", area, "span area", span_area, "of", 3 * H * W)
     # every valid sample's corner texels and the painted vertices' lie inside the box
     S = get_cfg_samples()
     pts = hip.Points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], n_samples=S)
@@ -198,6 +207,9 @@ def test_cropped_map_holds_every_texel_the_frame_reads(hip, gpu, net, focal, hw)
         for v, (xa, xb, ya, yb) in enumerate(_texel_use(b, f_crop, cloud, H, W)):
             x0, y0, x1, y1 = (int(q) for q in box[v])
             assert xa.min() >= x0 and xb.max() <= x1 and ya.min() >= y0 and yb.max() <= y1, (v, box[v])
+            sp = spans[v].to(xa.device)
+            for yy in (ya.long(), yb.long()):                 # both texel rows of every gather inside their rows' spans
+                assert bool((xa.long() >= sp[yy, 0]).all()) and bool((xb.long() <= sp[yy, 1]).all()), v
     a = r.render_fast(b, frame=f_crop)
     c = r.render_fast(b, frame=f_full)
     assert r.last_stats["valid_samples"] > 1000

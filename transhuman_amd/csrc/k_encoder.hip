@@ -48,8 +48,11 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
     const int x = blockIdx.x * 64 + lane, y = blockIdx.y;
     const int v = blockIdx.z / NG, grp = blockIdx.z % NG;
     if (box != nullptr) {               // cropped map (map_box_kernel): 64-pixel spans outside the view's box are not written
-        const int bx0 = box[4 * v], by0 = box[4 * v + 1], bx1 = box[4 * v + 2], by1 = box[4 * v + 3];
-        if (y < by0 || y > by1 || (int)blockIdx.x * 64 + 63 < bx0 || (int)blockIdx.x * 64 > bx1) return;
+        const int by0 = box[4 * v + 1], by1 = box[4 * v + 3];
+        if (y < by0 || y > by1) return;
+        // (the row's own span [x0, x1] behind the boxes: a tighter outline of the body than the box)
+        const int32_t* sp = box + 4 * (gridDim.z / NG) + ((long long)v * H + y) * 2;
+        if ((int)blockIdx.x * 64 + 63 < sp[0] || (int)blockIdx.x * 64 > sp[1]) return;
     }
     int cout0;
     if (grp == 4 && NG == 5) {          // compact map: channels 256..259 = r, g, b, 0 (one float4 per pixel)
@@ -124,9 +127,16 @@ __global__ __launch_bounds__(1024) void map_box_kernel(const float* __restrict__
     const float* cam = cams + 21 * v;
     float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
     bool bad = false;
+    // per image row the span [x0, x1] of the projected cubes that touch it (LDS, H <= 4096): the union of the vertices' own
+    // boxes row by row -- every gather within reach of a vertex reads inside that vertex's box, hence inside its rows' spans
+    extern __shared__ int span_l[];                 // [H][2]
+    for (int i = tid; i < H; i += 1024) { span_l[2 * i] = W; span_l[2 * i + 1] = -1; }
+    __syncthreads();
     for (int i = tid; i < na + nb; i += 1024) {
         const float* p = i < na ? va + 3 * i : vb + 3 * (i - na);
         const float x = p[0], y = p[1], z = p[2];
+        float vx0 = 3.0e38f, vx1 = -3.0e38f, vy0 = 3.0e38f, vy1 = -3.0e38f;
+        bool vbad = false;
         for (int k = 0; k < 8; ++k) {
             const float qx = x + ((k & 1) ? reach : -reach), qy = y + ((k & 2) ? reach : -reach),
                         qz = z + ((k & 4) ? reach : -reach);
@@ -139,9 +149,22 @@ __global__ __launch_bounds__(1024) void map_box_kernel(const float* __restrict__
             th_project(cam, qx, qy, qz, u, w);
             const float ix = ((u * scale[0] - 1.0f + 1.0f) / 2.0f) * (float)(W - 1);
             const float iy = ((w * scale[1] - 1.0f + 1.0f) / 2.0f) * (float)(H - 1);
-            if (!(pz > 1e-6f) || !(fabsf(ix) < 1.0e9f) || !(fabsf(iy) < 1.0e9f)) bad = true;
-            xmin = fminf(xmin, ix); xmax = fmaxf(xmax, ix);
-            ymin = fminf(ymin, iy); ymax = fmaxf(ymax, iy);
+            if (!(pz > 1e-6f) || !(fabsf(ix) < 1.0e9f) || !(fabsf(iy) < 1.0e9f)) vbad = true;
+            vx0 = fminf(vx0, ix); vx1 = fmaxf(vx1, ix);
+            vy0 = fminf(vy0, iy); vy1 = fmaxf(vy1, iy);
+        }
+        bad = bad || vbad;
+        xmin = fminf(xmin, vx0); xmax = fmaxf(xmax, vx1);
+        ymin = fminf(ymin, vy0); ymax = fmaxf(ymax, vy1);
+        if (!vbad) {            // this vertex's box (same widening and clamping as the view's box below) into its rows' spans
+            const int ax0 = (int)fminf(fmaxf(floorf(vx0) - 2.0f, 0.0f), (float)(W - 1));
+            const int ax1 = (int)fminf(fmaxf(floorf(vx1) + 3.0f, 0.0f), (float)(W - 1));
+            const int ay0 = (int)fminf(fmaxf(floorf(vy0) - 2.0f, 0.0f), (float)(H - 1));
+            const int ay1 = (int)fminf(fmaxf(floorf(vy1) + 3.0f, 0.0f), (float)(H - 1));
+            for (int yy = ay0; yy <= ay1; ++yy) {
+                atomicMin(&span_l[2 * yy], ax0);
+                atomicMax(&span_l[2 * yy + 1], ax1);
+            }
         }
     }
     __shared__ float red[4][16];
@@ -170,10 +193,20 @@ __global__ __launch_bounds__(1024) void map_box_kernel(const float* __restrict__
         }
         box[4 * v] = x0; box[4 * v + 1] = y0; box[4 * v + 2] = x1; box[4 * v + 3] = y1;
     }
+    __syncthreads();
+    // spans behind the gridDim.x boxes: [V][H][2]; a view whose box is the whole image (a cube behind the camera) gets full rows
+    int32_t* sp = box + 4 * gridDim.x + (long long)v * H * 2;
+    const bool full = sbad != 0 || na + nb <= 0;
+    for (int i = tid; i < H; i += 1024) {
+        sp[2 * i] = full ? 0 : span_l[2 * i];
+        sp[2 * i + 1] = full ? W - 1 : span_l[2 * i + 1];
+    }
 }
 int th_map_box_launch(const float* va, int na, const float* vb, int nb, const float* cams, int V, const float* scale, int H,
                       int W, float reach, int32_t* box, hipStream_t s) {
-    hipLaunchKernelGGL(map_box_kernel, dim3(V), dim3(1024), 0, s, va, na, vb, nb, cams, scale, H, W, reach, box);
+    TH_REQUIRE(H <= 4096, "th_map_box: at most 4096 image rows (row spans in LDS)");
+    hipLaunchKernelGGL(map_box_kernel, dim3(V), dim3(1024), (size_t)H * 2 * sizeof(int), s, va, na, vb, nb, cams, scale, H, W, reach,
+                       box);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -1593,10 +1593,11 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
     const int v = blockIdx.x / (P.H * tpr), rem = blockIdx.x - v * (P.H * tpr);
     const int y = rem / tpr, xt = rem - y * tpr;
     int x0 = 0, x1 = P.W - 1;
-    if (P.box != nullptr) {
-        x0 = P.box[4 * v];
-        x1 = P.box[4 * v + 2];
+    if (P.box != nullptr) {             // th_map_box: [V][4] boxes, then [V][H][2] row spans (empty rows: x1 < x0)
         if (y < P.box[4 * v + 1] || y > P.box[4 * v + 3]) return;
+        const int32_t* sp = P.box + 4 * P.V + ((long long)v * P.H + y) * 2;
+        x0 = sp[0];
+        x1 = sp[1];
     }
     const int xs = x0 + xt * MF_TEX;
     if (xs > x1) return;

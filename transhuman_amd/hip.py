@@ -629,10 +629,19 @@ def map_box(verts_a, verts_b, cams, scale_xy, H, W, reach):
     a = _f32(verts_a).reshape(-1, 3)
     b = _f32(verts_b).reshape(-1, 3) if verts_b is not None else None
     V = cams.shape[0]
-    box = torch.empty((V, 4), dtype=torch.int32, device=a.device)
+    # [V,4] boxes followed by [V,H,2] row spans (x0, x1 of every image row: the outline of the body inside the box); the
+    # returned tensor is the [V,4] head of that buffer, `map_spans(box, H)` views the rest
+    buf = torch.empty(V * 4 + V * int(H) * 2, dtype=torch.int32, device=a.device)
+    box = buf[: V * 4].view(V, 4)
     _check(lib.th_map_box(ctx(a.device), _p(a), a.shape[0], _p(b), b.shape[0] if b is not None else 0, _p(cams), V,
                           _p(scale_xy), int(H), int(W), float(reach), _p(box), _stream()))
     return box
+
+
+def map_spans(box, H):
+    """the [V,H,2] row spans (x0, x1 inclusive; x1 < x0: empty row) th_map_box wrote behind the boxes of ``box``"""
+    V = box.shape[0]
+    return torch.as_strided(box, (V, int(H), 2), (int(H) * 2, 2, 1), storage_offset=box.storage_offset() + V * 4)
 
 
 def upsample_concat_split(images, lat0, lat1, lat2, box=None, reach=0.0):
