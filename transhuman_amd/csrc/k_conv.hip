@@ -274,11 +274,9 @@ static int conv_launch_t(const float* x, const uint4* wp, float inv_scale, float
     constexpr size_t lds = (size_t)2 * IR * IC * STRB;
     static_assert(lds <= 160 * 1024, "input tile does not fit in LDS");
     auto kern = conv_mfma_kernel<CIN, COUT, S, KS, TR, WC>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0ull;
+    if (th_lds_attr_needed(&attr_done))
         TH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
     dim3 grid(th_cdiv(Wo, 32), th_cdiv(Ho, TR), N);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo, range);
     TH_LAUNCH_CHECK();
@@ -379,11 +377,9 @@ static int conv1_launch(const float* x, const uint4* wp, float inv_scale, float*
                         unsigned* range,
                         hipStream_t s) {
     constexpr size_t lds = (size_t)2 * C1_TR * 32 * C1_STRB + 3 * C1_IR * C1_IC * 4 + 16 * C1_KB * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0ull;
+    if (th_lds_attr_needed(&attr_done))
         TH_HIP(hipFuncSetAttribute((const void*)conv1_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
     dim3 grid(th_cdiv(Wo, 32), th_cdiv(Ho, C1_TR), N);
     hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo, range);
     TH_LAUNCH_CHECK();

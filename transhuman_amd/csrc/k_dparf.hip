@@ -455,11 +455,10 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
     if (ps) src = *ps; else { src = ThPointSrc{}; }
     size_t lds = ((size_t)((nc * 3 + 3) & ~3)) * sizeof(float) + DP_SAMPLES * sizeof(DpNbr) + 2 * 4 * 128 * sizeof(unsigned);
     TH_REQUIRE(lds <= 160 * 1024, "too many token centres for LDS staging");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_set = 0ull;
+    if (th_lds_attr_needed(&attr_set)) {
         TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
     }
     TH_REQUIRE(fmt == TH_ROWS_F32 || ((fmt == TH_ROWS_FOLDED || fmt == TH_ROWS_NBR) && pe_out != nullptr),
                "K4 writes fp32 rows, the folded form or neighbour records");
@@ -474,19 +473,15 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
     }
     static const bool per_view = getenv("TH_DPARF_PER_VIEW") != nullptr;       // A/B switch
     if (fmt == TH_ROWS_NBR) {
-        static bool attrn = false;
-        if (!attrn) {
+        static unsigned long long attrn = 0ull;
+        if (th_lds_attr_needed(&attrn))
             TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attrn = true;
-        }
         hipLaunchKernelGGL((dparf_kernel<true, -1>), dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
                            Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out, gi, cnt, cand);
     } else if (fmt == TH_ROWS_FOLDED && V == 3 && !per_view) {
-        static bool attr3 = false;
-        if (!attr3) {
+        static unsigned long long attr3 = 0ull;
+        if (th_lds_attr_needed(&attr3))
             TH_HIP(hipFuncSetAttribute((const void*)dparf_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr3 = true;
-        }
         hipLaunchKernelGGL((dparf_kernel<true, 3>), dim3(th_cdiv(P, DP_SAMPLES)), dim3(DP_THREADS), lds, s, pts_smpl, src, Rh,
                            Th, sel, P, centres, rot, tokens, V, nc, alpha, out, pe_out, gi, cnt, cand);
     } else if (fmt == TH_ROWS_FOLDED)

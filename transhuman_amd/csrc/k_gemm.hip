@@ -582,8 +582,8 @@ int th_gemm_h3(const float* A, int lda, int M, const ThPacked& W, const float* l
     }
     TH_REQUIRE((lda & 3) == 0 && (((uintptr_t)A) & 15) == 0, "A must be 16-byte aligned with lda % 4 == 0");
     const int KP = W.KB32 * 32;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr = 0ull;
+    if (th_lds_attr_needed(&attr)) {
         const int mx = 2 * 16 * 4 * (2 * 256 + 16), mx2 = 2 * 16 * 2 * (2 * 768 + 16);
         TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2));
         TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2));
@@ -591,7 +591,6 @@ int th_gemm_h3(const float* A, int lda, int M, const ThPacked& W, const float* l
         TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, mx2));
         TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
         TH_HIP(hipFuncSetAttribute((const void*)gemm_h3_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, mx));
-        attr = true;
     }
     // rows per workgroup: 16 (RT = 1).  Larger tiles re-read the weights less often (RT = 2 / 4: half / a quarter of the
     // 41-55 MB of L2 traffic per GEMM of the ViT) but were measured SLOWER at V N_c = 900 .. 4500 rows (0.79 / 0.86 /

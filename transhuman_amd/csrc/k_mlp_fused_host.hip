@@ -353,11 +353,9 @@ int th_map_fold_launch(const FusedParams& base, const float* map_split, int V, i
     p.box = box; p.V = V; p.H = H; p.W = W;
     p.out0 = fold; p.out12 = fold + (size_t)V * H * W * 256;
     p.range = range;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr_done = 0ull;
+    if (th_lds_attr_needed(&attr_done))
         TH_HIP(hipFuncSetAttribute((const void*)map_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MF_TEX * STR272));
-        attr = true;
-    }
     const int tpr = (W + MF_TEX - 1) / MF_TEX;
     hipLaunchKernelGGL(map_fold_kernel, dim3((unsigned)(V * H * tpr)), dim3(256), 2 * MF_TEX * STR272, s, p);
     TH_LAUNCH_CHECK();
@@ -389,8 +387,8 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
         f = nullptr;
     }
     p.stok = stok; p.pe = (const _Float16*)pe; p.f = (const _Float16*)f; p.vd = vd; p.vd_sel = vd_sel; p.vd_div = vd_div > 0 ? vd_div : 1; p.raw_c = raw_c; p.P = P; p.rgb_all = rgb_all; p.range = range;
-    static bool attr = false;
-    if (!attr) {
+    static unsigned long long attr_done = 0ull;
+    if (th_lds_attr_needed(&attr_done)) {
 #define FM_ATTR(V_, F_)                                                                                       \
     TH_HIP(hipFuncSetAttribute((const void*)mlp_fused_kernel<V_, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                FUSED_LDS_BYTES))
@@ -401,7 +399,6 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
                                FUSED_LDS_BYTES))
         FM_ATTR_T(1); FM_ATTR_T(2); FM_ATTR_T(3);
 #undef FM_ATTR_T
-        attr = true;
     }
     dim3 grid(tex ? 8 * th_cdiv(th_cdiv(P, FM_PTS), 8) : th_cdiv(P, FM_PTS));     // (TEX: XCD-contiguous tile order)
     // developer experiment (timing only, results are wrong): alias every layer's weights onto fc_1's image

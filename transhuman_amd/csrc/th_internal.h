@@ -291,6 +291,15 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
                          const void* pe, const void* f, int f_ld, const float* vd, const int32_t* vd_sel, int vd_div, int rgb_all,
                          float* raw_c, unsigned int* range, hipStream_t s, const void* tsplit = nullptr,
                          const float* t_inv = nullptr, int t_nc = 0, const float* tex_map = nullptr, size_t tex_stride = 0);
+// The > 64 KB dynamic-LDS attribute of a kernel belongs to the DEVICE's copy of it: set once per device, not once per process (a
+// process that drives two GPUs otherwise launches with the default limit on the second).  `done` = a static mask per call site.
+static inline bool th_lds_attr_needed(unsigned long long* done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    if ((*done >> dev) & 1ull) return false;
+    *done |= 1ull << dev;
+    return true;
+}
 // alpha_res_0 / rgb_res_0 / rgb_res_1 applied to the texels of the (cropped) split map: fold [2][V][H*W][256] (k_mlp_fused_kernel.h)
 int th_map_fold_launch(const FusedParams& base, const float* map_split, int V, int H, int W, const int32_t* box, float* fold,
                        unsigned int* range, hipStream_t s);
