@@ -659,6 +659,8 @@ def upsample_concat_split(images, lat0, lat1, lat2, box=None, reach=0.0):
         _check(lib.th_upsample_concat_split(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf), _stream()))
         return SplitMap(buf, V, H, W)
     assert box.dtype == torch.int32 and tuple(box.shape) == (V, 4) and box.is_contiguous()
+    # (th_map_box's buffer: the row spans follow the boxes)
+    assert box.untyped_storage().nbytes() - box.storage_offset() * 4 >= (V * 4 + V * H * 2) * 4, "box must come from hip.map_box"
     _check(lib.th_upsample_concat_split_box(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf),
                                             _p(box), _stream()))
     src = ThMapSource(_p(box), float(reach), _p(img), _p(l0), _p(l1), _p(l2), dims)
