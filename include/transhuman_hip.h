@@ -230,7 +230,7 @@ int th_upsample_concat_split(th_ctx* ctx, const float* img, const float* lat0, c
  * clamps monotonically); the whole image for a view with a cube corner at or behind its camera plane.
  * Behind the V boxes box_out also receives, per view and image row, the SPAN [x0, x1] (inclusive; x1 < x0: empty row) of
  * the vertices' own projected boxes that touch the row -- the body's outline inside the box, about half of it: box_out holds
- * V * 4 + V * H * 2 int32 (H <= 4096).  th_upsample_concat_split_box writes only the 64-texel runs of `out` that meet their
+ * V * 4 + V * H * 2 + V int32 (H <= 4096; the last V words are scratch of the kernels).  th_upsample_concat_split_box writes only the 64-texel runs of `out` that meet their
  * row's span (box == NULL: everything), th_map_fold only the texels inside it; the rest of `out` stays as it was.  No host
  * synchronisation: boxes and spans live on the device. */
 int th_map_box(th_ctx* ctx, const float* verts_a, int na, const float* verts_b, int nb, const float* cams, int V,

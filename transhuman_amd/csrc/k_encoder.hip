@@ -118,21 +118,36 @@ int th_upsample_concat_launch(const float* img, const float* lat0, const float* 
 // corners) their extrema sit at corners: the box of the projected corners of all cubes, in map texel coordinates (the
 // expression of th_bilinear_setup), widened by two texels for the second bilinear corner and fp32 rounding, contains
 // every texel those gathers read.  Border clamping is monotone, so clamping the box to the image keeps that true.  A cube
-// that reaches behind a camera makes that view's box the whole image.  One workgroup per view.
+// that reaches behind a camera makes that view's box the whole image.
+// Three small launches (one workgroup per view did all of it in 190 us -- on the side stream's dependent chain, which is what a rank
+// of an 8-rank job waits for): init (boxes empty, spans empty, flags 0), NB blocks per view over the vertices (block-local spans
+// in LDS, merged with integer atomics), finalise (a view with a cube at or behind its camera plane, or no vertices: whole image).
+// Buffer: [V][4] boxes, [V][H][2] spans, [V] flags.
+#define MAPBOX_NB 8
+__global__ void map_box_init_kernel(int V, int H, int W, int32_t* __restrict__ box) {
+    const int v = blockIdx.x;
+    int32_t* sp = box + 4 * V + (long long)v * H * 2;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) { sp[2 * i] = W; sp[2 * i + 1] = -1; }
+    if (threadIdx.x == 0) {
+        box[4 * v] = 0x7fffffff; box[4 * v + 1] = 0x7fffffff; box[4 * v + 2] = -1; box[4 * v + 3] = -1;
+        box[4 * V + (long long)V * H * 2 + v] = 0;
+    }
+}
 __global__ __launch_bounds__(1024) void map_box_kernel(const float* __restrict__ va, int na, const float* __restrict__ vb,
                                                        int nb, const float* __restrict__ cams,
                                                        const float* __restrict__ scale, int H, int W, float reach,
                                                        int32_t* __restrict__ box) {
-    const int v = blockIdx.x, tid = threadIdx.x;
+    const int v = blockIdx.x, V = gridDim.x, tid = threadIdx.x;
     const float* cam = cams + 21 * v;
-    float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
     bool bad = false;
     // per image row the span [x0, x1] of the projected cubes that touch it (LDS, H <= 4096): the union of the vertices' own
     // boxes row by row -- every gather within reach of a vertex reads inside that vertex's box, hence inside its rows' spans
     extern __shared__ int span_l[];                 // [H][2]
+    __shared__ int bx[4];
     for (int i = tid; i < H; i += 1024) { span_l[2 * i] = W; span_l[2 * i + 1] = -1; }
+    if (tid == 0) { bx[0] = 0x7fffffff; bx[1] = 0x7fffffff; bx[2] = -1; bx[3] = -1; }
     __syncthreads();
-    for (int i = tid; i < na + nb; i += 1024) {
+    for (int i = blockIdx.y * 1024 + tid; i < na + nb; i += 1024 * gridDim.y) {
         const float* p = i < na ? va + 3 * i : vb + 3 * (i - na);
         const float x = p[0], y = p[1], z = p[2];
         float vx0 = 3.0e38f, vx1 = -3.0e38f, vy0 = 3.0e38f, vy1 = -3.0e38f;
@@ -154,59 +169,46 @@ __global__ __launch_bounds__(1024) void map_box_kernel(const float* __restrict__
             vy0 = fminf(vy0, iy); vy1 = fmaxf(vy1, iy);
         }
         bad = bad || vbad;
-        xmin = fminf(xmin, vx0); xmax = fmaxf(xmax, vx1);
-        ymin = fminf(ymin, vy0); ymax = fmaxf(ymax, vy1);
-        if (!vbad) {            // this vertex's box (same widening and clamping as the view's box below) into its rows' spans
+        if (!vbad) {            // this vertex's box (widened by two texels for the second bilinear corner and fp32 rounding, clamped)
             const int ax0 = (int)fminf(fmaxf(floorf(vx0) - 2.0f, 0.0f), (float)(W - 1));
             const int ax1 = (int)fminf(fmaxf(floorf(vx1) + 3.0f, 0.0f), (float)(W - 1));
             const int ay0 = (int)fminf(fmaxf(floorf(vy0) - 2.0f, 0.0f), (float)(H - 1));
             const int ay1 = (int)fminf(fmaxf(floorf(vy1) + 3.0f, 0.0f), (float)(H - 1));
+            atomicMin(&bx[0], ax0); atomicMin(&bx[1], ay0); atomicMax(&bx[2], ax1); atomicMax(&bx[3], ay1);
             for (int yy = ay0; yy <= ay1; ++yy) {
                 atomicMin(&span_l[2 * yy], ax0);
                 atomicMax(&span_l[2 * yy + 1], ax1);
             }
         }
     }
-    __shared__ float red[4][16];
-    __shared__ int sbad;
-    if (tid == 0) sbad = 0;
+    if (bad) atomicOr(&box[4 * V + (long long)V * H * 2 + v], 1);
     __syncthreads();
-    for (int o = 32; o > 0; o >>= 1) {
-        xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
-        ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-    }
-    if (bad) atomicOr(&sbad, 1);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = xmin; red[1][tid >> 6] = xmax; red[2][tid >> 6] = ymin; red[3][tid >> 6] = ymax; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 16; ++w) {
-            xmin = fminf(xmin, red[0][w]); xmax = fmaxf(xmax, red[1][w]);
-            ymin = fminf(ymin, red[2][w]); ymax = fmaxf(ymax, red[3][w]);
+    int32_t* sp = box + 4 * V + (long long)v * H * 2;
+    for (int i = tid; i < H; i += 1024)
+        if (span_l[2 * i + 1] >= span_l[2 * i]) {
+            atomicMin(&sp[2 * i], span_l[2 * i]);
+            atomicMax(&sp[2 * i + 1], span_l[2 * i + 1]);
         }
-        int x0 = 0, y0 = 0, x1 = W - 1, y1 = H - 1;
-        if (!sbad && na + nb > 0) {
-            const float fx0 = fminf(fmaxf(floorf(xmin) - 2.0f, 0.0f), (float)(W - 1));
-            const float fx1 = fminf(fmaxf(floorf(xmax) + 3.0f, 0.0f), (float)(W - 1));
-            const float fy0 = fminf(fmaxf(floorf(ymin) - 2.0f, 0.0f), (float)(H - 1));
-            const float fy1 = fminf(fmaxf(floorf(ymax) + 3.0f, 0.0f), (float)(H - 1));
-            x0 = (int)fx0; x1 = (int)fx1; y0 = (int)fy0; y1 = (int)fy1;
-        }
-        box[4 * v] = x0; box[4 * v + 1] = y0; box[4 * v + 2] = x1; box[4 * v + 3] = y1;
+    if (tid == 0 && bx[2] >= 0) {
+        atomicMin(&box[4 * v], bx[0]); atomicMin(&box[4 * v + 1], bx[1]);
+        atomicMax(&box[4 * v + 2], bx[2]); atomicMax(&box[4 * v + 3], bx[3]);
     }
-    __syncthreads();
-    // spans behind the gridDim.x boxes: [V][H][2]; a view whose box is the whole image (a cube behind the camera) gets full rows
-    int32_t* sp = box + 4 * gridDim.x + (long long)v * H * 2;
-    const bool full = sbad != 0 || na + nb <= 0;
-    for (int i = tid; i < H; i += 1024) {
-        sp[2 * i] = full ? 0 : span_l[2 * i];
-        sp[2 * i + 1] = full ? W - 1 : span_l[2 * i + 1];
-    }
+}
+__global__ void map_box_final_kernel(int V, int H, int W, int nverts, int32_t* __restrict__ box) {
+    const int v = blockIdx.x;
+    const bool full = box[4 * V + (long long)V * H * 2 + v] != 0 || nverts <= 0 || box[4 * v + 2] < 0;
+    if (!full) return;
+    int32_t* sp = box + 4 * V + (long long)v * H * 2;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) { sp[2 * i] = 0; sp[2 * i + 1] = W - 1; }
+    if (threadIdx.x == 0) { box[4 * v] = 0; box[4 * v + 1] = 0; box[4 * v + 2] = W - 1; box[4 * v + 3] = H - 1; }
 }
 int th_map_box_launch(const float* va, int na, const float* vb, int nb, const float* cams, int V, const float* scale, int H,
                       int W, float reach, int32_t* box, hipStream_t s) {
     TH_REQUIRE(H <= 4096, "th_map_box: at most 4096 image rows (row spans in LDS)");
-    hipLaunchKernelGGL(map_box_kernel, dim3(V), dim3(1024), (size_t)H * 2 * sizeof(int), s, va, na, vb, nb, cams, scale, H, W, reach,
-                       box);
+    hipLaunchKernelGGL(map_box_init_kernel, dim3(V), dim3(256), 0, s, V, H, W, box);
+    hipLaunchKernelGGL(map_box_kernel, dim3(V, MAPBOX_NB), dim3(1024), (size_t)H * 2 * sizeof(int), s, va, na, vb, nb, cams, scale, H,
+                       W, reach, box);
+    hipLaunchKernelGGL(map_box_final_kernel, dim3(V), dim3(256), 0, s, V, H, W, na + nb, box);
     TH_LAUNCH_CHECK();
     return 0;
 }

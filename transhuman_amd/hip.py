@@ -631,7 +631,7 @@ def map_box(verts_a, verts_b, cams, scale_xy, H, W, reach):
     V = cams.shape[0]
     # [V,4] boxes followed by [V,H,2] row spans (x0, x1 of every image row: the outline of the body inside the box); the
     # returned tensor is the [V,4] head of that buffer, `map_spans(box, H)` views the rest
-    buf = torch.empty(V * 4 + V * int(H) * 2, dtype=torch.int32, device=a.device)
+    buf = torch.empty(V * 4 + V * int(H) * 2 + V, dtype=torch.int32, device=a.device)      # (+ V flag words of the kernels)
     box = buf[: V * 4].view(V, 4)
     _check(lib.th_map_box(ctx(a.device), _p(a), a.shape[0], _p(b), b.shape[0] if b is not None else 0, _p(cams), V,
                           _p(scale_xy), int(H), int(W), float(reach), _p(box), _stream()))
@@ -660,7 +660,7 @@ def upsample_concat_split(images, lat0, lat1, lat2, box=None, reach=0.0):
         return SplitMap(buf, V, H, W)
     assert box.dtype == torch.int32 and tuple(box.shape) == (V, 4) and box.is_contiguous()
     # (th_map_box's buffer: the row spans follow the boxes)
-    assert box.untyped_storage().nbytes() - box.storage_offset() * 4 >= (V * 4 + V * H * 2) * 4, "box must come from hip.map_box"
+    assert box.untyped_storage().nbytes() - box.storage_offset() * 4 >= (V * 4 + V * H * 2 + V) * 4, "box must come from hip.map_box"
     _check(lib.th_upsample_concat_split_box(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf),
                                             _p(box), _stream()))
     src = ThMapSource(_p(box), float(reach), _p(img), _p(l0), _p(l1), _p(l2), dims)
