@@ -410,3 +410,28 @@ def test_map_fold_equals_the_layers_on_the_texels(hip, gpu, net):
         for got, ref in ((m.fold[0], ref0), (m.fold[1], ref12)):
             g, e = got[v][inside].double(), ref[v][inside].detach()
             assert float((g - e).abs().max()) < 2e-5 * max(1.0, float(e.abs().max())), (v, float((g - e).abs().max()))
+
+
+def test_wave_cooperative_hull_test_equals_the_sequential_one(hip, gpu, monkeypatch):
+    """K1's hull test evaluates "a vertex within 0.1" per sample; the default form lets the whole wave test the vertices
+    of one undecided sample at a time, TH_HULL_SEQ=1 (read per launch) is the first form with one lane per sample all the
+    way.  Same predicate on the same pairs: the masks and the per-ray flags are equal bit for bit -- on a full frame,
+    S = 64 and S = 40 (waves straddling rays, a ragged last wave), explicit points incl. far outside the grid, and a
+    small and a large threshold (few / most cells of the neighbourhood in reach)."""
+    b = synth.batch_to(synth.make_batch(160, 160, 3, seed=2, all_rays=True, focal=190.0), gpu)
+    v = b["tar_smpl_vertice"][0]
+    cases = [(hip.Points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], n_samples=64), 0.1),
+             (hip.Points(b["ray_o"][0][:7001], b["ray_d"][0][:7001], b["near"][0][:7001], b["far"][0][:7001], n_samples=40), 0.1),
+             (hip.Points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], n_samples=64), 0.05),
+             (hip.Points(b["ray_o"][0][:9000], b["ray_d"][0][:9000], b["near"][0][:9000], b["far"][0][:9000], n_samples=64), 0.25)]
+    grid = synth.make_grid_pts({k: (t.cpu() if torch.is_tensor(t) else t) for k, t in b.items()}, 40).reshape(-1, 3)
+    far = torch.cat([grid, grid[:333] + 5.0, grid[:333] - 7.0]).to(gpu).contiguous()
+    cases.append((hip.Points(pts=far), 0.1))
+    for pts, thr in cases:
+        monkeypatch.delenv("TH_HULL_SEQ", raising=False)
+        m1, h1 = hip.hull_mask(pts, v, thr)
+        monkeypatch.setenv("TH_HULL_SEQ", "1")
+        m0, h0 = hip.hull_mask(pts, v, thr)
+        monkeypatch.delenv("TH_HULL_SEQ", raising=False)
+        assert int(m0.sum()) > 500 and int(m0.sum()) < m0.numel()
+        assert torch.equal(m1, m0) and torch.equal(h1, h0), (thr, int((m1 != m0).sum()))

@@ -13,7 +13,10 @@ def tm(idx, tag):
         t0=time.perf_counter(); m,h = hip.hull_mask(P, b["tar_smpl_vertice"][0]); torch.cuda.synchronize(); ts.append(time.perf_counter()-t0)
     print(tag, "rays", P.R, "hits", int(h.sum()), "valid", int(m.sum()), "ms", round(np.median(ts)*1e3,3))
 allr = torch.arange(512*512, device=dev)
-tm(allr, "full row-major")
-tm(shard_ray_indices(512,512,1,0,tile=8,tile_major=True).to(dev), "full tile-major")
+for seq in (True, False):          # TH_HULL_SEQ is read per launch: the one-lane-per-sample form, then the wave-cooperative default
+    if seq: os.environ["TH_HULL_SEQ"] = "1"
+    else: os.environ.pop("TH_HULL_SEQ", None)
+    tm(allr, "full row-major" + (" (TH_HULL_SEQ=1)" if seq else ""))
+    tm(shard_ray_indices(512,512,1,0,tile=8,tile_major=True).to(dev), "full tile-major" + (" (TH_HULL_SEQ=1)" if seq else ""))
 for r in (0,3):
     tm(shard_ray_indices(512,512,8,r,tile=8,tile_major=True).to(dev), f"shard {r}/8")

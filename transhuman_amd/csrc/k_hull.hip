@@ -153,6 +153,31 @@ __global__ void grid_bbox_kernel(const GridInfo* __restrict__ gi, const int* __r
         for (int a = 0; a < 3; ++a) { bbox[6 * c + a] = mn[a]; bbox[6 * c + 3 + a] = mx[a]; }
 }
 
+// Per cell of the grid EXTENDED by one layer (a sample one cell outside still reaches the boundary cells): the 27-bit
+// word of its non-empty neighbours, bit j = the cell at offset (j + 13) % 27 of the 3 x 3 x 3 block (bit 0 = the cell
+// itself) is inside the grid and holds a vertex.  The mask kernel screens only those; a sample in empty space reads 0.
+#define GRID_EXT_CELLS ((GRID_MAX_DIM + 2) * (GRID_MAX_DIM + 2) * (GRID_MAX_DIM + 2))
+__device__ __forceinline__ void grid_nbr_phase(const GridInfo& g, const int* __restrict__ starts, unsigned* __restrict__ nbr,
+                                               int tid, int nthreads) {
+    const int ex = g.dim[0] + 2, ey = g.dim[1] + 2, ez = g.dim[2] + 2;
+    for (int e = tid; e < ex * ey * ez; e += nthreads) {
+        const int cx = e % ex - 1, cy = (e / ex) % ey - 1, cz = e / (ex * ey) - 1;
+        unsigned m = 0u;
+        for (int j = 0; j < 27; ++j) {
+            const int o = (j + 13) % 27;
+            const int X = cx + o % 3 - 1, Y = cy + (o / 3) % 3 - 1, Z = cz + o / 9 - 1;
+            if (X >= 0 && X < g.dim[0] && Y >= 0 && Y < g.dim[1] && Z >= 0 && Z < g.dim[2]) {
+                const int c = (Z * g.dim[1] + Y) * g.dim[0] + X;
+                if (starts[c + 1] > starts[c]) m |= 1u << j;
+            }
+        }
+        nbr[e] = m;
+    }
+}
+__global__ void grid_nbr_kernel(const GridInfo* __restrict__ gi, const int* __restrict__ starts, unsigned* __restrict__ nbr) {
+    grid_nbr_phase(*gi, starts, nbr, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
 // The whole grid build as ONE single-workgroup launch (6890 vertices: 7 per thread): AABB -> GridInfo, zeroed counters,
 // per-cell counts, exclusive scan, bucket fill, per-cell bounding boxes -- the five launches above cost ~30 us alone
 // but ~80 us EACH when they have to squeeze in between the MLP tiles of a concurrent frame (frame pipeline, sharded
@@ -164,7 +189,7 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restric
                                                           int* __restrict__ starts, int* __restrict__ cursor,
                                                           float* __restrict__ sorted, float* __restrict__ bbox,
                                                           int32_t* __restrict__ ray_hit, int R,
-                                                          int32_t* __restrict__ info_zero) {
+                                                          int32_t* __restrict__ info_zero, unsigned* __restrict__ nbr) {
     __shared__ float smin[3][16], smax[3][16];
     __shared__ GridInfo g;
     __shared__ int wsum[16];
@@ -255,11 +280,15 @@ __global__ __launch_bounds__(1024) void grid_build_kernel(const float* __restric
         if (sub == 0)
             for (int a = 0; a < 3; ++a) { bbox[6 * c + a] = bmn[a]; bbox[6 * c + 3 + a] = bmx[a]; }
     }
+    grid_nbr_phase(g, starts, nbr, tid, 1024);               // (starts[] is complete since the barrier after the scan)
 }
 
 
-// one thread per sample; a wave covers 64 consecutive samples (= one ray at S=64)
-__global__ __launch_bounds__(256) void hull_mask_kernel(ThPointSrc ps, long long P, const GridInfo* __restrict__ gi,
+// one thread per sample; a wave covers 64 consecutive samples (= one ray at S=64).  The first form of the test (kept as the
+// A/B partner, TH_HULL_SEQ=1): every lane walks its own candidate vertices -- a wave takes as long as its slowest lane, and
+// on a ray through the body that is the one or two samples just OUTSIDE the hull that must test every vertex of every
+// cell whose box is in reach (100-300 vertices) while the samples inside leave after a few.
+__global__ __launch_bounds__(256) void hull_mask_seq_kernel(ThPointSrc ps, long long P, const GridInfo* __restrict__ gi,
                                                         const int* __restrict__ starts,
                                                         const float* __restrict__ sorted,
                                                         const float* __restrict__ bbox, float thresh,
@@ -310,9 +339,109 @@ __global__ __launch_bounds__(256) void hull_mask_kernel(ThPointSrc ps, long long
     if (hit && ray_hit) ray_hit[(int)(i / ps.S)] = 1;
 }
 
+// The default form: the same predicate on the same (sample, vertex) pairs, "exists" evaluated in another order.
+// (1) per lane: the 27 cells of the neighbourhood are screened against their bounding boxes -> a 27-bit word (bit 0 = the
+// sample's own cell); the first HULL_PROBE vertices of the own cell are tested by the lane itself (two of three samples
+// inside the hull leave here).  (2) per wave: the samples still open are taken one at a time by the WHOLE wave -- lane l
+// < 27 looks up the vertex range of screened cell l, then the 64 lanes test 64 vertices of a cell per step and the first
+// ballot with a set bit ends the sample.  The outcome is bit-identical (the predicate and its operands are unchanged, an
+// "or" over the same set); the near-miss samples cost ~5 wave steps instead of ~200 lane iterations.
+#ifndef HULL_PROBE
+#define HULL_PROBE 8
+#endif
+__global__ __launch_bounds__(256) void hull_mask_kernel(ThPointSrc ps, long long P, const GridInfo* __restrict__ gi,
+                                                        const int* __restrict__ starts,
+                                                        const float* __restrict__ sorted,
+                                                        const float* __restrict__ bbox, float thresh,
+                                                        uint8_t* __restrict__ mask, int32_t* __restrict__ ray_hit,
+                                                        const unsigned* __restrict__ nbr) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool valid = i < P;                           // (no early return: every lane serves the wave stage)
+    const GridInfo g = *gi;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (valid) th_get_point(ps, i, px, py, pz);
+    const int cx = cell_coord(px, g.gmin[0], g.inv_h), cy = cell_coord(py, g.gmin[1], g.inv_h),
+              cz = cell_coord(pz, g.gmin[2], g.inv_h);
+    // thresholds as in the sequential form: box rejection with a rounding margin (never a false skip), sqrt only inside
+    // a +-4e-6 band around thresh^2
+    const float rej = thresh * 1.001f + 1e-6f, rej2 = rej * rej;
+    const float t2 = thresh * thresh, t2lo = t2 * (1.0f - 4e-6f), t2hi = t2 * (1.0f + 4e-6f);
+    auto within = [&](float x, float y, float z, int v) -> bool {
+        float dx = x - sorted[3 * v], dy = y - sorted[3 * v + 1], dz = z - sorted[3 * v + 2];
+        float d2 = dx * dx + dy * dy;
+        d2 = d2 + dz * dz;
+        return d2 < t2hi && (d2 < t2lo || __fsqrt_rn(d2) < thresh);
+    };
+    unsigned pmask = 0u;                                // bit j: cell at offset (j + 13) % 27 of the 3 x 3 x 3 block is in reach
+    bool hit = false;
+    if (valid && cx >= -1 && cx <= g.dim[0] && cy >= -1 && cy <= g.dim[1] && cz >= -1 && cz <= g.dim[2]) {
+        const unsigned occ = nbr[((cz + 1) * (g.dim[1] + 2) + (cy + 1)) * (g.dim[0] + 2) + (cx + 1)];
+        // (cell indices relative to the own cell's; byte offsets as unsigned 32-bit lane offsets from a scalar base)
+        const int cb = (cz * g.dim[1] + cy) * g.dim[0] + cx, sy = g.dim[0], sz = g.dim[0] * g.dim[1];
+        if (occ != 0u)
+#pragma unroll
+        for (int j = 0; j < 27; ++j) {
+            const int o = (j + 13) % 27;
+            if ((occ >> j) & 1u) {                      // (in the grid and not empty)
+                const unsigned c = (unsigned)(cb + (o / 9 - 1) * sz + ((o / 3) % 3 - 1) * sy + (o % 3 - 1));
+                const float* bb = reinterpret_cast<const float*>(reinterpret_cast<const char*>(bbox) + c * 24u);
+                float ex = fmaxf(fmaxf(bb[0] - px, px - bb[3]), 0.f), ey = fmaxf(fmaxf(bb[1] - py, py - bb[4]), 0.f),
+                      ez = fmaxf(fmaxf(bb[2] - pz, pz - bb[5]), 0.f);
+                if (ex * ex + ey * ey + ez * ez <= rej2) pmask |= 1u << j;
+            }
+        }
+        if (pmask & 1u) {
+            const int c0 = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+            const int s0 = starts[c0], e0 = min(starts[c0 + 1], s0 + HULL_PROBE);
+            for (int v = s0; v < e0; ++v)
+                if (within(px, py, pz, v)) { hit = true; break; }
+        }
+    }
+    // ---- wave stage ----
+    const int lo = (lane + 13) % 27;                    // (lanes >= 27 hold no cell)
+    const int ldx = lo % 3 - 1, ldy = (lo / 3) % 3 - 1, ldz = lo / 9 - 1;
+    unsigned long long todo = __ballot(pmask != 0u && !hit);
+    while (todo) {
+        const int b = __builtin_amdgcn_readfirstlane(__ffsll((long long)todo) - 1);
+        todo &= todo - 1;
+        const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px), b));
+        const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py), b));
+        const float sz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz), b));
+        const int scx = __builtin_amdgcn_readlane(cx, b), scy = __builtin_amdgcn_readlane(cy, b),
+                  scz = __builtin_amdgcn_readlane(cz, b);
+        const unsigned pm = (unsigned)__builtin_amdgcn_readlane((int)pmask, b);
+        int vs = 0, ve = 0;
+        if (lane < 27 && ((pm >> lane) & 1u)) {
+            const int c = ((scz + ldz) * g.dim[1] + (scy + ldy)) * g.dim[0] + (scx + ldx);
+            vs = starts[c];
+            ve = starts[c + 1];
+            if (lane == 0) vs = min(ve, vs + HULL_PROBE);          // the lane's own probe covered these
+        }
+        unsigned cells = (unsigned)__ballot(ve > vs);
+        bool h = false;
+        while (cells && !h) {
+            const int l = __builtin_amdgcn_readfirstlane(__ffs((int)cells) - 1);
+            cells &= cells - 1;
+            const int s0 = __builtin_amdgcn_readlane(vs, l), e0 = __builtin_amdgcn_readlane(ve, l);
+            for (int v0 = s0; v0 < e0 && !h; v0 += 64) {
+                const int v = v0 + lane;
+                const bool t = v < e0 && within(sx, sy, sz, v);
+                h = __ballot(t) != 0ull;
+            }
+        }
+        if (h && lane == b) hit = true;
+    }
+    if (valid) {
+        mask[i] = hit ? 1 : 0;
+        if (hit && ray_hit) ray_hit[(int)(i / ps.S)] = 1;
+    }
+}
+
 size_t th_hull_ws(int n_verts) {
     return th_align(sizeof(GridInfo)) + 3 * th_align((GRID_MAX_CELLS + 1) * sizeof(int)) +
-           th_align((size_t)n_verts * 3 * sizeof(float)) + th_align((size_t)GRID_MAX_CELLS * 6 * sizeof(float));
+           th_align((size_t)n_verts * 3 * sizeof(float)) + th_align((size_t)GRID_MAX_CELLS * 6 * sizeof(float)) +
+           th_align((size_t)GRID_EXT_CELLS * sizeof(unsigned));
 }
 
 int th_hull_mask_launch(const ThPointSrc& ps, long long P, const float* verts, int nv, float thresh, uint8_t* mask,
@@ -325,7 +454,8 @@ int th_hull_mask_launch(const ThPointSrc& ps, long long P, const float* verts, i
     int* cursor = ar.take<int>(GRID_MAX_CELLS + 1);
     float* sorted = ar.take<float>((size_t)nv * 3);
     float* bbox = ar.take<float>((size_t)GRID_MAX_CELLS * 6);
-    TH_REQUIRE(sorted != nullptr && bbox != nullptr, "workspace carve failed");
+    unsigned* nbr = ar.take<unsigned>(GRID_EXT_CELLS);
+    TH_REQUIRE(sorted != nullptr && bbox != nullptr && nbr != nullptr, "workspace carve failed");
     // cell size: thresh plus 5 % so fp rounding of the cell index can never
     // separate a vertex within `thresh` from the 3x3x3 neighbourhood
     float h0 = thresh * 1.05f;
@@ -336,14 +466,20 @@ int th_hull_mask_launch(const ThPointSrc& ps, long long P, const float* verts, i
         hipLaunchKernelGGL(grid_scan_kernel, dim3(1), dim3(1024), 0, s, gi, counts, starts, cursor);
         hipLaunchKernelGGL(grid_fill_kernel, dim3(th_cdiv(nv, 256)), dim3(256), 0, s, verts, nv, gi, cursor, sorted);
         hipLaunchKernelGGL(grid_bbox_kernel, dim3(th_cdiv(GRID_MAX_CELLS * 8, 256)), dim3(256), 0, s, gi, starts, sorted, bbox);
+        hipLaunchKernelGGL(grid_nbr_kernel, dim3(64), dim3(256), 0, s, gi, starts, nbr);
         if (ray_hit) TH_HIP(hipMemsetAsync(ray_hit, 0, sizeof(int32_t) * (size_t)ps.R, s));
         if (info_zero) TH_HIP(hipMemsetAsync(info_zero, 0, 16 * sizeof(int32_t), s));
     } else {
         hipLaunchKernelGGL(grid_build_kernel, dim3(1), dim3(1024), 0, s, verts, nv, h0, gi, counts, starts, cursor, sorted, bbox,
-                           ray_hit, ray_hit ? ps.R : 0, info_zero);
+                           ray_hit, ray_hit ? ps.R : 0, info_zero, nbr);
     }
-    hipLaunchKernelGGL(hull_mask_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, ps, P, gi, starts, sorted, bbox, thresh,
-                       mask, ray_hit);
+    const bool seq = getenv("TH_HULL_SEQ") != nullptr;          // A/B switch, read per launch: one lane per sample throughout
+    if (seq)
+        hipLaunchKernelGGL(hull_mask_seq_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, ps, P, gi, starts, sorted, bbox, thresh,
+                           mask, ray_hit);
+    else
+        hipLaunchKernelGGL(hull_mask_kernel, dim3(th_cdiv(P, 256)), dim3(256), 0, s, ps, P, gi, starts, sorted, bbox, thresh,
+                           mask, ray_hit, nbr);
     TH_LAUNCH_CHECK();
     return 0;
 }
