@@ -60,6 +60,9 @@ typedef _Float16 dp_h4 __attribute__((ext_vector_type(4)));
 // fifth of the instructions of the full-range library sinf, which made the PE channels the largest VALU block
 // of this kernel.
 __device__ __forceinline__ float dp_sin(float a) {
+#if defined(DP_EXP) && DP_EXP == 1
+    return a;                                              // timing build: what the kernel costs without its sines
+#endif
     const float k = rintf(a * 0.15915494309189535f);
     float r = fmaf(-k, 6.28125f, a);                       // 2*pi = 6.28125 + 1.93500518798828125e-3 + 3.0199159819e-7
     r = fmaf(-k, 1.93500518798828125e-3f, r);
@@ -258,6 +261,9 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                 nlist = cell_count[cell];
             }
         }
+#if defined(DP_EXP) && DP_EXP == 2
+        nlist = min(nlist, 14);                            // timing build: a scan of 7 candidates per lane
+#endif
         for (int j = half; j < nlist; j += 2) {
             const int c = list ? list[j] : j;
             float dx = x - cen[3 * c], dy = y - cen[3 * c + 1], dz = z - cen[3 * c + 2];
