@@ -334,6 +334,71 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
     }
     const float PI_F = 3.14159274101257324219f;          // fp32(pi)
     const float HALF_PI_F = 1.57079637050628662109f;     // fp32(pi/2)
+    if constexpr (FOLDED && VT < 0) {
+#ifndef DP_PHASE2_WAVE
+        // TH_ROWS_NBR writes no table rows, so nothing here is 64 lanes wide: FOUR samples per wave step, 16 lanes each.
+        // Lane q of a sample owns the PE channels 4 q .. 4 q + 3 (channel 63 is the row's zero pad) -- the same 441 sines per
+        // sample, every term and the order of the seven-term sums as in the wave-per-sample loop below (bit-identical rows),
+        // but the per-sample overhead of that loop (weight broadcasts, record lanes, two 2-byte stores per lane) is paid
+        // once per four samples and the PE halves leave as 8-byte stores.
+        const int sub = lane >> 4, l16 = lane & 15;
+        unsigned aoff[4];
+        float fr[4], phs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ch = 4 * l16 + q;
+            int a = 0, oc = 0;
+            float ph0 = 0.f;
+            if (ch < 3) a = ch;
+            else if (ch < 63) {
+                const int qq = ch - 3, r = qq % 6;
+                oc = qq / 6;
+                a = r % 3;
+                ph0 = (r >= 3) ? HALF_PI_F : 0.f;
+            }
+            aoff[q] = (unsigned)a;
+            fr[q] = PI_F * (float)(1 << oc);
+            phs[q] = ph0;
+        }
+        for (int it = 0; it < DP_SAMPLES / 16; ++it) {
+            const int lp = it * 16 + wave * 4 + sub;
+            const int gp = blockIdx.x * DP_SAMPLES + lp;
+            if (gp >= P) continue;
+            const DpNbr& n = nb[lp];
+            float pe[4];
+#pragma unroll
+            for (int k = 0; k < DP_K; ++k) {
+                const float wk = n.w[k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float xv = n.def[k][aoff[q]];
+                    float val = dp_sin(fmaf(xv, fr[q], phs[q]));
+                    if (q < 3) val = (4 * l16 + q < 3) ? xv : val;          // channels 0..2: the raw offsets
+                    pe[q] = (k == 0) ? wk * val : fmaf(wk, val, pe[q]);
+                }
+            }
+            if (l16 == 15) pe[3] = 0.f;                                     // channel 63: pad
+            unsigned rec = 0u;                                              // the neighbour record (16 dwords)
+            if (l16 < 7) {
+                const int c = n.idx[l16], t = lp >> 5;
+                rec = ubw[t * 128 + (c >> 5)] + __popc(ubm[t * 128 + (c >> 5)] & ((1u << (c & 31)) - 1u));   // slot of centre c
+            } else if (l16 >= 8 && l16 < 15) rec = __builtin_bit_cast(unsigned, n.w[l16 - 8]);
+            reinterpret_cast<unsigned*>(out)[(long long)gp * 16 + l16] = rec;
+            dp_h4 hi, lo;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                _Float16 x, y;
+                dp_split(pe[q], x, y);
+                hi[q] = x;
+                lo[q] = y;
+            }
+            _Float16* ph = reinterpret_cast<_Float16*>(pe_out) + (long long)gp * 128;
+            *reinterpret_cast<dp_h4*>(ph + 4 * l16) = hi;
+            *reinterpret_cast<dp_h4*>(ph + 64 + 4 * l16) = lo;
+        }
+        return;
+#endif
+    }
     // PE channel `lane` (0..62): 0..2 raw xyz; then per octave f: sin xyz, cos xyz
     int axis = 0, oct = 0;
     float phase = 0.f;
