@@ -1005,7 +1005,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         float* a_f = (float*)(pb + pl.a_f);
         float* a_h = (float*)(pb + pl.a_h);
         float* a_pe = (float*)(pb + pl.a_pe);
-        const bool grid = getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
+        const bool grid = getenv("TH_DPARF_NOGRID") == nullptr && th_dparf_grid_ok(f->n_clusters);
         // K4 on the context's second stream, K5 on `s`: the two producers share nothing but the sample list -- K5 sits on
         // the texture path (TA busy 80-90 %, VALU 43 %), K4 since TH_ROWS_NBR is a 7-NN scan out of LDS (no row gather) --
         // so their waves co-reside on the CUs instead of running back to back (TH_K4_SIDE=0: one stream, K4 then K5).
@@ -1078,7 +1078,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     if (n > 0) TH_TRY(token_table(c, f->tokens, V, f->n_clusters, tprime, &table, s));
     // exact candidate grid for the 7-NN scan of K4 (TH_DPARF_NOGRID=1: full scan, same result)
     // (not needed when every sample's records were pre-gathered: K4 does not run again)
-    const bool use_grid = n > npre && getenv("TH_DPARF_NOGRID") == nullptr && (size_t)f->n_clusters * 4 <= 48 * 1024;
+    const bool use_grid = n > npre && getenv("TH_DPARF_NOGRID") == nullptr && th_dparf_grid_ok(f->n_clusters);
     if (use_grid) TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s));
     if (npre > 0) {          // rows and records of these samples were written by th_render_pregather: ONE fused launch
         ChunkBufs pc = cb;

@@ -425,6 +425,8 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
                     int V, int nc, float alpha, float* out, float* pe_out, int fmt, const void* grid_ws,
                     hipStream_t s);
 // exact candidate grid over the token centres for the 7-NN scan of K4 (per frame); grid_ws = nullptr: full scan
+// (the grid builder keeps four cells' squared distances in the default 64 KiB of dynamic LDS: nc <= 4096)
+static inline bool th_dparf_grid_ok(int nc) { return nc >= 7 && (size_t)nc * 16 <= 64 * 1024; }
 size_t th_dparf_grid_ws(int nc);
 int th_dparf_grid_build(const float* centres, int nc, void* ws, size_t ws_bytes, hipStream_t s);
 // k_pixfeat.hip
