@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 7
+#define TH_ABI_VERSION 8
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -512,6 +512,17 @@ int th_render_prepass(th_ctx* ctx, const th_frame* f, const th_points* rays, voi
  * identical with or without it. */
 int th_render_pregather(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
                         size_t workspace_bytes, void* shade_pool, size_t shade_pool_bytes, th_stream stream);
+/* ABI 8.  th_render_pregather for a frame pipeline that queues frame i+1's pre-gather stage right behind frame i's
+ * th_render_rays on the same stream and shading pool: the neighbour-record producer (on the context's second stream) is
+ * ordered behind the PER-SAMPLE stage of that th_render_rays -- the last user of the pool regions it writes -- instead of
+ * behind everything queued on `stream` since, so frame i's compositing and whatever the caller queued after it (image
+ * assembly, an all-gather) run beside the producer instead of in front of it.  The caller promises that everything the
+ * stage reads -- the prepass of this workspace, `f` except f->tokens, the ray arrays -- was complete on `stream` BEFORE
+ * that th_render_rays was queued (e.g. the stream waited on the event of the front that produced them).  Without a
+ * th_render_rays on the same stream and pool since the last pre-gather it behaves exactly as th_render_pregather;
+ * `stream` has waited for the whole stage when the call returns, as there.  Results are identical. */
+int th_render_pregather_early(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
+                              size_t workspace_bytes, void* shade_pool, size_t shade_pool_bytes, th_stream stream);
 /* Waits (host) for the counts of the prepass pending in `workspace`: counts_host[0] = hit rays, [1] = 1 when the
  * R' <= small_frame_rays rule fired (un-masked branch), [2] = valid samples -- what th_shade_pool_bytes wants.
  * Returns 1 (and leaves counts_host alone) when no prepass is pending for that workspace. */

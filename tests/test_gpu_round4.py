@@ -435,3 +435,34 @@ def test_wave_cooperative_hull_test_equals_the_sequential_one(hip, gpu, monkeypa
         monkeypatch.delenv("TH_HULL_SEQ", raising=False)
         assert int(m0.sum()) > 500 and int(m0.sum()) < m0.numel()
         assert torch.equal(m1, m0) and torch.equal(h1, h0), (thr, int((m1 != m0).sum()))
+
+
+def test_early_pregather_is_a_pure_reordering(hip, gpu, net, monkeypatch):
+    """render_sequence starts the next frame's neighbour records (K4, on the context's second stream) behind the PER-SAMPLE
+    stage of the frame being shaded instead of behind its compositing and whatever the consumer queued since
+    (th_render_pregather_early, ABI 8; TH_PREGATHER_EARLY=0: the plain fork).  A stream of DIFFERENT frames (own images, pose,
+    rays; two sizes, so the shading pool is re-allocated in between) with a consumer that keeps the render stream busy
+    between frames: every image equals render_fast's on that frame bit for bit, with and without the early start, three
+    times over."""
+    r = _renderer(net, 500)
+    frames = [synth.batch_to(synth.make_batch(hw, hw, 3, seed=sd, all_rays=True, focal=fc * hw / 64.0), gpu)
+              for hw, sd, fc in ((96, 0, 210.0), (96, 1, 190.0), (160, 2, 230.0), (160, 0, 200.0), (96, 2, 215.0), (96, 1, 205.0))]
+    ref = []
+    for b in frames:
+        o = r.render_fast(b)
+        ref.append({k: v.clone() for k, v in o.items()})
+    assert maxdiff(ref[0]["rgb_map"].cpu(), ref[1]["rgb_map"].cpu()) > 1e-2
+    busy = torch.zeros(1 << 22, device=gpu)
+    for rep, early in enumerate(("1", "0", "1")):
+        monkeypatch.setenv("TH_PREGATHER_EARLY", early)
+        got = []
+        for o in r.render_sequence(iter(frames)):
+            got.append({k: v.clone() for k, v in o.items()})
+            for _ in range(3):                                   # the consumer's work on the render stream (image assembly ...)
+                busy = busy * 1.0001 + 1.0
+        torch.cuda.synchronize()
+        assert len(got) == len(frames)
+        for i in range(len(frames)):
+            for k in ("rgb_map", "acc_map", "depth_map"):
+                assert torch.equal(got[i][k], ref[i][k]), (rep, early, i, k)
+    hip.drop_workspaces(gpu)

@@ -96,6 +96,7 @@ void th_ctx_destroy(th_ctx* c) {
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
     if (c->aux_join) (void)hipEventDestroy(c->aux_join);
+    if (c->after_shade) (void)hipEventDestroy(c->after_shade);
     for (auto& e : c->range_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& t : c->prepass)
@@ -1017,8 +1018,18 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
                 TH_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
                 TH_HIP(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
             }
-            TH_HIP(hipEventRecord(c->aux_fork, s));          // sample list, candidate grid and every earlier user of the pool
-            TH_HIP(hipStreamWaitEvent(c->aux, c->aux_fork, 0));
+            // th_render_pregather_early: K4 is ordered behind the per-sample stage of the previous th_render_rays on this
+            // stream and pool (the last user of the pool's record regions) instead of behind everything queued on `s` since
+            // -- that frame's compositing and whatever the caller queued after it run beside K4, not in front of it
+            const bool early = c->pregather_early && c->after_shade_valid && c->after_shade_stream == s &&
+                               c->after_shade_pool == pool;
+            c->after_shade_valid = false;
+            if (early) {
+                TH_HIP(hipStreamWaitEvent(c->aux, c->after_shade, 0));
+            } else {
+                TH_HIP(hipEventRecord(c->aux_fork, s));      // sample list, candidate grid and every earlier user of the pool
+                TH_HIP(hipStreamWaitEvent(c->aux, c->aux_fork, 0));
+            }
             s4 = c->aux;
         }
         // From here on work may be in flight on the second stream: whatever happens, `s` waits for it before this call
@@ -1184,6 +1195,12 @@ int th_render_rays(th_ctx* c, const th_frame* f, const th_points* rays, float* r
     const int32_t* ray_hit = nullptr;
     TH_TRY(shade_points(c, f, ps, P, true, ar, pool, pool_bytes, &raw, &mask, stats_host, s, slot >= 0 ? 2 : 0,
                         slot >= 0 ? slot : 0, &ray_hit));
+    // (for th_render_pregather_early of the next frame: the pool's record regions are free from here on)
+    if (!c->after_shade) TH_HIP(hipEventCreateWithFlags(&c->after_shade, hipEventDisableTiming));
+    TH_HIP(hipEventRecord(c->after_shade, s));
+    c->after_shade_stream = s;
+    c->after_shade_pool = pool;
+    c->after_shade_valid = true;
     ProfScope sc(prof_of(c), TH_PROF_COMPOSITE, s);
     TH_TRY(th_composite_launch(raw, nullptr, ps, white_bkgd, rgb, acc, depth, nullptr, mask, s, ray_hit));
     const int snap = th_range_snapshot(c, stream);
@@ -1247,6 +1264,15 @@ int th_render_pregather(th_ctx* c, const th_frame* f, const th_points* rays, voi
     float* raw = nullptr;
     const uint8_t* mask = nullptr;
     return shade_points(c, f, ps, P, true, ar, pool, pool_bytes, &raw, &mask, nullptr, (hipStream_t)stream, 3, slot);
+}
+
+int th_render_pregather_early(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, void* pool,
+                              size_t pool_bytes, th_stream stream) {
+    TH_REQUIRE(c != nullptr, "null argument");
+    c->pregather_early = true;
+    const int rc = th_render_pregather(c, f, rays, ws, ws_bytes, pool, pool_bytes, stream);
+    c->pregather_early = false;
+    return rc;
 }
 
 int th_render_prepass_cancel(th_ctx* c) {

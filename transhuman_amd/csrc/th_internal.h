@@ -353,6 +353,12 @@ struct th_ctx {
     // runs beside K5 (pixel-feature gather: texture-path bound) instead of behind it
     hipStream_t aux = nullptr;
     hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    // th_render_pregather_early: the point of the last th_render_rays' stream where its per-sample stage (fused MLP +
+    // scatter) was complete -- recorded before the compositing -- and the stream / shading pool it belongs to
+    hipEvent_t after_shade = nullptr;
+    hipStream_t after_shade_stream = nullptr;
+    const void* after_shade_pool = nullptr;
+    bool after_shade_valid = false, pregather_early = false;
     void* prof = nullptr;             // ThProf (th_api.hip)
     // range guard (th_range_*): device table the kernels merge their maxima into, pinned snapshots + events
     unsigned int* range_dev = nullptr;

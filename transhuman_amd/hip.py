@@ -150,6 +150,8 @@ SYMBOLS = {
                                     C.c_void_p]),
     "th_render_pregather": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
+    "th_render_pregather_early": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
     "th_conv_pack_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "th_conv_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                C.POINTER(C.c_float), C.c_void_p]),
@@ -191,7 +193,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 7:
+    if lib.th_abi_version() != 8:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -1139,10 +1141,12 @@ def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=240
     points._prepass_pending = True          # only THIS Points object (it keeps the ray tensors alive) may consume it
 
 
-def render_pregather(net, frame, points, slot=0):
+def render_pregather(net, frame, points, slot=0, early=False):
     """th_render_pregather: behind a render_prepass of the same ``points`` / workspace ``slot``, queue the pixel-feature
     gather and the neighbour records of the first chunks -- ``frame`` may still lack its tokens (Frame(tokens=None)),
-    so TransHE can run on another stream meanwhile."""
+    so TransHE can run on another stream meanwhile.  ``early=True`` (th_render_pregather_early): the caller has made the
+    current stream wait for this frame's front BEFORE it queued the previous frame's render_rays, so the neighbour
+    records may start as soon as that frame's per-sample stage is done, beside its compositing."""
     if not getattr(points, "_prepass_pending", False):
         return
     lib = load_library()
@@ -1154,8 +1158,8 @@ def render_pregather(net, frame, points, slot=0):
         return
     pool = _shade_pool(frame.c, cnt[2], True, dev)
     points._pregathered = True
-    _check(lib.th_render_pregather(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(ws), ws.numel(), _p(pool), pool.numel(),
-                                   _stream()))
+    fn = lib.th_render_pregather_early if early else lib.th_render_pregather
+    _check(fn(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(ws), ws.numel(), _p(pool), pool.numel(), _stream()))
 
 
 def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_frame_rays=None):

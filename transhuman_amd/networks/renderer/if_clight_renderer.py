@@ -361,7 +361,7 @@ class Renderer:
                 frame = self.prepare_frame(b, token_exchange=token_exchange, defer_tokens=split, stem_exchange=stem_exchange)
                 ready = torch.cuda.Event()
                 ready.record(side)
-            return [b, pts, frame, ready, ep]
+            return [b, pts, frame, ready, ep, ready, False]      # [5]: piece A's event (tokens() replaces [3]); [6]: see below
 
         def tokens(ent, side):
             """side stream: piece B of an entry whose piece A has been issued"""
@@ -422,7 +422,7 @@ class Renderer:
             return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
 
         while queue:
-            cur, pts, frame, ready, epoch = queue.popleft()
+            cur, pts, frame, ready, epoch, _, early = queue.popleft()
             main = torch.cuda.current_stream(dev)
             main.wait_event(ready)
             # everything queued so far (inputs of coming batches, the shading of the previous frame -- the last user
@@ -437,7 +437,14 @@ class Renderer:
             # frame's shading: its ~130 small launches share the chip with the producers (which leave LDS / registers /
             # the matrix pipe free) instead of time-slicing with MLP tiles that own whole CUs.
             if os.environ.get("TH_PREGATHER") != "0":
-                hip.render_pregather(self.net, frame, pts)
+                hip.render_pregather(self.net, frame, pts, early=early)
+            # The NEXT frame's neighbour records (K4, the long pole of its producers) may start the moment this frame's
+            # per-sample stage is done, beside this frame's compositing and the consumer's image assembly instead of behind
+            # them (th_render_pregather_early): for that, the current stream is ordered behind piece A of the next frame's
+            # front BEFORE this frame's shading is queued -- it was issued a whole frame ago (split front: lookahead >= 2).
+            if queue and os.environ.get("TH_PREGATHER_EARLY", "1") != "0":
+                main.wait_event(queue[0][5])
+                queue[0][6] = True
             rgb, acc, depth, stats, check = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
                                                             defer_guard=True, small_frame_rays=small_frame_rays)
             side.wait_event(fence)
