@@ -518,7 +518,8 @@ int th_render_pregather(th_ctx* ctx, const th_frame* f, const th_points* rays, v
  * behind everything queued on `stream` since, so frame i's compositing and whatever the caller queued after it (image
  * assembly, an all-gather) run beside the producer instead of in front of it.  The caller promises that everything the
  * stage reads -- the prepass of this workspace, `f` except f->tokens, the ray arrays -- was complete on `stream` BEFORE
- * that th_render_rays was queued (e.g. the stream waited on the event of the front that produced them).  Without a
+ * that th_render_rays was queued (e.g. the stream waited on the event of the front that produced them); a non-NULL
+ * f->tokens is taken as complete on `stream` now, and the per-frame token table is then queued here as well.  Without a
  * th_render_rays on the same stream and pool since the last pre-gather it behaves exactly as th_render_pregather;
  * `stream` has waited for the whole stage when the call returns, as there.  Results are identical. */
 int th_render_pregather_early(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,

@@ -1050,6 +1050,14 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
                                                f->scale_xy, a_f, f_ld, fmt, s, c->range_dev);
             }
         }
+        // th_render_pregather_early with the tokens already in the frame: the token table T' (one small GEMM + its split)
+        // is queued here, beside K4, instead of between K4's end and the fused MLP's start
+        t.pre_tokens = nullptr;
+        if (rc == 0 && c->pregather_early && f->tokens != nullptr) {
+            const float* table = nullptr;
+            rc = token_table(c, f->tokens, V, f->n_clusters, tprime, &table, s);
+            if (rc == 0) t.pre_tokens = f->tokens;
+        }
         if (k4_side) {
             const hipError_t e1 = hipEventRecord(c->aux_join, c->aux);
             const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, c->aux_join, 0) : e1;
@@ -1086,7 +1094,11 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     if (!ray_mode && CH > 0) TH_HIP(hipMemsetAsync(cb.vdc, 0, (size_t)CH * 27 * 4, s));   // zero view dirs, if_mesh_renderer.py:62
     TH_REQUIRE(f->n_clusters <= TH_MAX_CLUSTERS, "too many token clusters");
     const float* table = nullptr;
-    if (n > 0) TH_TRY(token_table(c, f->tokens, V, f->n_clusters, tprime, &table, s));
+    if (n > 0) {
+        if (npre > 0 && c->prepass[slot].pre_tokens == f->tokens && mlp_is_fused(c, V)) table = tprime;    // (queued by the pre-gather stage)
+        else TH_TRY(token_table(c, f->tokens, V, f->n_clusters, tprime, &table, s));
+    }
+    if (prepass == 2) c->prepass[slot].pre_tokens = nullptr;
     // exact candidate grid for the 7-NN scan of K4 (TH_DPARF_NOGRID=1: full scan, same result)
     // (not needed when every sample's records were pre-gathered: K4 does not run again)
     const bool use_grid = n > npre && getenv("TH_DPARF_NOGRID") == nullptr && th_dparf_grid_ok(f->n_clusters);
@@ -1228,6 +1240,7 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     t.valid = false;
     t.npre = 0;                                   // (a pre-gather of an abandoned frame must not outlive its prepass)
     t.map_done = nullptr;
+    t.pre_tokens = nullptr;
     if (R <= 0) return 0;
     long long P = (long long)R * S;
     TH_REQUIRE(P < (1LL << 31), "R*S must fit in int32");
