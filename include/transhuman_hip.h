@@ -512,6 +512,13 @@ int th_render_prepass(th_ctx* ctx, const th_frame* f, const th_points* rays, voi
  * identical with or without it. */
 int th_render_pregather(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace,
                         size_t workspace_bytes, void* shade_pool, size_t shade_pool_bytes, th_stream stream);
+/* ABI 8.  Optional, behind a th_render_prepass of the same workspace / ray arrays and before its th_render_pregather: builds
+ * the candidate grid of the 7-neighbour search (cross_transformer.py:151-160; exact pruning) for f->centres
+ * into the workspace on `stream` -- a frame pipeline calls it on the stream that produced the centres (th_paint_group),
+ * long before the pre-gather stage, which then starts with the neighbour search itself.  The caller orders `stream` before
+ * the pre-gather stage (as for the prepass).  A no-op without a matching prepass; results are identical. */
+int th_render_pregrid(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace, size_t workspace_bytes,
+                      th_stream stream);
 /* ABI 8.  th_render_pregather for a frame pipeline that queues frame i+1's pre-gather stage right behind frame i's
  * th_render_rays on the same stream and shading pool: the neighbour-record producer (on the context's second stream) is
  * ordered behind the PER-SAMPLE stage of that th_render_rays -- the last user of the pool regions it writes -- instead of

@@ -898,6 +898,28 @@ static size_t shade_ws_bytes(const th_frame* f, long long P, int R) {
            th_align((size_t)P * 4) + th_align(64) + th_align((size_t)R * 27 * 4) + th_align((size_t)P * 16) +
            th_align(TPRIME_FLOATS(f->V) * 4) + th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1);
 }
+// (one carve for every entry point that works in a ray workspace)
+struct ShadeWs {
+    uint8_t* mask; int32_t* ray_hit; void* hws; size_t hws_b; void* cws; size_t cws_b; int32_t* idx; int32_t* info;
+    float* vd_all; float* raw; float* tprime; void* gws; size_t gws_b;
+};
+static ShadeWs carve_shade_ws(const th_frame* f, long long P, int R, ThArena& ar) {
+    ShadeWs w{};
+    w.mask = ar.take<uint8_t>((size_t)P);
+    w.ray_hit = ar.take<int32_t>((size_t)R);
+    w.hws_b = th_hull_ws(f->n_verts);
+    w.hws = ar.take<char>(w.hws_b);
+    w.cws_b = th_compact_ws(P);
+    w.cws = ar.take<char>(w.cws_b);
+    w.idx = ar.take<int32_t>((size_t)P);
+    w.info = ar.take<int32_t>(16);
+    w.vd_all = ar.take<float>((size_t)R * 27);
+    w.raw = ar.take<float>((size_t)P * 4);
+    w.tprime = ar.take<float>(TPRIME_FLOATS(f->V));
+    w.gws_b = th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1);
+    w.gws = ar.take<char>(w.gws_b);
+    return w;
+}
 static int frame_f_ld(const th_frame* f) {
     return (f->map_channels == TH_MAP_COMPACT || f->map_channels == TH_MAP_SPLIT) ? 272 : 384;
 }
@@ -919,19 +941,13 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     const size_t tex_stride = (size_t)f->V * f->H * f->W * 256;
     TH_REQUIRE(prepass == 1 || !compact || c->mlp.compact_ready,
                "compact pixel map needs th_mlp_weights.upsample_color (colour-folded layers) to be uploaded");
-    uint8_t* mask = ar.take<uint8_t>((size_t)P);
-    int32_t* ray_hit = ar.take<int32_t>((size_t)R);
-    size_t hws_b = th_hull_ws(f->n_verts);
-    void* hws = ar.take<char>(hws_b);
-    size_t cws_b = th_compact_ws(P);
-    void* cws = ar.take<char>(cws_b);
-    int32_t* idx = ar.take<int32_t>((size_t)P);
-    int32_t* info = ar.take<int32_t>(16);
-    float* vd_all = ar.take<float>((size_t)R * 27);
-    float* raw = ar.take<float>((size_t)P * 4);
-    float* tprime = ar.take<float>(TPRIME_FLOATS(V));
-    const size_t gws_b = th_dparf_grid_ws(f->n_clusters > 0 ? f->n_clusters : 1);
-    void* gws = ar.take<char>(gws_b);
+    const ShadeWs w = carve_shade_ws(f, P, R, ar);
+    uint8_t* mask = w.mask;
+    int32_t* ray_hit = w.ray_hit;
+    const size_t hws_b = w.hws_b, cws_b = w.cws_b, gws_b = w.gws_b;
+    void *hws = w.hws, *cws = w.cws, *gws = w.gws;
+    int32_t *idx = w.idx, *info = w.info;
+    float *vd_all = w.vd_all, *raw = w.raw, *tprime = w.tprime;
     TH_REQUIRE(raw != nullptr && tprime != nullptr && gws != nullptr, "workspace too small");
 
     ThProf* pf = prof_of(c);
@@ -1037,7 +1053,8 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         int rc = 0;
         {
             // (the candidate grid of the 7-NN scan is K4's alone: built on K4's stream, not in front of the pixel gather)
-            if (grid) rc = th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s4);
+            if (grid && t.grid_centres != f->centres) rc = th_dparf_grid_build(f->centres, f->n_clusters, gws, gws_b, s4);
+            t.grid_centres = nullptr;                 // (th_render_pregrid's grid is consumed: chunks beyond the stage rebuild)
             if (rc == 0) {
                 ProfScope ps1(pf, TH_PROF_DPARF, s4);
                 rc = th_dparf_launch(nullptr, &ps, f->Rh, f->Th, idx, m, f->centres, f->rot, nullptr, V, f->n_clusters, 0.5f, a_h,
@@ -1241,6 +1258,7 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     t.npre = 0;                                   // (a pre-gather of an abandoned frame must not outlive its prepass)
     t.map_done = nullptr;
     t.pre_tokens = nullptr;
+    t.grid_centres = nullptr;
     if (R <= 0) return 0;
     long long P = (long long)R * S;
     TH_REQUIRE(P < (1LL << 31), "R*S must fit in int32");
@@ -1277,6 +1295,26 @@ int th_render_pregather(th_ctx* c, const th_frame* f, const th_points* rays, voi
     float* raw = nullptr;
     const uint8_t* mask = nullptr;
     return shade_points(c, f, ps, P, true, ar, pool, pool_bytes, &raw, &mask, nullptr, (hipStream_t)stream, 3, slot);
+}
+
+int th_render_pregrid(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, th_stream stream) {
+    TH_REQUIRE(c && f && rays && ws && f->centres, "null argument");
+    if (getenv("TH_DPARF_NOGRID") != nullptr || !th_dparf_grid_ok(f->n_clusters)) return 0;
+    int slot = -1;
+    for (int k = 0; k < th_ctx::kPrepassSlots; ++k) {
+        th_ctx::Prepass& t = c->prepass[k];
+        if (t.valid && t.ws == ws && t.rays == (const void*)rays->ray_o && t.R == rays->R && t.S == rays->S) slot = k;
+    }
+    if (slot < 0) return 0;                      // no matching th_render_prepass: the pre-gather stage builds the grid itself
+    const long long P = (long long)rays->R * rays->S;
+    TH_REQUIRE(ws_bytes >= shade_ws_bytes(f, P, rays->R), "workspace too small");
+    ThArena ar(ws, ws_bytes);
+    const ShadeWs w = carve_shade_ws(f, P, rays->R, ar);
+    TH_REQUIRE(w.gws != nullptr, "workspace too small");
+    c->prepass[slot].grid_centres = nullptr;
+    TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, w.gws, w.gws_b, (hipStream_t)stream));
+    c->prepass[slot].grid_centres = f->centres;
+    return 0;
 }
 
 int th_render_pregather_early(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, void* pool,

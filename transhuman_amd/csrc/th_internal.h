@@ -343,6 +343,7 @@ struct th_ctx {
         const void* pre_map = nullptr;
         const void* pre_centres = nullptr;
         const void* pre_pool = nullptr;
+        const void* grid_centres = nullptr;         // th_render_pregrid: K4's candidate grid of these centres is in the workspace
         const void* pre_tokens = nullptr;           // th_render_pregather_early: T' of these tokens already sits in the workspace
         const void* map_done = nullptr;      // the cropped map this prepass's frame has already completed (written once)
     };

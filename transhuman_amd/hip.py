@@ -148,6 +148,8 @@ SYMBOLS = {
                                  C.POINTER(C.c_int64), C.c_void_p]),
     "th_render_prepass": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
                                     C.c_void_p]),
+    "th_render_pregrid": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
+                                    C.c_void_p]),
     "th_render_pregather": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "th_render_pregather_early": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t,
@@ -1139,6 +1141,16 @@ def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=240
     points._prepass_keep = (v, ws)
     _check(lib.th_render_prepass(ctx(dev), C.byref(f), C.byref(points.c), _p(ws), ws.numel(), _stream()))
     points._prepass_pending = True          # only THIS Points object (it keeps the ray tensors alive) may consume it
+
+
+def render_pregrid(frame, points):
+    """th_render_pregrid: the candidate grid of K4's 7-neighbour search for the frame's token centres, into the workspace of
+    the pending render_prepass of ``points`` -- on the current stream (the one that produced the centres)."""
+    if not getattr(points, "_prepass_pending", False):
+        return
+    _, ws = points._prepass_keep
+    _check(load_library().th_render_pregrid(ctx(frame.verts.device), C.byref(frame.c), C.byref(points.c), _p(ws), ws.numel(),
+                                            _stream()))
 
 
 def render_pregather(net, frame, points, slot=0, early=False):

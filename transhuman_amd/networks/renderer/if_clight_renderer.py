@@ -359,6 +359,8 @@ class Renderer:
                     hip.render_prepass(pts, b["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
                                        n_clusters=len(self.csr_offsets) - 1, slot=1 + j % nslots)
                 frame = self.prepare_frame(b, token_exchange=token_exchange, defer_tokens=split, stem_exchange=stem_exchange)
+                if V <= 4 and pts.R > 0 and os.environ.get("TH_PREGRID", "1") != "0":
+                    hip.render_pregrid(frame, pts)         # K4's candidate grid: here, not in front of K4
                 ready = torch.cuda.Event()
                 ready.record(side)
             return [b, pts, frame, ready, ep, ready, False]      # [5]: piece A's event (tokens() replaces [3]); [6]: see below
