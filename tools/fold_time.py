@@ -7,7 +7,8 @@ from transhuman_amd.networks.renderer.if_clight_renderer import Renderer
 dev = torch.device("cuda:0")
 cfg = get_cfg(); cfg.N_samples, cfg.num_class = 64, 500
 net = bench.build_net(dev)
-bc = synth.make_batch(512, 512, 3, seed=0, all_rays=True)
+WIDTH = int(sys.argv[1]) if len(sys.argv) > 1 else 512      # image width: the map's row pitch is WIDTH KiB
+bc = synth.make_batch(512, WIDTH, 3, seed=0, all_rays=True)
 body = bc["tar_smpl_vertice_smplcoord"][0].numpy()
 r = Renderer(net, vertex_can=body.astype(np.float64) * 1.02 + 0.001, pc2voxel_ind=bench.load_assign(500, body))
 b = synth.batch_to(bc, dev)
