@@ -59,8 +59,8 @@ def knn_points_exact(p, q, K, chunk=4096):
     L2 computed as (dx*dx + dy*dy) + dz*dz in fp32, idx [P,K] int64; ties go to
     the lower index)."""
     P = p.shape[0]
-    d2o = torch.empty((P, K), dtype=p.dtype)
-    ido = torch.empty((P, K), dtype=torch.int64)
+    d2o = torch.empty((P, K), dtype=p.dtype, device=p.device)
+    ido = torch.empty((P, K), dtype=torch.int64, device=p.device)
     for s in range(0, P, chunk):
         pp = p[s:s + chunk]
         dx = pp[:, None, 0] - q[None, :, 0]
@@ -101,7 +101,7 @@ def view_embed(ray_d, view_res=4):
     v = ray_d / torch.norm(ray_d, dim=-1, keepdim=True)
     out = [v]
     freqs = (2.0 ** torch.linspace(0.0, view_res - 1, steps=view_res)).to(ray_d.dtype)
-    for f in freqs:
+    for f in freqs.tolist():
         out.append(torch.sin(v * f))
         out.append(torch.cos(v * f))
     return torch.cat(out, -1)
@@ -118,7 +118,7 @@ def pe_encode(x, num_freqs, include_input=True):
     _phases = _phases.view(1, -1, 1)
     e = x.unsqueeze(1).repeat(1, num_freqs * 2, 1)
     # (the fp32 constants of the reference, widened when the oracle runs in float64: see render_fast(dtype=...))
-    e = torch.sin(torch.addcmul(_phases.to(x.dtype), e, _freqs.to(x.dtype)))              # :132
+    e = torch.sin(torch.addcmul(_phases.to(x), e, _freqs.to(x)))              # :132
     e = e.view(x.shape[0], -1)
     if include_input:
         e = torch.cat((x, e), dim=-1)
@@ -127,7 +127,7 @@ def pe_encode(x, num_freqs, include_input=True):
 
 def normalize_pe(pe, cr=(-1.5, -1.5, -1.5, 1.5, 1.5, 1.5)):
     """if_clight_renderer.py:373-383 (float64 in, float32 out)."""
-    cr = torch.tensor(cr)
+    cr = torch.tensor(cr).to(pe.device)
     mn, mx = cr[:3][None, None, :], cr[3:][None, None, :]
     out = (((pe - mn) / (mx - mn)) - 0.5) * 2
     return out.type(torch.float32)
@@ -159,7 +159,7 @@ def bilinear_border(feat, uv, scale):
     padding_mode='border') as used at if_clight_renderer.py:197-206.
     feat [V,C,H,W]; uv [V,N,2] pixel coords; scale [2] -> [V,C,N]."""
     V, C, H, W = feat.shape
-    g = uv * scale - 1.0                                          # :197
+    g = uv * scale.to(uv.device) - 1.0                                          # :197
     ix = ((g[..., 0] + 1.0) / 2.0) * (W - 1)
     iy = ((g[..., 1] + 1.0) / 2.0) * (H - 1)
     ix = ix.clamp(0.0, float(W - 1))
@@ -170,7 +170,7 @@ def bilinear_border(feat, uv, scale):
     w_ne = (ix - x0) * (y1 - iy)
     w_sw = (x1 - ix) * (iy - y0)
     w_se = (ix - x0) * (iy - y0)
-    out = torch.zeros((V, C, uv.shape[1]), dtype=feat.dtype)
+    out = torch.zeros((V, C, uv.shape[1]), dtype=feat.dtype, device=feat.device)
     fl = feat.reshape(V, C, H * W)
     for (xx, yy, ww) in ((x0, y0, w_nw), (x1, y0, w_ne), (x0, y1, w_sw), (x1, y1, w_se)):
         inb = (xx >= 0) & (xx <= W - 1) & (yy >= 0) & (yy <= H - 1)
@@ -195,7 +195,7 @@ def segment_mean(src, offsets, members):
     over the member list in stored order.  src [NV,...] -> [N_c,...] (dtype kept)."""
     out = []
     for c in range(len(offsets) - 1):
-        idx = torch.as_tensor(members[offsets[c]:offsets[c + 1]], dtype=torch.long)
+        idx = torch.as_tensor(members[offsets[c]:offsets[c + 1]], dtype=torch.long, device=src.device)
         out.append(src[idx].mean(0))
     return torch.stack(out)
 
@@ -208,7 +208,9 @@ def vit_forward(x, pe_xyz, sd, depth, prefix="ViT.", heads=3):
     V, N, C = x.shape
     # (32 octaves: the top ones are sin(pi 2^31 x) -- DEFINED by the fp32 rounding of the argument, a hash of x; the table
     # is therefore always the fp32 one, widened when the oracle runs in float64)
-    pe = pe_encode(pe_xyz.float().reshape(-1, 3), C // 6, include_input=False).view(V, N, C).to(x.dtype)
+    # ... and always evaluated on the HOST: sin() of arguments up to pi 2^31 depends on the library's argument reduction, and
+    # the goldens (the reference imported on the host) pin the host's table -- the oracle may run on a device (tools/dense_tail.py)
+    pe = pe_encode(pe_xyz.float().cpu().reshape(-1, 3), C // 6, include_input=False).view(V, N, C).to(x)
     x = x + pe                                                     # :366-367
     hd = C // heads
     for i in range(depth):
@@ -303,18 +305,18 @@ def network_forward(sd, pixel_feat, viewdir, pts_s, centres, blend, tokens, pts_
     P = pts_s.shape[0]
     f_all = pixel_feat.permute(2, 0, 1)
     if pts_mask is not None:
-        raw = torch.zeros((P, 4), dtype=pts_s.dtype)
+        raw = torch.zeros((P, 4), dtype=pts_s.dtype, device=pts_s.device)
         if pts_mask.sum() == 0:
             return raw
         sel = pts_mask
     else:
-        sel = torch.ones(P, dtype=torch.bool)
+        sel = torch.ones(P, dtype=torch.bool, device=pts_s.device)
     ps, f, vd = pts_s[sel], f_all[sel], viewdir[sel]
     h = dparf(ps, centres, blend, tokens, K, n_freq, alpha)
     inter = multiview_agg(sd, h, f)
     sig = alpha_forward(sd, inter)
     if pts_mask is not None:
-        rgb = torch.zeros((ps.shape[0], 3), dtype=pts_s.dtype)
+        rgb = torch.zeros((ps.shape[0], 3), dtype=pts_s.dtype, device=pts_s.device)
         dm = sig[:, 0] > 0
         if dm.sum() > 0:
             rgb[dm] = rgb_forward(sd, inter[dm], f[dm], vd[dm])
@@ -333,7 +335,7 @@ def raw2outputs(raw, z, ray_d, white_bkgd=False):
     d = d * torch.norm(ray_d[..., None, :], dim=-1)                # :37
     c = torch.sigmoid(raw[..., :3])
     a = 1.0 - torch.exp(-F.relu(raw[..., 3]) * d)                  # :27-28,:44
-    T = torch.cumprod(torch.cat([torch.ones((a.shape[0], 1), dtype=a.dtype), 1.0 - a + 1e-10], -1), -1)[:, :-1]
+    T = torch.cumprod(torch.cat([torch.ones((a.shape[0], 1), dtype=a.dtype, device=a.device), 1.0 - a + 1e-10], -1), -1)[:, :-1]
     w = a * T                                                      # :46-49
     rgb = torch.sum(w[..., None] * c, -2)
     depth = torch.sum(w * z, -1)
@@ -388,7 +390,9 @@ def render_fast(sd, batch, holder_feat_map, pixel_feat_map, offsets, members, ca
     pts32 = pts if dt == torch.float32 else sampling_points(ray_o.float(), ray_d.float(), near.float(), far.float(), n_samples)[0]
     vm = hull_mask(pts32.reshape(-1, 3), batch["tar_smpl_vertice"][0].float(), hull).view(R, n_samples)
     hit = vm.sum(-1) > 0                                           # :443
-    out = dict(rgb_map=torch.zeros(1, R, 3, dtype=dt), acc_map=torch.zeros(1, R, dtype=dt), depth_map=torch.zeros(1, R, dtype=dt))
+    dv = ray_o.device
+    out = dict(rgb_map=torch.zeros(1, R, 3, dtype=dt, device=dv), acc_map=torch.zeros(1, R, dtype=dt, device=dv),
+               depth_map=torch.zeros(1, R, dtype=dt, device=dv))
     Rp = int(hit.sum())
     fc = frame_constants(sd, batch, holder_feat_map, offsets, members, can_centres64, vit_depth)
     if Rp == 0:

@@ -129,7 +129,7 @@ def test_s_dense_full_all_rays_and_1024_oracle_rays(hip, gpu, net):
         # wherever sigma > 0, so rgb carries sigmoid(raw) of ONE sample at full weight -- raw-logit rounding noise of the
         # shared front (encoder, TransHE, PE: 5e-5 .. 1.5e-4 between the oracle's own fp32 and fp64 evaluations) shows
         # through undamped.  The HIP path must not be further from the exact result than the reference's fp32 arithmetic.
-        assert g64 < max(2.0 * o64, 2e-5), (name, g64, o64)
+        assert g64 <= o64 + 1e-5, (name, g64, o64)
     hip.drop_workspaces(gpu)
 
 
@@ -149,7 +149,7 @@ def test_nc1500_frame_all_rays_and_512_oracle_rays(hip, gpu, net):
     ref32 = _oracle_on(bc, pick, assign, make_sd())
     ref64 = _oracle_on(bc, pick, assign, make_sd(), dtype=torch.float64)
     g32, g64, o64 = _three_way("N_c=1500 fused", o1, pick, ref32, ref64)
-    assert g32 < BAR_ORACLE and g64 < max(2.0 * o64, 2e-5), (g32, g64, o64)
+    assert g32 < BAR_ORACLE and g64 <= o64 + 1e-5, (g32, g64, o64)
     hip.drop_workspaces(gpu)
 
 
@@ -194,7 +194,7 @@ def test_heavy_tailed_weights_frame(hip, gpu, seed):
     ref64 = _oracle_on(bc, pick, synth_assign(500), sd_cpu, dtype=torch.float64)
     g32, g64, o64 = _three_way(f"heavy-tailed seed {seed} fused", out, pick, ref32, ref64)
     assert float(ref32["acc_map"].max()) > 0.9
-    assert g32 < BAR_ORACLE and g64 < max(2.0 * o64, 2e-5), (g32, g64, o64)
+    assert g32 < BAR_ORACLE and g64 <= o64 + 1e-5, (g32, g64, o64)
     assert not any(v for k, v in hip.guard_state(gpu).items() if k != "epoch")
     hip.drop_workspaces(gpu)
 

@@ -952,6 +952,11 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
 
     ThProf* pf = prof_of(c);
     int32_t* hp = c->host_pinned;
+    // Any per-sample stage that is handed a pool (th_render_rays, th_eval_sigma_grid) becomes the pool's last user: the
+    // "pool is free behind the previous th_render_rays" event th_render_pregather_early relies on is void from here on and
+    // is re-armed only by a th_render_rays that ran to its end (an error return leaves it void: the early path then falls
+    // back to ordering K4 behind everything queued on the stream).
+    if ((prepass == 0 || prepass == 2) && pool != nullptr) c->after_shade_valid = false;
     if (prepass == 2 || prepass == 3) {
         hp = c->host_pinned + 16 + 4 * slot;
         TH_HIP(hipStreamWaitEvent(s, c->prepass[slot].ev, 0));      // the prepass may have run on another stream

@@ -154,6 +154,7 @@ class TokenExchange:
             self.group = dist.new_group() if group is None else group
         self.frame = 0
         self.computed = 0           # frames whose tokens this rank produced itself
+        self.last_mine = False      # the last frame handed out was computed here
         self._last = None
 
     def owner(self, j):
@@ -163,7 +164,7 @@ class TokenExchange:
         """tokens of the next frame: ``compute()`` on the owner, a receive buffer elsewhere, then the broadcast"""
         j = self.frame
         self.frame += 1
-        mine = self.owner(j) == self.rank
+        mine = self.last_mine = self.owner(j) == self.rank
         if mine:
             tok = compute().contiguous()
             assert tuple(tok.shape) == tuple(shape) and tok.dtype == dtype

@@ -335,6 +335,12 @@ def _sync_weights(mod, kind):
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), kind)
     own = _ctx_owner.get(key)
     if own is None or own[0]() is not mod or own[1] != ver:
+        # The context's packed weight image is rewritten in place on the CURRENT stream.  Frame pipelines call this from a
+        # side stream while kernels of earlier frames may still read the image on the shading stream (and the other way
+        # round): a weight change is rare (load_state_dict, an optimiser step between evaluations), so it simply drains the
+        # device first.
+        if own is not None:
+            torch.cuda.synchronize(dev)
         (set_mlp_weights if kind == "mlp" else set_vit_weights)(mod)
         _ctx_owner[key] = (weakref.ref(mod), ver)
         # new weights: back to the modes the caller asked for (the guard re-checks them).  The Network's parameter set
@@ -620,6 +626,8 @@ def map_fold(net, split_map):
     assert isinstance(split_map, SplitMap)
     _sync_weights(net, "mlp")
     V, H, W = split_map.V, split_map.H, split_map.W
+    if split_map.box is not None:
+        _box_checked(split_map.box, H)
     fold = torch.empty((2, V, H, W, 256), dtype=torch.float32, device=split_map.device)
     _check(load_library().th_map_fold(ctx(split_map.device), _p(split_map), V, H, W, _p(split_map.box), _p(fold), _stream()))
     split_map.fold = fold
@@ -637,13 +645,24 @@ def map_box(verts_a, verts_b, cams, scale_xy, H, W, reach):
     # returned tensor is the [V,4] head of that buffer, `map_spans(box, H)` views the rest
     buf = torch.empty(V * 4 + V * int(H) * 2 + V, dtype=torch.int32, device=a.device)      # (+ V flag words of the kernels)
     box = buf[: V * 4].view(V, 4)
+    box._th_map_box = (buf, int(H))              # (a clone / an exchanged [V,4] copy has no spans behind it: _box_checked)
     _check(lib.th_map_box(ctx(a.device), _p(a), a.shape[0], _p(b), b.shape[0] if b is not None else 0, _p(cams), V,
                           _p(scale_xy), int(H), int(W), float(reach), _p(box), _stream()))
     return box
 
 
+def _box_checked(box, H):
+    """``box`` must be the tensor hip.map_box returned (the row spans and flag words th_map_box wrote sit BEHIND it in the
+    same buffer and the C side reads them through the box pointer): a copy of the [V,4] values is refused"""
+    tag = getattr(box, "_th_map_box", None)
+    if tag is None or tag[0].data_ptr() != box.data_ptr() or tag[1] != int(H):
+        raise HipError("box must be the tensor hip.map_box returned for this image height (its row spans follow it in memory)")
+    return box
+
+
 def map_spans(box, H):
     """the [V,H,2] row spans (x0, x1 inclusive; x1 < x0: empty row) th_map_box wrote behind the boxes of ``box``"""
+    _box_checked(box, H)
     V = box.shape[0]
     return torch.as_strided(box, (V, int(H), 2), (int(H) * 2, 2, 1), storage_offset=box.storage_offset() + V * 4)
 
@@ -664,7 +683,7 @@ def upsample_concat_split(images, lat0, lat1, lat2, box=None, reach=0.0):
         return SplitMap(buf, V, H, W)
     assert box.dtype == torch.int32 and tuple(box.shape) == (V, 4) and box.is_contiguous()
     # (th_map_box's buffer: the row spans follow the boxes)
-    assert box.untyped_storage().nbytes() - box.storage_offset() * 4 >= (V * 4 + V * H * 2 + V) * 4, "box must come from hip.map_box"
+    _box_checked(box, H)
     _check(lib.th_upsample_concat_split_box(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf),
                                             _p(box), _stream()))
     src = ThMapSource(_p(box), float(reach), _p(img), _p(l0), _p(l1), _p(l2), dims)

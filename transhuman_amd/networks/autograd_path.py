@@ -68,6 +68,23 @@ def sample_map(feat, uv, enc, image_shape):
     return F.grid_sample(feat, g, align_corners=True, mode="bilinear", padding_mode="border")[:, :, :, 0]
 
 
+_pool_cache = {}
+
+
+def pooling_matrix_cached(renderer, n_verts, device, dtype):
+    """pooling_matrix of the renderer's clustering, built once per (renderer, device, dtype): the dense [N_c, 6890] matrix is
+    a constant of the renderer, not of the call"""
+    key = (id(renderer), int(n_verts), str(device), dtype)
+    ent = _pool_cache.get(key)
+    if ent is None or ent[0]() is not renderer:
+        import weakref
+        if len(_pool_cache) > 16:
+            _pool_cache.clear()
+        ent = (weakref.ref(renderer), pooling_matrix(renderer.csr_offsets, renderer.csr_members, n_verts, device, dtype))
+        _pool_cache[key] = ent
+    return ent[1]
+
+
 def pooling_matrix(offsets, members, n_verts, device, dtype):
     """voxelization (:356-371) as one matrix: row c holds 1 / |cluster c| at the cluster's vertices"""
     rows = torch.repeat_interleave(torch.arange(len(offsets) - 1), torch.as_tensor(offsets[1:] - offsets[:-1]))
@@ -170,11 +187,11 @@ def render(renderer, batch, chunk=32768):
     if cfg.rasterize:
         painted = painted * batch["input_vizmaps"][0][0][..., None].to(painted.dtype)              # :181-182
     nv = verts_in.shape[0]
-    M = pooling_matrix(renderer.csr_offsets, renderer.csr_members, nv, dev, torch.float32)
+    M = pooling_matrix_cached(renderer, nv, dev, torch.float32)
     tokens = vit_forward(net.ViT, torch.einsum("cn,vnd->vcd", M, painted), renderer._pe_norm(V, dev))
     centres = M @ batch["tar_smpl_vertice_smplcoord"][0]
     blend = batch["blend_mtx"][0]
-    M64 = pooling_matrix(renderer.csr_offsets, renderer.csr_members, nv, dev, blend.dtype)        # (float64 mean, :544)
+    M64 = pooling_matrix_cached(renderer, nv, dev, blend.dtype)        # (float64 mean, :544)
     rot = (M64 @ blend.reshape(nv, 16)).reshape(-1, 4, 4)[:, :3, :3].to(torch.float32)             # cross_transformer.py:185
 
     raws = []

@@ -151,8 +151,14 @@ class Renderer:
         if fused_encoder_tail and hasattr(enc, "trunk"):
             H, W = images.shape[2:]
             V = images.shape[0]
+            # (a device whose stem has been switched to the stock convolutions -- range guard, or non-finite latents received
+            # from another rank -- computes its own latents from here on: the owner rank may not have switched yet)
+            # -- it still takes part in the exchange (a collective: the other ranks wait for its turn as owner) but drops what
+            # it receives
             lat = enc.trunk(images) if stem_exchange is None else stem_exchange.latents(enc.trunk, images)
             stem_flag = None if stem_exchange is None else stem_exchange.last_flag
+            if stem_exchange is not None and hip.conv_fallback(dev) and not stem_exchange.last_mine:
+                lat, stem_flag = enc.trunk(images), None
             cw, cb = enc.upsample_color.weight, enc.upsample_color.bias
             scale = hip.feat_scale(enc.feat_scale(H, W), image_shape, dev)
             thr = cfg_hull() if hull_thresh is None else hull_thresh
@@ -417,11 +423,13 @@ class Renderer:
         def finish(ent):
             rgb, acc, depth, stats, frame, cur, pts, check, epoch = ent
             ok = check()
-            if getattr(frame, "stem_flag", None) is not None and bool(frame.stem_flag):
+            bad_stem = getattr(frame, "stem_flag", None) is not None and bool(frame.stem_flag)
+            if bad_stem:
                 hip.force_conv_fallback(dev, "the stem latents received for this frame are not finite (fp16 overflow in "
                                              "the owner rank's convolutions)")
-            if not ok or epoch != hip.range_epoch(dev):
-                if hip.conv_fallback(dev) or hip.vit_fallback(dev):
+            # (bad_stem on its own is a reason to rebuild: once the device is in conv fallback the epoch does not move again)
+            if not ok or bad_stem or epoch != hip.range_epoch(dev):
+                if bad_stem or hip.conv_fallback(dev) or hip.vit_fallback(dev):
                     frame = frame.rebuild()                 # constants again, through the paths the guard switched to
                 rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
                                                          small_frame_rays=small_frame_rays)
@@ -481,6 +489,13 @@ class Renderer:
             if not batch["ray_o"].is_cuda:
                 raise hip.HipError("Renderer.render needs the batch on an MI355X (there is no CPU path)")
             from transhuman_amd.networks import autograd_path
+            n_rays = int(batch["ray_o"].shape[1])
+            if wants_grad and not randomised and n_rays > 4 * 2400:
+                # the reference trains on patches of <= 2400 rays (:551); a whole frame with gradients enabled is almost
+                # always an evaluation loop that forgot torch.no_grad() -- it would build the autograd graph of every sample
+                import warnings
+                warnings.warn(f"Renderer.render: {n_rays} rays with gradients enabled take the differentiable torch path "
+                              "(training entry), not the HIP kernels; wrap inference in torch.no_grad()", RuntimeWarning)
             out = autograd_path.render(self, batch)
             self.last_stats = dict(hit_rays=int(batch["ray_o"].shape[1]), valid_samples=int(batch["ray_o"].shape[1]) * int(cfg.N_samples),
                                    unmasked=1)
