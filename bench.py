@@ -87,7 +87,7 @@ def hbm_traffic():
         return None
 
 
-def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_step=None, n_valid=0, folded_flops=0.0):
+def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_step=None, n_valid=0, folded_flops=0.0, fold_ms=0.0):
     """Dominant kernel = the per-point MLP.  `achieved` counts ALGORITHMIC fp32 FLOPs (the reference's
     layer shapes).  mode 1 (default): the fused kernel evaluates every fp32 MAC as three fp16 MFMA MACs
     (hi*hi + hi*lo + lo*hi, fp32 accumulate), so the pipe it is bound by is the fp16 MFMA pipe at one third
@@ -106,8 +106,18 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
     # the committed PMC pass measured launches of t["launch_samples"] samples: bytes per sample x this run's samples per launch
     per_launch = (float(n_valid) / max(launches, 1.0) / t["launch_samples"]) if t else 0.0
     traffic = t["mlp_fused_bytes_per_launch"] * per_launch if t else None
-    return {"bound": "mfma", "kernel": kernel, "achieved": achieved / 1e12, "peak": peak / 1e12,
-            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+    # `frac`: the reference's layer shapes (ALGORITHMIC FLOPs) over the time of EVERY kernel that evaluates them -- the fused
+    # kernel's launches plus map_fold_kernel's (the three folded layers are its work; its HIP-event span on the side stream is
+    # stretched by the overlap with the shading, which errs on the low side).  `frac_executed` / `mfma_pipe_util` say how busy
+    # the matrix pipe really is; the round-4 line divided by the fused kernel's time alone (kept as `frac_fused_kernel_time_only`).
+    total_s = max((stage_ms + fold_ms) * 1e-3, 1e-12)
+    frac = flops_step / total_s / peak
+    return {"bound": "mfma", "kernel": kernel, "achieved": flops_step / total_s / 1e12, "peak": peak / 1e12,
+            "unit": "TFLOP/s", "frac": frac, "traffic": traffic,
+            "frac_note": "algorithmic FLOPs / (mlp_fused_kernel + map_fold_kernel time) / (fp16 MFMA peak / 3); read with "
+                         "frac_executed (MFMA work the pipe actually did / time / the same peak) and mfma_pipe_util",
+            "frac_fused_kernel_time_only": achieved / peak,
+            "fold_kernel_ms_per_step": fold_ms,
             "traffic_note": (f"HBM bytes per launch ({n_valid / max(launches, 1.0):.0f} samples), rocprofv3 PMC (" + t["source"] +
                              f", measured on a launch of {t['launch_samples']} samples); algorithmic " +
                              f"{t['mlp_fused_algorithmic_bytes_per_launch'] * per_launch:.3g} (" + t["algorithmic_note"] + ")") if t else
@@ -616,9 +626,14 @@ def main():
     torch.cuda.synchronize()
     hip.host_wait_read(dev)
     dist_wait[0] = 0.0
+    # per-step device time: one event behind every step on the shading stream (the frame pipeline hands out frame i when frame
+    # i + 1 is queued: consecutive events are one steady-state frame apart)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
     t0 = time.perf_counter()
     for i in range(args.steps):
         img, stats = step()
+        marks[i + 1].record()
         if i < n_probe:
             with torch.cuda.stream(probe_stream):
                 hip.clock_probe(clk[i])
@@ -634,6 +649,7 @@ def main():
         _np.save(os.environ["TH_SAVE_IMAGE"], img.detach().cpu().numpy())
     prof = hip.profile_read()
     hip.profile_enable(False)
+    step_ms = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]) if args.steps > 0 else np.zeros(1)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -658,6 +674,12 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            # spread over the timed steps (HIP events on the shading stream, one per step; rank 0)
+            "ms_per_step_min": float(step_ms.min()), "ms_per_step_median": float(np.median(step_ms)),
+            "ms_per_step_max": float(step_ms.max()),
+            # rays/s depends on the synthetic frame's hit rate (19.5 % of the rays hit the hull here); shaded samples/s does not --
+            # the all-valid S_dense_full frame of `extra` runs at the same samples/s and 1/8 of the rays/s
+            "valid_samples_per_s_rank0": float(stats["valid_samples"]) * args.steps / dt,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -676,7 +698,8 @@ def main():
             },
             "roofline": roofline_block(args.mlp_mode, achieved, flops_step, mlp_ms / max(args.steps, 1),
                                        mlp_launches / max(args.steps, 1), executed_mlp_flops(V, n_valid, n_pos, map_fold=args.mlp_mode == 1 and hip.tex_rows_enabled(dev)), n_valid=n_valid,
-                                       folded_flops=(2.0 * V * (98304.0 * n_valid + 147456.0 * n_pos)) if (args.mlp_mode == 1 and hip.tex_rows_enabled(dev)) else 0.0),
+                                       folded_flops=(2.0 * V * (98304.0 * n_valid + 147456.0 * n_pos)) if (args.mlp_mode == 1 and hip.tex_rows_enabled(dev)) else 0.0,
+                                       fold_ms=prof["fold"][0] / max(args.steps, 1)),
             "gather": (texel_handover_block if hip.tex_rows_enabled(dev) else gather_block)(V, n_valid, prof["gather"][0] / max(args.steps, 1)),
             # what the range guard of the fp16 hi/lo split has switched on this device (every entry false = the fast paths
             # ran; a tripped MLP guard means per-layer fp32 launches, ~7x slower frames) + the last table read (fp16 bit
@@ -704,6 +727,10 @@ def main():
             ms_rf, _ = time_steps(lambda: renderer.render_fast(shard), max(3, args.steps // 2), warmup=1)
             res["render_fast_ms_per_step"] = ms_rf
             res["render_fast_rays_per_s"] = R / ms_rf * 1e3
+            # the number a caller of the UNCHANGED run.py gets (run.py:52,109 call render_fast per frame; `value` above is
+            # Renderer.render_sequence, the frame pipeline a video / evaluation loop can opt into)
+            res["dropin_ms_per_step"] = ms_rf
+            res["dropin_rays_per_s"] = R / ms_rf * 1e3
             if args.mlp_mode == 1 and not args.no_extras:
                 res["fused_vs_fp32_full_frame"] = fused_vs_fp32(renderer, batch, hip)
         if world == 1 and not args.no_cpu_baseline and not emu:

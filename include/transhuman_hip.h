@@ -47,7 +47,7 @@ void        th_ctx_destroy(th_ctx* ctx);
  * hipEventRecord on `stream`; th_profile_read drains the accumulated
  * per-phase milliseconds / launch counts (arrays of TH_PROF_PHASES). */
 enum { TH_PROF_HULL = 0, TH_PROF_DPARF = 1, TH_PROF_GATHER = 2, TH_PROF_MLP = 3, TH_PROF_COMPOSITE = 4,
-       TH_PROF_VIT = 5, TH_PROF_PHASES = 8 };
+       TH_PROF_VIT = 5, TH_PROF_FOLD = 6 /* th_map_fold: the f-consuming layers applied to the map's texels */, TH_PROF_PHASES = 8 };
 int th_profile_enable(th_ctx* ctx, int on);
 int th_profile_read(th_ctx* ctx, double* ms_out, int64_t* count_out);
 /* Host milliseconds the calling thread spent inside the BLOCKING waits of the entry points (sample counts of

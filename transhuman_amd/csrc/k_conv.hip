@@ -135,7 +135,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
         const float* xn = x + (long long)n * CIN * H * W;
         const long long HW = (long long)H * W;
         unsigned rmax = 0u;
-#ifndef CV_SKIP_STAGE
         for (int it0 = tid; it0 < ITEMS; it0 += 256 * SB) {
             float v[SB][4];
             int off[SB];
@@ -166,7 +165,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
                 }
             }
         }
-#endif
         cv_range_commit(range, rmax);
     }
     __syncthreads();
@@ -212,9 +210,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
     for (int j = 0; j < DW - 1; ++j)
         if (j < STEPS) load_w(j, j);
     load_x(0, 0);
-#ifdef CV_SKIP_GEMM
-    if (inv_scale == 12345.f)
-#endif
 #pragma unroll 1
     for (int st0 = 0; st0 < STEPS; st0 += DW) {
 #pragma unroll
@@ -445,9 +440,7 @@ int th_conv2d_launch(const float* x, int N, int CIN, int H, int W, const void* p
     const uint4* wp = (const uint4*)packed;
     if (CIN == 3 && COUT == 64 && KS == 7 && stride == 2) return conv1_launch(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
     if (CIN == 64 && COUT == 64 && KS == 3 && stride == 1)
-        #ifndef CV_TR64
 #define CV_TR64 4
-#endif
         return conv_launch_t<64, 64, 1, 3, CV_TR64, 2>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
     if (CIN == 64 && COUT == 128 && KS == 3 && stride == 2)
         return conv_launch_t<64, 128, 2, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);

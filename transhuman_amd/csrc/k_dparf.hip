@@ -60,9 +60,6 @@ typedef _Float16 dp_h4 __attribute__((ext_vector_type(4)));
 // fifth of the instructions of the full-range library sinf, which made the PE channels the largest VALU block
 // of this kernel.
 __device__ __forceinline__ float dp_sin(float a) {
-#if defined(DP_EXP) && DP_EXP == 1
-    return a;                                              // timing build: what the kernel costs without its sines
-#endif
     const float k = rintf(a * 0.15915494309189535f);
     float r = fmaf(-k, 6.28125f, a);                       // 2*pi = 6.28125 + 1.93500518798828125e-3 + 3.0199159819e-7
     r = fmaf(-k, 1.93500518798828125e-3f, r);
@@ -78,9 +75,7 @@ __device__ __forceinline__ float dp_sin(float a) {
 // neighbours, distances and tie order as scanning all N_c centres, with ~70 instead of N_c candidates.  Points
 // outside the grid fall back to the full scan.  Built once per frame (thousands of tiny blocks, ~20 us).
 #define DPG_MAXCELLS 8192
-#ifndef DPG_CELL
 #define DPG_CELL 0.075f        // cell size asked for; 0.1: lists of ~70 candidates, 0.075: ~55, K4 0.73 -> 0.71 ms; (dpgrid_setup_kernel grows it until the grid fits DPG_MAXCELLS)
-#endif
 struct DpGrid {
     float gmin[3];
     float g, inv_g;
@@ -253,9 +248,6 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                 nlist = cell_count[cell];
             }
         }
-#if defined(DP_EXP) && DP_EXP == 2
-        nlist = min(nlist, 14);                            // timing build: a scan of 7 candidates per lane
-#endif
         for (int j = half; j < nlist; j += 2) {
             const int c = list ? list[j] : j;
             float dx = x - cen[3 * c], dy = y - cen[3 * c + 1], dz = z - cen[3 * c + 2];
@@ -327,7 +319,6 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
     const float PI_F = 3.14159274101257324219f;          // fp32(pi)
     const float HALF_PI_F = 1.57079637050628662109f;     // fp32(pi/2)
     if constexpr (FOLDED && VT < 0) {
-#ifndef DP_PHASE2_WAVE
         // TH_ROWS_NBR writes no table rows, so nothing here is 64 lanes wide: FOUR samples per wave step, 16 lanes each.
         // Lane q of a sample owns the PE channels 4 q .. 4 q + 3 (channel 63 is the row's zero pad) -- the same 441 sines per
         // sample, every term and the order of the seven-term sums as in the wave-per-sample loop below (bit-identical rows),
@@ -389,7 +380,6 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
             *reinterpret_cast<dp_h4*>(ph + 64 + 4 * l16) = lo;
         }
         return;
-#endif
     }
     // PE channel `lane` (0..62): 0..2 raw xyz; then per octave f: sin xyz, cos xyz
     int axis = 0, oct = 0;

@@ -346,9 +346,7 @@ __global__ __launch_bounds__(256) void hull_mask_seq_kernel(ThPointSrc ps, long 
 // < 27 looks up the vertex range of screened cell l, then the 64 lanes test 64 vertices of a cell per step and the first
 // ballot with a set bit ends the sample.  The outcome is bit-identical (the predicate and its operands are unchanged, an
 // "or" over the same set); the near-miss samples cost ~5 wave steps instead of ~200 lane iterations.
-#ifndef HULL_PROBE
 #define HULL_PROBE 8
-#endif
 __global__ __launch_bounds__(256) void hull_mask_kernel(ThPointSrc ps, long long P, const GridInfo* __restrict__ gi,
                                                         const int* __restrict__ starts,
                                                         const float* __restrict__ sorted,

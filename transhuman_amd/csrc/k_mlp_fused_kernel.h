@@ -132,10 +132,8 @@ __device__ __forceinline__ void stage_glds(const _Float16* __restrict__ src, int
             p = p < npts ? p : npts - 1;
             const int col = slot < DS ? slot * 32 : 0;
             const char* g = gbase + (long long)((pbase + p) * V + vw) * (4 * KROW) + col;
-#ifndef FM_STAGE_AUX
 #define FM_STAGE_AUX 0      // cache-policy bits of the staging loads (1 = sc0, 2 = nt, 16 = sc1); nt / nt + sc1: +5 % per tile
                             // (135.5 k vs 130 k cycles): the RGB branch's second filling lives on what the first left in L2
-#endif
             __builtin_amdgcn_global_load_lds((fm_gptr)g, (fm_lptr)(hi + c * 1024), 16, 0, FM_STAGE_AUX);
             __builtin_amdgcn_global_load_lds((fm_gptr)(g + 16), (fm_lptr)(lo + c * 1024), 16, 0, FM_STAGE_AUX);
         }
@@ -188,11 +186,7 @@ __device__ __forceinline__ void load_wfrag(const uint4* __restrict__ wl, int kb,
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
         w[c][0] = p[(c * 2 + 0) * 64];
-#ifdef FM_EXP_HALFW      // timing experiment only (wrong results): half the weight bytes
-        w[c][1] = w[c][0];
-#else
         w[c][1] = p[(c * 2 + 1) * 64];
-#endif
     }
 }
 
@@ -214,12 +208,8 @@ template <> struct FLay<1> { static constexpr int LD = 272, KA = 272, KB2 = 0, S
 //    of latency tolerance, no register copies (loop unrolled by D, D even);
 //  * activation fragments (LDS, ds_read_b128) ping-pong between two register sets: block k+1 is read
 //    while block k multiplies, so no burst starts with an exposed LDS round trip.
-#ifndef FM_RING_D
 #define FM_RING_D 4       // weight ring depth of the 3-column-tile (key/value) phases: register-tight
-#endif
-#ifndef FM_RING_D2
 #define FM_RING_D2 4      // ... of the 1- and 2-column-tile phases
-#endif
 template <int CT, int RT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[CT][RT]) {
 #pragma unroll
@@ -262,7 +252,6 @@ __device__ __forceinline__ void ring_step(const char* __restrict__ ahi, const ch
     // instruction after each of the first MFMAs: the 2*CT global loads + 2*RT ds_reads issue in the
     // shadow of running MFMAs instead of in front of the burst.
     const int kx = (kb + j + 1 < KB) ? kb + j + 1 : KB - 1;
-#ifndef FM_EXP_NOW       // timing experiments only (wrong results): drop the in-loop weight / activation loads
     if (RAMP) {
 #pragma unroll
         for (int q = 1; q < D; ++q) load_wfrag<CT>(wl, q < KB ? q : KB - 1, w[q]);
@@ -270,11 +259,8 @@ __device__ __forceinline__ void ring_step(const char* __restrict__ ahi, const ch
         const int kw = (kb + j + D - 1 < KB) ? kb + j + D - 1 : KB - 1;
         load_wfrag<CT>(wl, kw, w[(j + D - 1) % D]);
     }
-#endif
     if (XPP) {
-#ifndef FM_EXP_NOX
         load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kx, xh[(j + 1) & 1], xl[(j + 1) & 1]);
-#endif
         mfma_kblock<RT, CT, FIRST>(w[j], xh[j & 1], xl[j & 1], acc);
     } else {   // register-tight phases: one activation set, read right before its burst
         load_xfrag<RT, STR, ROWSTEP>(ahi, alo, aoff, kb + j, xh[0], xl[0]);
@@ -574,11 +560,7 @@ __device__ __forceinline__ const uint4* wslice(const FusedLayer& L, int wave, in
 
 // FM_NUM_VGPR (build experiment): cap the architectural VGPRs so that the wave's unified allocation (VGPRs + AGPRs)
 // stays below 512 and a low-register kernel of another stream can become co-resident on the same SIMDs
-#ifdef FM_NUM_VGPR
-#define FM_VGPR_ATTR __attribute__((amdgpu_num_vgpr(FM_NUM_VGPR)))
-#else
 #define FM_VGPR_ATTR
-#endif
 template <int V, int FM, bool TEX = false>
 __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedParams P) {
     using FL = FLay<FM>;
@@ -648,15 +630,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         if (tid < 64 * V) t.rq = *reinterpret_cast<const fm_u4*>(P.tex_rec + (long long)tl * V * 32 * 8 + tid * 4);
         return t;
     };
-    // timing builds only (wrong images): -DTX_EXP=1 every request reads texel 0 of the map (L1 / L2 hits: what the row
-    // requests cost without the memory system), -DTX_EXP=2 the texel of the first list entry (one row per tile)
-#if defined(TX_EXP) && TX_EXP == 1
-#define TX_ADDR(id) (size_t)(((id) & 0u) + loff)
-#elif defined(TX_EXP) && TX_EXP == 2
-#define TX_ADDR(id) (size_t)((((unsigned)__builtin_amdgcn_readlane((int)h0, 8) + ((id) & 0u)) << 10) + loff)
-#else
 #define TX_ADDR(id) (size_t)(((id) << 10) + loff)
-#endif
     // `rgb` (a std::bool_constant): false = pixel branch: rows of fold0 (alpha_res_0 of the texels), p = relu(blend + bias) written
     // as the hi / lo operand planes of kv0; true = RGB branch: rows of fold12 ([Wa rgb_res_0 | rgb_res_1] of the texels), the
     // blended fp32 rows written to ABUF ([row][256], 1040-byte rows) for the accumulator-layout reads of the epilogue.
@@ -1082,9 +1056,6 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         f32x16 acc3[3][V];
         gemm_phase_core<V, 3, STR256, 32 * STR256, FM_RING_D, true, 7, true>(abuf, a256_lo, wslice(P.kv1, wave, 3, 0), P.kv1.KB, lane,
                                                                             acc3, wk3);
-#ifdef FM_STAMPS
-        FM_STAMP();
-#endif
         {
             const BiasT bk = load_bias(P.kv1.bias, wave * 32, lane), bv0 = load_bias(P.kv1.bias, 128 + wave * 64, lane),
                         bv1 = load_bias(P.kv1.bias, 128 + wave * 64 + 32, lane);
@@ -1111,15 +1082,9 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         fill_tex(tex_pre, std::false_type{}, [] {});
     } else {
     stage_glds<V, FL::LD, FL::KA, FL::SA>(P.f, 0, pbase, npts, abuf, fa_lo, wave, lane);
-#ifdef FM_STAMPS
-    FM_STAMP();
-#endif
     ring_prefetch0<2, FM_RING_D2>(wslice(P.ar0, wave, 2, 0), lane, wk2);
     FM_SYNC();
     gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 3, true>(abuf, fa_lo, wslice(P.ar0, wave, 2, 0), FL::NA, lane, acc2, wk2);
-#ifdef FM_STAMPS
-    FM_STAMP();
-#endif
     const BiasT bp[2] = {load_bias(P.ar0.bias, wave * 64, lane), load_bias(P.ar0.bias, wave * 64 + 32, lane)};
     FM_SYNCL();
     if constexpr (FL::NB > 0) {
@@ -1201,17 +1166,11 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
 #pragma unroll
             for (int ji = 0; ji < V * V; ++ji) {
                 float s = acc[ji];
-#ifdef FM_EXP_SHFL
-                s += __shfl_xor(s, 1);
-                s += __shfl_xor(s, 2);
-                s += __shfl_xor(s, 4);
-#else
                 // sum over the 8 lanes of a sample with DPP moves (VALU, no LDS round trip like ds_bpermute): quad
                 // neighbours, quad halves, then the mirrored lane of the other quad of the 8-lane group
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));  // row_half_mirror
-#endif
                 acc[ji] = s / 11.313708498984761f;          // every lane of the 8-lane group holds the full sum
             }
             // softmax over j for each (sample, i), computed by every lane of the group (9 exponentials; as its own
@@ -1290,9 +1249,6 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     FM_SYNCL();
     gemm_phase_core<V, 2, STR256, 32 * STR256, FM_RING_D2, true, 3, true>(abuf, a256_lo, wslice(P.fc_2, wave, 2, 0), P.fc_2.KB, lane, acc2,
                                                                          wk2);
-#ifdef FM_STAMPS
-    FM_STAMP();
-#endif
     const BiasT bi[2] = {load_bias(P.fc_2.bias, wave * 64, lane), load_bias(P.fc_2.bias, wave * 64 + 32, lane)};
     FM_SYNCL();
     // inter = relu(.) -> ABUF (operand of feature_fc); its view mean -> MBUF (operand of fc_3)
@@ -1347,17 +1303,11 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         const BiasT b3[2] = {load_bias(P.fc_3.bias, wave * 64, lane), load_bias(P.fc_3.bias, wave * 64 + 32, lane)};
         // the view_fc product on inter does not depend on sigma: it shares the loop with fc_3 (see gemm_dual_fc3_vfa)
         // unless no sample can need colour (sigma-only consumers)
-#ifdef FM_STAMPS
-        FM_STAMP();
-#endif
         if (P.rgb_all != 2)
             gemm_dual_fc3_vfa<V>(mbuf, mbuf + 32 * STR256, abuf, a256_lo, wslice(P.fc_3, wave, 2, 0), wslice(P.vfA, wave, 1, 0),
                                  lane, a1, vf);
         else
             gemm_phase_z<1, 2, STR256, 32 * STR256, 6>(mbuf, mbuf + 32 * STR256, wslice(P.fc_3, wave, 2, 0), P.fc_3.KB, lane, a1);
-#ifdef FM_STAMPS
-        FM_STAMP();
-#endif
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -1422,9 +1372,6 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
         }
         if constexpr (!TEX) {
         gemm_phase_core<V, 2, FL::SA, 32 * FL::SA, FM_RING_D2, true, 0, true>(abuf, fa_lo, wslice(P.rst, wave, 2, 0), FL::NA, lane, acc2, wk2);
-#ifdef FM_STAMPS
-        FM_STAMP();
-#endif
         if constexpr (FL::NB > 0) {
             FM_SYNCL();
             stage_glds<V, FL::LD, FL::KB2, FL::SB>(P.f, FL::KA, pbase, npts, abuf, fb_lo, wave, lane);
@@ -1569,19 +1516,10 @@ struct MapFoldParams {
 
 // MF_RT row tiles of 32 texels per workgroup.  Measured on the headline frame's boxes (342 k texels, tools/fold_time.py): 3 (96
 // texels, one workgroup per CU) 0.55 ms; 2 (64 texels, two workgroups per CU, meant to overlap one's staging with the other's
-// GEMMs) 0.65 ms -- the launch is bound by the weight stream, 557 KB per workgroup out of L2 whatever its row count (timing
-// builds -DMF_EXP: stores 0.20 ms, the two GEMMs 0.28 ms, staging + launch 0.17 ms, additive), so more rows per workgroup win.
-// timing builds only (wrong maps): -DMF_EXP=1 no stores, -DMF_EXP=2 four k-blocks instead of 17 in both GEMMs
-#if defined(MF_EXP) && MF_EXP == 1
-#define MF_STORE(c) ((c) && P.V > 1000)
-#else
+// GEMMs) 0.65 ms -- the launch is bound by the weight stream, 557 KB per workgroup out of L2 whatever its row count (by
+// parts, round 4: stores 0.20 ms, the two GEMMs 0.28 ms, staging + launch 0.17 ms, additive), so more rows per workgroup win.
 #define MF_STORE(c) (c)
-#endif
-#if defined(MF_EXP) && MF_EXP == 2
-#define MF_KB 4
-#else
 #define MF_KB 17
-#endif
 #define MF_RT 3
 #define MF_TEX (32 * MF_RT)
 __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {

@@ -17,9 +17,7 @@
 #include "th_internal.h"
 
 #define PG_G 16
-#ifndef PG_B
 #define PG_B 4      // rows per batch: 4 PG_B corner loads in flight per wave
-#endif
 typedef _Float16 pg_h4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void pg_split(float x, _Float16& hi, _Float16& lo) {
     hi = (_Float16)x;
@@ -63,14 +61,8 @@ __device__ __forceinline__ void pg_store8(float* __restrict__ orow, int g, float
 #pragma unroll
         for (int e = 0; e < 4; ++e) pg_range_acc(rm, reinterpret_cast<const unsigned*>(&hv)[e]);
         _Float16* og = reinterpret_cast<_Float16*>(orow) + 16 * g;
-#ifndef PG_EXP_NOSTORE      // timing experiments only
         *reinterpret_cast<pg_h8*>(og) = hv;
-#ifndef PG_EXP_NOLO
         *reinterpret_cast<pg_h8*>(og + 8) = lv;
-#endif
-#else
-        if (hv[0] == (_Float16)123.f && lv[1] == (_Float16)77.f) *reinterpret_cast<pg_h8*>(og) = hv;
-#endif
     }
 }
 // Contiguous form of pg_store8 for the latents of a split row: lane gl of a half-wave holds channels 4 gl .. 4 gl + 3 (a) and
@@ -78,9 +70,7 @@ __device__ __forceinline__ void pg_store8(float* __restrict__ orow, int g, float
 // the 8 hi halves and lane 2k+1 the 8 lo halves of channel group k (a) and of group 16 + k (b): piece gl of the row's first 512
 // bytes and piece gl of its second -- two store instructions that each write 512 contiguous bytes per half-wave.
 // Every lane of the wave must call this (DPP reads the neighbour); `live` masks the stores.
-#ifndef PG_CONTIG
 #define PG_CONTIG 1
-#endif
 __device__ __forceinline__ unsigned pg_swap1(unsigned v) {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
 }
@@ -144,18 +134,8 @@ __device__ __forceinline__ void pg_store4(float* __restrict__ orow, int ldo, int
         pg_split(r.w, x, y); hv[3] = x; lv[3] = y;
         pg_range_acc(rm, reinterpret_cast<const unsigned*>(&hv)[0]);
         pg_range_acc(rm, reinterpret_cast<const unsigned*>(&hv)[1]);
-#ifndef PG_EXP_NOSTORE      // timing experiments only
         *reinterpret_cast<pg_h4*>(oh + 4 * c4) = hv;
-#ifndef PG_EXP_NOLO
-#ifdef PG_EXP_LOSAME     // timing experiment only (wrong results): second store instruction, same bytes
-        *reinterpret_cast<volatile pg_h4*>(oh + 4 * c4) = lv;
-#else
         *reinterpret_cast<pg_h4*>(oh + ldo + 4 * c4) = lv;
-#endif
-#endif
-#else
-        if (hv[0] == (_Float16)123.f && lv[1] == (_Float16)77.f) *reinterpret_cast<pg_h4*>(oh) = hv;
-#endif
     }
 }
 

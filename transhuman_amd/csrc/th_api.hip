@@ -578,6 +578,7 @@ int th_pixel_gather_split(th_ctx* c, const float* map_split, int V, int H, int W
 int th_map_fold(th_ctx* c, const float* map_split, int V, int H, int W, const int32_t* box, float* fold, th_stream stream) {
     TH_REQUIRE(c && map_split && fold, "null argument");
     TH_REQUIRE(c->fused_ready && c->fused.compact_ready, "th_map_fold needs the MLP weights incl. upsample_color (th_set_mlp_weights)");
+    ProfScope sc(prof_of(c), TH_PROF_FOLD, (hipStream_t)stream);
     return th_map_fold_launch(c->fused, map_split, V, H, W, box, fold, c->range_dev, (hipStream_t)stream);
 }
 

@@ -1325,7 +1325,7 @@ def set_chunk_samples(n):
     _check(load_library().th_set_chunk_samples(int(n)))
 
 
-PROF_PHASES = ("hull", "dparf", "gather", "mlp", "composite", "vit", "_6", "_7")
+PROF_PHASES = ("hull", "dparf", "gather", "mlp", "composite", "vit", "fold", "_7")
 
 
 def profile_enable(on=True, device=None):
@@ -1337,7 +1337,7 @@ def profile_read(device=None):
     ms = (C.c_double * 8)()
     cnt = (C.c_int64 * 8)()
     _check(load_library().th_profile_read(ctx(device), ms, cnt))
-    return {PROF_PHASES[i]: (ms[i], cnt[i]) for i in range(6)}
+    return {PROF_PHASES[i]: (ms[i], cnt[i]) for i in range(7)}
 
 
 def clock_probe(out):
