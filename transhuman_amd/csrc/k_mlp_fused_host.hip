@@ -401,13 +401,6 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
 #undef FM_ATTR_T
     }
     dim3 grid(tex ? 8 * th_cdiv(th_cdiv(P, FM_PTS), 8) : th_cdiv(P, FM_PTS));     // (TEX: XCD-contiguous tile order)
-    // developer experiment (timing only, results are wrong): alias every layer's weights onto fc_1's image
-    // so the weight working set is 256 KB -> shows how much of a phase is L2-capacity/latency
-    static int alias_w = getenv("TH_FUSED_ALIAS_W") ? 1 : 0;
-    if (alias_w) {
-        FusedLayer* ls[] = {&p.kv1, &p.ar0, &p.kv0, &p.fc_2, &p.fc_3, &p.vfA, &p.rst, &p.fc_4};
-        for (auto* l : ls) l->w = p.kv1.w;
-    }
     // developer aid: TH_FUSED_DBG=1 -> average cycles between barriers over every 16th tile (first big launch only)
     static int dbg_state = getenv("TH_FUSED_DBG") ? 1 : 0;
     static long long* dbg_dev = nullptr;
