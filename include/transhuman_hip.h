@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 8
+#define TH_ABI_VERSION 9
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -238,6 +238,19 @@ int th_map_box(th_ctx* ctx, const float* verts_a, int na, const float* verts_b, 
 int th_upsample_concat_split_box(th_ctx* ctx, const float* img, const float* lat0, const float* lat1, const float* lat2,
                                  const int32_t* dims_host, int V, int H, int W, float* out, const int32_t* box,
                                  th_stream stream);
+/* Demand-driven map (round 5).  Behind a th_render_prepass the texels a frame reads are known exactly: the four bilinear
+ * corners, in every view, of the prepass's valid samples (get_pixel_aligned_feature, if_clight_renderer.py:210-269 behind the
+ * hull mask :440-444) and of the painted input vertices (:168-172).  th_render_predemand (below, with the frame-level entry
+ * points) marks them in a demand buffer of th_map_demand_bytes(V, H, W) bytes -- on the device, no host synchronisation --;
+ * th_upsample_concat_split_demand writes only those texels of `out` (inside `box`, which may be NULL) and th_map_fold_demand
+ * evaluates the folded layers only at the samples' texels (a compacted list: full tiles wherever the texels lie).  A rank of an
+ * N-rank job reads about 1 / N of what the whole frame reads, so the map write and the fold shrink with the ray shard.  W must
+ * be a multiple of 64.  Frames built this way carry the buffer in th_map_source.demand: a frame-level call whose sample list is
+ * not the one the buffer was made from writes the rest of the map first (like the other premises of a cropped map). */
+size_t th_map_demand_bytes(int V, int H, int W);
+int th_upsample_concat_split_demand(th_ctx* ctx, const float* img, const float* lat0, const float* lat1, const float* lat2,
+                                    const int32_t* dims_host, int V, int H, int W, float* out, const int32_t* box,
+                                    const void* demand, th_stream stream);
 /* paint_neural_human + can_body_grouping without materialising holder_feat_map: reduction_layer
  * (1x1 conv C->out_f, encoder.py:85,146) commutes with the bilinear sampling at :168-172, so the C-channel
  * channels-last map is sampled at the projected vertices and the layer is applied to those V*n_verts
@@ -323,6 +336,7 @@ int th_pixel_gather_split(th_ctx* ctx, const float* map_split, int V, int H, int
  * (no biases; the colour lift is inside, th_mlp_weights.upsample_color).  box: th_map_box's output (boxes + row spans) -> only
  * texels inside each row's span are computed, or NULL: the whole map.  Once per frame, after th_set_mlp_weights; th_frame.map_fold. */
 int th_map_fold(th_ctx* ctx, const float* map_split, int V, int H, int W, const int32_t* box, float* fold, th_stream stream);
+int th_map_fold_demand(th_ctx* ctx, const float* map_split, int V, int H, int W, const void* demand, float* fold, th_stream stream);
 
 /* K5t, the producer of the texel hand-over (th_set_tex_rows; k_pixtex.hip), on its own -- exposed for tests.  Samples are taken
  * in tiles of 32 consecutive entries (of `sel`, or of the points when sel is NULL); out (th_pixel_texlist_bytes(V, P) bytes,
@@ -442,6 +456,8 @@ typedef struct {
     const float*   lat1;
     const float*   lat2;
     int32_t        dims[6];
+    const void*    demand;         /* NULL, or the th_render_predemand buffer the map (and its fold) was written for: only the
+                                      texels the valid samples of THAT th_render_prepass (and the painted vertices) read exist */
 } th_map_source;
 
 /* Per-frame constants produced by th_paint_group / th_vit_forward / the
@@ -519,6 +535,14 @@ int th_render_pregather(th_ctx* ctx, const th_frame* f, const th_points* rays, v
  * the pre-gather stage (as for the prepass).  A no-op without a matching prepass; results are identical. */
 int th_render_pregrid(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace, size_t workspace_bytes,
                       th_stream stream);
+/* ABI 9.  Optional, behind a th_render_prepass of the same workspace / ray arrays: marks, on `stream` (which is first ordered
+ * behind the prepass), the map texels the prepass's valid samples read in the V views of f (f->cams, f->scale_xy, f->V, f->H,
+ * f->W; the other fields as for th_render_prepass) and those the n_paint vertices of verts_paint read (NULL / 0: none -- e.g. a
+ * rank that receives this frame's tokens) into `demand` (th_map_demand_bytes).  See th_upsample_concat_split_demand.  A frame
+ * whose th_map_source.demand is this buffer is complete for exactly this prepass; returns 1 (and leaves `demand` untouched) without
+ * a matching prepass. */
+int th_render_predemand(th_ctx* ctx, const th_frame* f, const th_points* rays, void* workspace, size_t workspace_bytes,
+                        const float* verts_paint, int n_paint, void* demand, size_t demand_bytes, th_stream stream);
 /* ABI 8.  th_render_pregather for a frame pipeline that queues frame i+1's pre-gather stage right behind frame i's
  * th_render_rays on the same stream and shading pool: the neighbour-record producer (on the context's second stream) is
  * ordered behind the PER-SAMPLE stage of that th_render_rays -- the last user of the pool regions it writes -- instead of

@@ -110,3 +110,56 @@ def test_config0_as_written(hip, gpu, focal, expect_unmasked):
     assert d < BAR and dd < 1e-3
     get_cfg().N_samples, get_cfg().num_class = 64, 500
     hip.drop_workspaces(gpu)
+
+
+def _img(o):
+    return torch.cat([o["rgb_map"][0], o["acc_map"][0][:, None], o["depth_map"][0][:, None]], dim=1)
+
+
+def test_demand_driven_map_equals_the_cropped_map(hip, gpu, monkeypatch):
+    """The map written only where the frame's valid samples / painted vertices read it (th_render_predemand, round 5) against the
+    map written over the row spans of the hull's box (round 3 / 4): same image bit for bit, through render_fast and through the
+    frame pipeline, for the whole frame and for a rank's shard (8 x 8 tiles, the demand of a rank of 8), both branches of the
+    R' <= 2400 rule; and a frame built for one sample list, then used with other rays, completes its map first."""
+    from transhuman_amd.dist import shard_ray_indices
+    net = make_net(12).to(gpu)
+    r = _renderer(net, 500, 64, synth_assign(500))
+    for (res, focal) in ((256, 300.0), (128, 40.0)):          # masked branch / un-masked branch (<= 2400 hit rays)
+        bc = synth.make_batch(res, res, 3, seed=0, all_rays=True, focal=focal)
+        b = synth.batch_to(bc, gpu)
+        my = shard_ray_indices(res, res, 8, 3, tile=8).to(gpu)
+        sh = dict(b)
+        for k in ("ray_o", "ray_d", "near", "far"):
+            sh[k] = b[k][:, my].contiguous()
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("TH_MAP_DEMAND", mode)
+            o_full = _img(r.render_fast(b, is_train=False))
+            st = dict(r.last_stats)
+            o_sh = _img(r.render_fast(sh, is_train=False, small_frame_rays=-1))
+            seq = [_img(o) for o in r.render_sequence([b, sh, b], small_frame_rays=2400)]
+            out[mode] = (o_full, o_sh, seq, st)
+        assert out["1"][3]["hit_rays"] > 100 and (out["1"][3]["unmasked"] == 1) == (focal == 40.0)
+        assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1])
+        for a, c in zip(out["0"][2], out["1"][2]):
+            assert torch.equal(a, c)
+        assert float(out["1"][0][:, 3].max()) > 0.05
+    # a demand-built frame handed to OTHER rays: the C side completes the map (th_map_source.demand) -- same pixels as a plain frame
+    monkeypatch.setenv("TH_MAP_DEMAND", "1")
+    bc = synth.make_batch(256, 256, 3, seed=0, all_rays=True, focal=300.0)
+    b = synth.batch_to(bc, gpu)
+    my = shard_ray_indices(256, 256, 8, 5, tile=8).to(gpu)
+    sh = dict(b)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        sh[k] = b[k][:, my].contiguous()
+    pts = hip.Points(sh["ray_o"][0], sh["ray_d"][0], sh["near"][0], sh["far"][0], n_samples=64)
+    hip.render_prepass(pts, b["tar_smpl_vertice"][0], 3, 0.1, -1, n_clusters=500)
+    dm = r.predemand(b, pts)
+    assert dm is not None
+    frame = r.prepare_frame(b, demand=dm)
+    assert frame.map.demand is not None
+    o_other = _img(r.render_fast(b, is_train=False, frame=frame))            # all rays, not the shard the demand was made for
+    monkeypatch.setenv("TH_MAP_DEMAND", "0")
+    o_ref = _img(r.render_fast(b, is_train=False))
+    assert torch.equal(o_other, o_ref)
+    hip.drop_workspaces(gpu)

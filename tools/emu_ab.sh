@@ -1,8 +1,8 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/h12
-for rep in 1 2; do
-for case in "head|TH_X=0" "nopregrid|TH_PREGRID=0" "la2|TH_LOOKAHEAD=2" "hullseq|TH_HULL_SEQ=1"; do
-  name=${case%%|*}; envs=${case#*|}
-  env $envs python bench.py --emulate-world 8 --emulate-rank 0 --no-cpu-baseline --no-extras > gpurun_out/h12/$name$rep.json 2> gpurun_out/h12/$name$rep.err
-  python -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().split(chr(10))[-1]); print(sys.argv[1], round(d['ms_per_step'],3), d.get('host_queue_ms_per_step'), d.get('host_wait_ms_per_step'))" gpurun_out/h12/$name$rep.json
-done; done
+#!/bin/bash
+# tools/emu_ab.sh "ENV=VAL ..." ["ENV=VAL ..." ...]: per environment the N = 1 frame and the emulated rank 3 of 8 (bench.py), one box
+one() { python bench.py "$@" --no-cpu-baseline --no-extras 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().split(chr(10))[-1]); s=d['stage_ms_per_step']; print(round(d['ms_per_step'],3), 'median', round(d['ms_per_step_median'],3), 'mlp', round(s['mlp'],3), 'fold', round(s.get('fold',0),3), 'host', round(d['host_pure_ms_per_step'],3), 'dropin', d.get('dropin_ms_per_step'))"; }
+for e in "$@"; do
+  echo "== $e"
+  echo -n "  n1    : "; env $e bash -c "$(declare -f one); one"
+  echo -n "  emu8r3: "; env $e bash -c "$(declare -f one); one --emulate-world 8 --emulate-rank 3"
+done

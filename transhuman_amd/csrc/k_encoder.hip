@@ -42,11 +42,19 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
                                                                    const float* __restrict__ bc, int H, int W,
                                                                    int NG, int CO, float* __restrict__ out,
                                                                    float* __restrict__ rgb4,
-                                                                   const int32_t* __restrict__ box) {
+                                                                   const int32_t* __restrict__ box,
+                                                                   const unsigned* __restrict__ need) {
     __shared__ float tile[64][65];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane, y = blockIdx.y;
     const int v = blockIdx.z / NG, grp = blockIdx.z % NG;
+    // demand-driven map (k_demand.hip; W % 64 == 0): one bit per texel -- this workgroup's 64 texels are two words
+    unsigned long long want = ~0ull;
+    if (need != nullptr) {
+        const unsigned* nw = need + ((((long long)v * H + y) * W + (long long)blockIdx.x * 64) >> 5);
+        want = (unsigned long long)nw[0] | ((unsigned long long)nw[1] << 32);
+        if (want == 0ull) return;
+    }
     if (box != nullptr) {               // cropped map (map_box_kernel): 64-pixel spans outside the view's box are not written
         const int by0 = box[4 * v + 1], by1 = box[4 * v + 3];
         if (y < by0 || y > by1) return;
@@ -56,7 +64,7 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
     }
     int cout0;
     if (grp == 4 && NG == 5) {          // compact map: channels 256..259 = r, g, b, 0 (one float4 per pixel)
-        if (wave == 0 && x < W) {
+        if (wave == 0 && x < W && ((want >> lane) & 1ull)) {
             long long hw = (long long)H * W;
             const float* ip = img + (long long)v * 3 * hw + (long long)y * W + x;
             // (split layout: the colour plane [V,H,W,4] behind the 256-channel latent plane)
@@ -94,19 +102,19 @@ __global__ __launch_bounds__(256) void upsample_concat_nhwc_kernel(UpsSrc s0, Up
     __syncthreads();
     float* orow = out + (((long long)v * H + y) * W + (long long)blockIdx.x * 64) * CO + cout0;
     for (int px = wave; px < 64; px += 4)
-        if (blockIdx.x * 64 + px < W) orow[(long long)px * CO + lane] = tile[px][lane];
+        if (blockIdx.x * 64 + px < W && ((want >> px) & 1ull)) orow[(long long)px * CO + lane] = tile[px][lane];
 }
 
 int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
                               const int* dims /* h0,w0,h1,w1,h2,w2 */, int V, int H, int W, const float* wc,
-                              const float* bc, float* out, hipStream_t s, int split, const int32_t* box) {
+                              const float* bc, float* out, hipStream_t s, int split, const int32_t* box, const unsigned* need) {
     UpsSrc s0{lat0, 64, dims[0], dims[1], 0};
     UpsSrc s1{lat1, 64, dims[2], dims[3], 64};
     UpsSrc s2{lat2, 128, dims[4], dims[5], 128};
     const int NG = wc ? 6 : 5, CO = wc ? 384 : (split ? 256 : 260);
     float* rgb4 = (!wc && split) ? out + (long long)V * H * W * 256 : nullptr;
     hipLaunchKernelGGL(upsample_concat_nhwc_kernel, dim3(th_cdiv(W, 64), H, V * NG), dim3(256), 0, s, s0, s1, s2, img, wc,
-                       bc, H, W, NG, CO, out, rgb4, box);
+                       bc, H, W, NG, CO, out, rgb4, box, need);
     TH_LAUNCH_CHECK();
     return 0;
 }

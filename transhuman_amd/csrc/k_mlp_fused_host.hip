@@ -344,7 +344,7 @@ int th_tok_split(float* tprime, int rows, float* sc, unsigned int* range, hipStr
 
 // map_split: TH_MAP_SPLIT ([V][H*W][256] latents, then [V][H*W][4] colours); fold: [2][V][H*W][256] (fold0, then fold12)
 int th_map_fold_launch(const FusedParams& base, const float* map_split, int V, int H, int W, const int32_t* box, float* fold,
-                       unsigned int* range, hipStream_t s) {
+                       unsigned int* range, hipStream_t s, const unsigned* demand) {
     TH_REQUIRE(base.compact_ready, "the map fold needs the colour-folded layers (th_mlp_weights.upsample_color)");
     TH_REQUIRE(V >= 1 && H >= 1 && W >= 1 && map_split && fold, "bad argument");
     MapFoldParams p;
@@ -353,11 +353,24 @@ int th_map_fold_launch(const FusedParams& base, const float* map_split, int V, i
     p.box = box; p.V = V; p.H = H; p.W = W;
     p.out0 = fold; p.out12 = fold + (size_t)V * H * W * 256;
     p.range = range;
+    p.list = nullptr; p.count = nullptr;
     static unsigned long long attr_done = 0ull;
-    if (th_lds_attr_needed(&attr_done))
-        TH_HIP(hipFuncSetAttribute((const void*)map_fold_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MF_TEX * STR272));
+    if (th_lds_attr_needed(&attr_done)) {
+        TH_HIP(hipFuncSetAttribute((const void*)map_fold_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MF_TEX * STR272));
+        TH_HIP(hipFuncSetAttribute((const void*)map_fold_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * MF_TEX * STR272));
+    }
+    if (demand != nullptr) {
+        // demand-driven map (k_demand.hip): the listed texels only.  The list's length lives on the device: two workgroups per CU
+        // walk it in strides of the grid.
+        const size_t NW = (size_t)V * H * W / 32;
+        p.count = demand + 2 * NW;
+        p.list = reinterpret_cast<const int32_t*>(demand + 2 * NW + 16);
+        hipLaunchKernelGGL(map_fold_kernel<true>, dim3(512), dim3(256), 2 * MF_TEX * STR272, s, p);
+        TH_LAUNCH_CHECK();
+        return 0;
+    }
     const int tpr = (W + MF_TEX - 1) / MF_TEX;
-    hipLaunchKernelGGL(map_fold_kernel, dim3((unsigned)(V * H * tpr)), dim3(256), 2 * MF_TEX * STR272, s, p);
+    hipLaunchKernelGGL(map_fold_kernel<false>, dim3((unsigned)(V * H * tpr)), dim3(256), 2 * MF_TEX * STR272, s, p);
     TH_LAUNCH_CHECK();
     return 0;
 }

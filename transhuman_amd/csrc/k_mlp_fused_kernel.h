@@ -1512,6 +1512,8 @@ struct MapFoldParams {
     float* out0;
     float* out12;
     unsigned int* range;           // TH_RANGE_F takes max |hi half| of the texels that are split
+    const int32_t* list;           // LIST form (demand-driven map, k_demand.hip): texel indices, any order ...
+    const unsigned* count;         // ... and their number (device)
 };
 
 // MF_RT row tiles of 32 texels per workgroup.  Measured on the headline frame's boxes (342 k texels, tools/fold_time.py): 3 (96
@@ -1522,24 +1524,44 @@ struct MapFoldParams {
 #define MF_KB 17
 #define MF_RT 3
 #define MF_TEX (32 * MF_RT)
+// LIST: the workgroup's 96 texels are entries blockIdx.x * 96 ... of a list of texel indices (the texels this frame's samples
+// read, k_demand.hip) instead of a run of an image row: every tile but the last is full, wherever the texels lie.
+template <bool LIST>
 __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* hi_pl = lds;
     char* lo_pl = lds + MF_TEX * STR272;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int xs = 0, x1 = 0;
+    long long trow = 0;
+    if constexpr (LIST) {
+        const int n = (int)*P.count;
+        xs = (int)blockIdx.x * MF_TEX;           // (position in the list; "x" below is a list position)
+        x1 = n - 1;
+        if (xs > x1) return;
+    } else {
     const int tpr = (P.W + MF_TEX - 1) / MF_TEX;
     const int v = blockIdx.x / (P.H * tpr), rem = blockIdx.x - v * (P.H * tpr);
     const int y = rem / tpr, xt = rem - y * tpr;
-    int x0 = 0, x1 = P.W - 1;
+    int x0 = 0;
+    x1 = P.W - 1;
     if (P.box != nullptr) {             // th_map_box: [V][4] boxes, then [V][H][2] row spans (empty rows: x1 < x0)
         if (y < P.box[4 * v + 1] || y > P.box[4 * v + 3]) return;
         const int32_t* sp = P.box + 4 * P.V + ((long long)v * P.H + y) * 2;
         x0 = sp[0];
         x1 = sp[1];
     }
-    const int xs = x0 + xt * MF_TEX;
+    xs = x0 + xt * MF_TEX;
     if (xs > x1) return;
-    const long long trow = ((long long)v * P.H + y) * P.W;      // texel index of (v, y, 0)
+    trow = ((long long)v * P.H + y) * P.W;      // texel index of (v, y, 0)
+    }
+    // texel index of position x of this tile's run
+    auto texel = [&](int x) __attribute__((always_inline)) -> long long {
+        if constexpr (LIST) return (long long)P.list[x];
+        else return trow + x;
+    };
+    // (LIST: a workgroup walks the list in strides of the grid -- the list's length is only known on the device)
+    for (;;) {
     unsigned rmax = 0u;
     const unsigned seen_f = P.range ? P.range[TH_RANGE_F] : 0u;
     // ---- the MF_TEX texels as fp16 hi / lo planes [texel][272] (texels past the box's edge: the edge texel again, never stored)
@@ -1548,7 +1570,7 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
 #pragma unroll 4
         for (int k = 0; k < MF_TEX / 4; ++k) {
             const int r = wv + 4 * k;
-            const long long t = trow + min(xs + r, x1);
+            const long long t = texel(min(xs + r, x1));
             const float4 q = *reinterpret_cast<const float4*>(P.lat + t * 256 + 4 * lane);
             uint2 h, l;
             split_pair(q.x, q.y, h.x, l.x);
@@ -1559,7 +1581,7 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
             *reinterpret_cast<uint2*>(lo_pl + r * STR272 + lane * 8) = l;
         }
         if (tid < MF_TEX) {             // channels 256..258 = r g b, 259..271 = 0
-            const long long t = trow + min(xs + tid, x1);
+            const long long t = texel(min(xs + tid, x1));
             const float4 c = *reinterpret_cast<const float4*>(P.rgb + t * 4);
             uint4 th = make_uint4(0u, 0u, 0u, 0u), tl = make_uint4(0u, 0u, 0u, 0u);
             split_pair(c.x, c.y, th.x, tl.x);
@@ -1586,7 +1608,7 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
         for (int r = 0; r < MF_RT; ++r) {
             const int x = xs + r * 32 + myrow;
             if (MF_STORE(x <= x1)) {
-                float* o = P.out0 + (trow + x) * 256 + wave * 64 + 4 * (lane >> 5);
+                float* o = P.out0 + texel(x) * 256 + wave * 64 + 4 * (lane >> 5);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
@@ -1604,7 +1626,7 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
         for (int r = 0; r < MF_RT; ++r) {
             const int x = xs + r * 32 + myrow;
             if (MF_STORE(x <= x1)) {
-                float* o = P.out12 + (trow + x) * 256 + wave * 32 + 4 * (lane >> 5);
+                float* o = P.out12 + texel(x) * 256 + wave * 32 + 4 * (lane >> 5);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     *reinterpret_cast<float4*>(o + 8 * g) =
@@ -1614,5 +1636,10 @@ __global__ __launch_bounds__(256, 1) void map_fold_kernel(MapFoldParams P) {
                 }
             }
         }
+    }
+    if (!LIST) break;
+    xs += (int)gridDim.x * MF_TEX;
+    if (xs > x1) break;
+    __syncthreads();            // (the operand planes are read by every wave until its last MFMA)
     }
 }

@@ -94,6 +94,8 @@ void th_ctx_destroy(th_ctx* c) {
     if (c->range_dev) (void)hipFree(c->range_dev);
     if (c->range_host) (void)hipHostFree(c->range_host);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->aux2) (void)hipStreamDestroy(c->aux2);
+    if (c->aux2_join) (void)hipEventDestroy(c->aux2_join);
     if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
     if (c->aux_join) (void)hipEventDestroy(c->aux_join);
     if (c->after_shade) (void)hipEventDestroy(c->after_shade);
@@ -441,6 +443,18 @@ int th_upsample_concat_split_box(th_ctx* c, const float* img, const float* lat0,
                                      box);
 }
 
+size_t th_map_demand_bytes(int V, int H, int W) { return th_demand_bytes(V, H, W); }
+
+int th_upsample_concat_split_demand(th_ctx* c, const float* img, const float* lat0, const float* lat1, const float* lat2,
+                                    const int32_t* dims_host, int V, int H, int W, float* out, const int32_t* box,
+                                    const void* demand, th_stream stream) {
+    TH_REQUIRE(c && img && lat0 && lat1 && lat2 && dims_host && out && demand, "null argument");
+    TH_REQUIRE((W % 64) == 0, "demand-driven map: image width must be a multiple of 64");
+    const unsigned* need_map = reinterpret_cast<const unsigned*>(demand) + (size_t)V * H * W / 32;
+    return th_upsample_concat_launch(img, lat0, lat1, lat2, dims_host, V, H, W, nullptr, nullptr, out, (hipStream_t)stream, 1,
+                                     box, need_map);
+}
+
 int th_map_box(th_ctx* c, const float* verts_a, int na, const float* verts_b, int nb, const float* cams, int V,
                const float* scale_xy, int H, int W, float reach, int32_t* box_out, th_stream stream) {
     TH_REQUIRE(c && cams && scale_xy && box_out && (verts_a || na == 0) && (verts_b || nb == 0), "null argument");
@@ -580,6 +594,14 @@ int th_map_fold(th_ctx* c, const float* map_split, int V, int H, int W, const in
     TH_REQUIRE(c->fused_ready && c->fused.compact_ready, "th_map_fold needs the MLP weights incl. upsample_color (th_set_mlp_weights)");
     ProfScope sc(prof_of(c), TH_PROF_FOLD, (hipStream_t)stream);
     return th_map_fold_launch(c->fused, map_split, V, H, W, box, fold, c->range_dev, (hipStream_t)stream);
+}
+
+int th_map_fold_demand(th_ctx* c, const float* map_split, int V, int H, int W, const void* demand, float* fold, th_stream stream) {
+    TH_REQUIRE(c && map_split && fold && demand, "null argument");
+    TH_REQUIRE(c->fused_ready && c->fused.compact_ready, "th_map_fold needs the MLP weights incl. upsample_color (th_set_mlp_weights)");
+    ProfScope sc(prof_of(c), TH_PROF_FOLD, (hipStream_t)stream);
+    return th_map_fold_launch(c->fused, map_split, V, H, W, nullptr, fold, c->range_dev, (hipStream_t)stream,
+                              reinterpret_cast<const unsigned*>(demand));
 }
 
 size_t th_pixel_texlist_bytes(int V, int P) { return th_pixtex_bytes(V, P); }
@@ -1003,8 +1025,14 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     // R' <= small_frame_rays: every sample of the hit rays is shaded), a frame without a hull test and a hull test wider
     // than the crop's reach gather outside it: the rest of the map is written first (same values inside the box) -- once
     // per frame (the pre-gather stage and the shading of one prepass share the completed map).
+    // A demand-driven map (th_map_source.demand, th_render_predemand) additionally holds only the texels of ONE prepass's sample
+    // list: any other caller of the frame (other rays, a sigma grid, a render without the prepass) gets the rest first too.
+    const bool demand_miss = f->map_source != nullptr && f->map_source->demand != nullptr &&
+                             !(tk && tk->demand == f->map_source->demand);
     if (f->map_source != nullptr && n > 0 && !(tk && tk->map_done == f->pixel_map_nhwc) &&
-        (unmasked || f->hull_thresh < 0.f || f->hull_thresh > f->map_source->reach)) {
+        !(c->map_completed != nullptr && c->map_completed == f->pixel_map_nhwc) &&
+        (f->map_source->demand != nullptr ? demand_miss      // (a demand made from THIS sample list covers every branch)
+                                          : (unmasked || f->hull_thresh < 0.f || f->hull_thresh > f->map_source->reach))) {
         const th_map_source* ms = f->map_source;
         TH_REQUIRE(f->map_channels == TH_MAP_SPLIT && ms->img && ms->lat0 && ms->lat1 && ms->lat2, "map_source: split map only");
         TH_TRY(th_upsample_concat_launch(ms->img, ms->lat0, ms->lat1, ms->lat2, ms->dims, V, f->H, f->W, nullptr, nullptr,
@@ -1013,6 +1041,7 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         if (tex) TH_TRY(th_map_fold_launch(c->fused, f->pixel_map_nhwc, V, f->H, f->W, nullptr, const_cast<float*>(f->map_fold),
                                            c->range_dev, s));
         if (tk) tk->map_done = f->pixel_map_nhwc;
+        if (f->map_source->demand != nullptr) c->map_completed = f->pixel_map_nhwc;      // (until the next th_render_predemand)
     }
     const bool can_pre = ray_mode && tok_gather(c, V) && fmt == TH_ROWS_SPLIT;
     char* pb = (char*)pool;
@@ -1033,12 +1062,14 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         // the texture path (TA busy 80-90 %, VALU 43 %), K4 since TH_ROWS_NBR is a 7-NN scan out of LDS (no row gather) --
         // so their waves co-reside on the CUs instead of running back to back (TH_K4_SIDE=0: one stream, K4 then K5).
         static const bool k4_side = !(getenv("TH_K4_SIDE") && getenv("TH_K4_SIDE")[0] == '0');
-        hipStream_t s4 = s;
+        hipStream_t s4 = s, s5 = s;
         if (k4_side) {
             if (!c->aux) {
                 TH_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
                 TH_HIP(hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming));
                 TH_HIP(hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming));
+                TH_HIP(hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking));
+                TH_HIP(hipEventCreateWithFlags(&c->aux2_join, hipEventDisableTiming));
             }
             // th_render_pregather_early: K4 is ordered behind the per-sample stage of the previous th_render_rays on this
             // stream and pool (the last user of the pool's record regions) instead of behind everything queued on `s` since
@@ -1046,13 +1077,20 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
             const bool early = c->pregather_early && c->after_shade_valid && c->after_shade_stream == s &&
                                c->after_shade_pool == pool;
             c->after_shade_valid = false;
+            // K5t (the texel hand-over's producer: rays, cameras, sample list -- no map) gets a stream of its own under the same
+            // rule: in the early form it starts with K4 behind the previous frame's per-sample stage, beside that frame's
+            // compositing and the consumer's image assembly, instead of behind them on `s` (the window between two launches of
+            // the fused kernel of a rank of 8: 360 -> 240 us)
             if (early) {
                 TH_HIP(hipStreamWaitEvent(c->aux, c->after_shade, 0));
+                if (tex) TH_HIP(hipStreamWaitEvent(c->aux2, c->after_shade, 0));
             } else {
                 TH_HIP(hipEventRecord(c->aux_fork, s));      // sample list, candidate grid and every earlier user of the pool
                 TH_HIP(hipStreamWaitEvent(c->aux, c->aux_fork, 0));
+                if (tex) TH_HIP(hipStreamWaitEvent(c->aux2, c->aux_fork, 0));
             }
             s4 = c->aux;
+            if (tex) s5 = c->aux2;
         }
         // From here on work may be in flight on the second stream: whatever happens, `s` waits for it before this call
         // returns (a caller that frees or reuses the pool after an error must not race with K4).
@@ -1067,8 +1105,8 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
                                      a_pe, TH_ROWS_NBR, grid ? gws : nullptr, s4);
             }
             if (rc == 0) {
-                ProfScope ps2(pf, TH_PROF_GATHER, s);
-                rc = tex ? th_pixtex_launch(V, f->H, f->W, &ps, idx, m, f->cams, f->scale_xy, a_f, s)
+                ProfScope ps2(pf, TH_PROF_GATHER, s5);
+                rc = tex ? th_pixtex_launch(V, f->H, f->W, &ps, idx, m, f->cams, f->scale_xy, a_f, s5)
                          : th_pixgather_launch(f->pixel_map_nhwc, V, f->map_channels, f->H, f->W, nullptr, &ps, idx, m, f->cams,
                                                f->scale_xy, a_f, f_ld, fmt, s, c->range_dev);
             }
@@ -1085,6 +1123,11 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
             const hipError_t e1 = hipEventRecord(c->aux_join, c->aux);
             const hipError_t e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, c->aux_join, 0) : e1;
             if (e2 != hipSuccess) (void)hipStreamSynchronize(c->aux);      // last resort: nothing left in flight
+            if (s5 != s) {
+                const hipError_t e3 = hipEventRecord(c->aux2_join, c->aux2);
+                const hipError_t e4 = e3 == hipSuccess ? hipStreamWaitEvent(s, c->aux2_join, 0) : e3;
+                if (e4 != hipSuccess) (void)hipStreamSynchronize(c->aux2);
+            }
         }
         if (rc != 0) return rc;
         if (!t.ev2) TH_HIP(hipEventCreateWithFlags(&t.ev2, hipEventDisableTiming));
@@ -1265,6 +1308,7 @@ int th_render_prepass(th_ctx* c, const th_frame* f, const th_points* rays, void*
     t.map_done = nullptr;
     t.pre_tokens = nullptr;
     t.grid_centres = nullptr;
+    t.demand = nullptr;
     if (R <= 0) return 0;
     long long P = (long long)R * S;
     TH_REQUIRE(P < (1LL << 31), "R*S must fit in int32");
@@ -1320,6 +1364,32 @@ int th_render_pregrid(th_ctx* c, const th_frame* f, const th_points* rays, void*
     c->prepass[slot].grid_centres = nullptr;
     TH_TRY(th_dparf_grid_build(f->centres, f->n_clusters, w.gws, w.gws_b, (hipStream_t)stream));
     c->prepass[slot].grid_centres = f->centres;
+    return 0;
+}
+
+int th_render_predemand(th_ctx* c, const th_frame* f, const th_points* rays, void* ws, size_t ws_bytes, const float* verts_paint,
+                        int n_paint, void* demand, size_t demand_bytes, th_stream stream) {
+    TH_REQUIRE(c && f && rays && ws && demand && f->cams && f->scale_xy, "null argument");
+    TH_REQUIRE(f->V >= 1 && f->V <= 3 && f->H >= 1 && f->W >= 64, "th_render_predemand: 1..3 views and their map size");
+    TH_REQUIRE(demand_bytes >= th_demand_bytes(f->V, f->H, f->W), "demand buffer too small (th_map_demand_bytes)");
+    int slot = -1;
+    for (int k = 0; k < th_ctx::kPrepassSlots; ++k) {
+        th_ctx::Prepass& t = c->prepass[k];
+        if (t.valid && t.ws == ws && t.rays == (const void*)rays->ray_o && t.R == rays->R && t.S == rays->S) slot = k;
+    }
+    if (slot < 0) return 1;
+    const long long P = (long long)rays->R * rays->S;
+    TH_REQUIRE(ws_bytes >= shade_ws_bytes(f, P, rays->R), "workspace too small");
+    ThArena ar(ws, ws_bytes);
+    const ShadeWs w = carve_shade_ws(f, P, rays->R, ar);
+    TH_REQUIRE(w.gws != nullptr, "workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    th_ctx::Prepass& t = c->prepass[slot];
+    t.demand = nullptr;
+    c->map_completed = nullptr;
+    TH_HIP(hipStreamWaitEvent(s, t.ev, 0));                      // the prepass may have run on another stream
+    TH_TRY(th_demand_launch(th_src(rays), w.idx, w.info, f->cams, f->scale_xy, f->V, f->H, f->W, verts_paint, n_paint, demand, s));
+    t.demand = demand;
     return 0;
 }
 

@@ -302,7 +302,7 @@ static inline bool th_lds_attr_needed(unsigned long long* done) {
 }
 // alpha_res_0 / rgb_res_0 / rgb_res_1 applied to the texels of the (cropped) split map: fold [2][V][H*W][256] (k_mlp_fused_kernel.h)
 int th_map_fold_launch(const FusedParams& base, const float* map_split, int V, int H, int W, const int32_t* box, float* fold,
-                       unsigned int* range, hipStream_t s);
+                       unsigned int* range, hipStream_t s, const unsigned* demand = nullptr /* k_demand.hip buffer: listed texels only */);
 // K5t (k_pixtex.hip): texel lists + records for P samples into `out` (th_pixtex_bytes); with tex_map != nullptr
 // th_mlp_fused_forward reads `f` as that block instead of rows
 size_t th_pixtex_bytes(int V, long long P);
@@ -345,6 +345,7 @@ struct th_ctx {
         const void* pre_pool = nullptr;
         const void* grid_centres = nullptr;         // th_render_pregrid: K4's candidate grid of these centres is in the workspace
         const void* pre_tokens = nullptr;           // th_render_pregather_early: T' of these tokens already sits in the workspace
+        const void* demand = nullptr;               // th_render_predemand: this demand buffer describes the prepass's sample list
         const void* map_done = nullptr;      // the cropped map this prepass's frame has already completed (written once)
     };
     static constexpr int kPrepassSlots = 4;
@@ -353,8 +354,9 @@ struct th_ctx {
     int n_cu = 256;
     // second stream of the pre-gather stage: K4 (neighbour records: VALU / LDS work, no row gather since TH_ROWS_NBR)
     // runs beside K5 (pixel-feature gather: texture-path bound) instead of behind it
-    hipStream_t aux = nullptr;
-    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
+    const void* map_completed = nullptr;    // a demand-driven map that a later call had to write in full (shade_points)
+    hipStream_t aux = nullptr, aux2 = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr, aux2_join = nullptr;
     // th_render_pregather_early: the point of the last th_render_rays' stream where its per-sample stage (fused MLP +
     // scatter) was complete -- recorded before the compositing -- and the stream / shading pool it belongs to
     hipEvent_t after_shade = nullptr;
@@ -480,7 +482,12 @@ int th_bound_mask_launch(const int32_t* corners_xy /* host [8][2] */, int H, int
 // k_encoder.hip
 int th_upsample_concat_launch(const float* img, const float* lat0, const float* lat1, const float* lat2,
                               const int* dims, int V, int H, int W, const float* wc, const float* bc, float* out,
-                              hipStream_t s, int split, const int32_t* box /* device [V][4] or null: th_map_box_launch */);
+                              hipStream_t s, int split, const int32_t* box /* device [V][4] or null: th_map_box_launch */,
+                              const unsigned* need = nullptr /* demand-driven map: one bit per texel (k_demand.hip), W % 64 == 0 */);
+// k_demand.hip: the texels the valid samples `sel[0 .. info[2])` (+ the painted vertices) read -> demand buffer
+size_t th_demand_bytes(int V, int H, int W);
+int th_demand_launch(const ThPointSrc& ps, const int32_t* sel, const int32_t* info, const float* cams, const float* scale, int V,
+                     int H, int W, const float* verts_paint, int n_paint, void* demand, hipStream_t s);
 int th_map_box_launch(const float* va, int na, const float* vb, int nb, const float* cams, int V, const float* scale, int H,
                       int W, float reach, int32_t* box, hipStream_t s);
 // W' [N,260] = [W[:, :256] | W[:, 256:384] Wc | 0], b' = b + W[:, 256:384] bc  (fp64 accumulation)

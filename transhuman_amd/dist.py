@@ -160,6 +160,10 @@ class TokenExchange:
     def owner(self, j):
         return (j + self.shift) % self.world
 
+    def will_compute(self):
+        """whether the NEXT call runs ``compute`` on this rank (its frame is this rank's, or the emulation has nothing to re-use)"""
+        return self.owner(self.frame) == self.rank or (self.emulate is not None and self._last is None)
+
     def __call__(self, compute, shape, device, dtype=torch.float32):
         """tokens of the next frame: ``compute()`` on the owner, a receive buffer elsewhere, then the broadcast"""
         j = self.frame

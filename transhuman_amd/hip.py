@@ -53,7 +53,7 @@ class ThFrame(C.Structure):
 
 class ThMapSource(C.Structure):
     _fields_ = [("box", C.c_void_p), ("reach", C.c_float), ("img", C.c_void_p), ("lat0", C.c_void_p),
-                ("lat1", C.c_void_p), ("lat2", C.c_void_p), ("dims", C.c_int32 * 6)]
+                ("lat1", C.c_void_p), ("lat2", C.c_void_p), ("dims", C.c_int32 * 6), ("demand", C.c_void_p)]
 
 
 # every symbol include/transhuman_hip.h declares (tests/test_cabi.py checks the export table)
@@ -102,6 +102,13 @@ SYMBOLS = {
     "th_upsample_concat_split_box": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                C.c_void_p]),
+    "th_map_demand_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "th_upsample_concat_split_demand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p]),
+    "th_map_fold_demand": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "th_render_predemand": (C.c_int, [C.c_void_p, C.POINTER(ThFrame), C.POINTER(ThPoints), C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     "th_map_box": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                              C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "th_paint_group_nhwc_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -195,7 +202,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 8:
+    if lib.th_abi_version() != 9:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -604,6 +611,11 @@ class SplitMap:
         """device int32 [V,4] (x0, y0, x1, y1 inclusive) of a cropped map, else None"""
         return self.source[1][0] if self.source is not None else None
 
+    @property
+    def demand(self):
+        """the render_predemand buffer a demand-driven map was written for, else None"""
+        return self.source[1][5] if self.source is not None and len(self.source[1]) > 5 else None
+
     def data_ptr(self):
         return self.buf.data_ptr()
 
@@ -626,9 +638,13 @@ def map_fold(net, split_map):
     assert isinstance(split_map, SplitMap)
     _sync_weights(net, "mlp")
     V, H, W = split_map.V, split_map.H, split_map.W
+    fold = torch.empty((2, V, H, W, 256), dtype=torch.float32, device=split_map.device)
+    if split_map.demand is not None:          # demand-driven map: the texels the frame's samples read, as a compacted list
+        _check(load_library().th_map_fold_demand(ctx(split_map.device), _p(split_map), V, H, W, _p(split_map.demand), _p(fold), _stream()))
+        split_map.fold = fold
+        return fold
     if split_map.box is not None:
         _box_checked(split_map.box, H)
-    fold = torch.empty((2, V, H, W, 256), dtype=torch.float32, device=split_map.device)
     _check(load_library().th_map_fold(ctx(split_map.device), _p(split_map), V, H, W, _p(split_map.box), _p(fold), _stream()))
     split_map.fold = fold
     return fold
@@ -667,7 +683,7 @@ def map_spans(box, H):
     return torch.as_strided(box, (V, int(H), 2), (int(H) * 2, 2, 1), storage_offset=box.storage_offset() + V * 4)
 
 
-def upsample_concat_split(images, lat0, lat1, lat2, box=None, reach=0.0):
+def upsample_concat_split(images, lat0, lat1, lat2, box=None, reach=0.0, demand=None):
     """th_upsample_concat_split(_box): the compact map (colour lift folded into the consumers) in the split layout.
     ``box`` (map_box, computed with ``reach``): only the texels of each view's box are written -- the returned SplitMap
     carries what it was made from (``source``) and hip.Frame hands that to the C side, which completes the map on its
@@ -678,6 +694,12 @@ def upsample_concat_split(images, lat0, lat1, lat2, box=None, reach=0.0):
     assert l0.shape[1] == 64 and l1.shape[1] == 64 and l2.shape[1] == 128
     dims = (C.c_int32 * 6)(l0.shape[2], l0.shape[3], l1.shape[2], l1.shape[3], l2.shape[2], l2.shape[3])
     buf = torch.empty(V * H * W * 260, dtype=torch.float32, device=img.device)
+    if demand is not None:
+        # demand-driven map (render_predemand): only the texels the frame's valid samples / painted vertices read are written
+        _check(lib.th_upsample_concat_split_demand(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf), None,
+                                                   _p(demand), _stream()))
+        src = ThMapSource(None, float(reach), _p(img), _p(l0), _p(l1), _p(l2), dims, _p(demand))
+        return SplitMap(buf, V, H, W, source=(src, (None, img, l0, l1, l2, demand)))
     if box is None:
         _check(lib.th_upsample_concat_split(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf), _stream()))
         return SplitMap(buf, V, H, W)
@@ -686,7 +708,7 @@ def upsample_concat_split(images, lat0, lat1, lat2, box=None, reach=0.0):
     _box_checked(box, H)
     _check(lib.th_upsample_concat_split_box(ctx(img.device), _p(img), _p(l0), _p(l1), _p(l2), dims, V, H, W, _p(buf),
                                             _p(box), _stream()))
-    src = ThMapSource(_p(box), float(reach), _p(img), _p(l0), _p(l1), _p(l2), dims)
+    src = ThMapSource(_p(box), float(reach), _p(img), _p(l0), _p(l1), _p(l2), dims, None)
     return SplitMap(buf, V, H, W, source=(src, (box, img, l0, l1, l2)))
 
 
@@ -1158,8 +1180,35 @@ def render_prepass(points, verts_world, V, hull_thresh=0.1, small_frame_rays=240
     f.n_clusters = n_clusters                  # (sizes the workspace exactly like the frame that follows)
     ws = _cached_ws(lib.th_render_workspace_bytes(C.byref(f), points.R, points.S), dev, slot)
     points._prepass_keep = (v, ws)
+    points._prepass_nc = int(n_clusters)
     _check(lib.th_render_prepass(ctx(dev), C.byref(f), C.byref(points.c), _p(ws), ws.numel(), _stream()))
     points._prepass_pending = True          # only THIS Points object (it keeps the ray tensors alive) may consume it
+
+
+def render_predemand(points, cams, scale_xy, V, H, W, verts_paint=None):
+    """th_render_predemand: behind the pending render_prepass of ``points`` (on the current stream, which is ordered behind it),
+    mark the map texels its valid samples -- and the ``verts_paint`` [n,3] vertices, if given -- read in the V views.  -> the demand
+    buffer (device uint8 tensor) for upsample_concat_split(demand=...) / map_fold, or None (no pending prepass, or a map
+    width that is not a multiple of 64)."""
+    if not getattr(points, "_prepass_pending", False) or int(W) % 64 != 0 or V > 3:
+        return None
+    lib = load_library()
+    v, ws = points._prepass_keep
+    dev = v.device
+    f = ThFrame()
+    f.verts_world, f.n_verts, f.V, f.H, f.W = v.data_ptr(), v.shape[0], int(V), int(H), int(W)
+    f.cams, f.scale_xy = cams.data_ptr(), scale_xy.data_ptr()
+    f.n_clusters, f.map_channels = points._prepass_nc, 384
+    vp = _f32(verts_paint).reshape(-1, 3) if verts_paint is not None else None
+    nb = int(lib.th_map_demand_bytes(int(V), int(H), int(W)))
+    demand = torch.empty(nb, dtype=torch.uint8, device=dev)
+    rc = lib.th_render_predemand(ctx(dev), C.byref(f), C.byref(points.c), _p(ws), ws.numel(), _p(vp), vp.shape[0] if vp is not None else 0,
+                                 _p(demand), nb, _stream())
+    if rc == 1:
+        return None
+    _check(rc)
+    demand._keep = (vp, cams, scale_xy)
+    return demand
 
 
 def render_pregrid(frame, points):

@@ -102,7 +102,7 @@ class Renderer:
 
     # ---- per-frame constants ---------------------------------------------------------
     def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True, token_exchange=None,
-                      pregather=None, defer_tokens=False, stem_exchange=None, crop_map=None):
+                      pregather=None, defer_tokens=False, stem_exchange=None, crop_map=None, demand=None):
         """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
 
         fused_encoder_tail=True (default): the ResNet stem runs through SpatialEncoder.trunk (K12 / K11), its tail
@@ -131,7 +131,10 @@ class Renderer:
         records of the frame's first chunks (hip.render_pregather: they need the map and the token centres, not the
         tokens) are queued on the current stream and TransHE runs BESIDE them on a second stream instead of in front.
         defer_tokens=True (render_sequence): everything up to the grouped vertex features; ``frame.finish_tokens()`` runs
-        TransHE later (the frame pipeline issues it at the start of the next shading window, see render_sequence)."""
+        TransHE later (the frame pipeline issues it at the start of the next shading window, see render_sequence).
+        demand=(buffer, event) (``self.predemand``, behind the frame's hull prepass): the map and its fold are written only at
+        the texels the prepass's valid samples (and, where this rank paints, the input vertices) read -- the frame is then
+        complete for exactly that prepass; any other use of it writes the rest first (th_map_source.demand)."""
         cfg = get_cfg()
         assert cfg.time_steps == 1                                                  # :412
         t = 0
@@ -166,6 +169,9 @@ class Renderer:
                 crop_map = os.environ.get("TH_MAP_CROP") != "0"
             if compact_map == "interleaved":            # A/B: one [V,H,W,260] tensor (1040-byte texel rows)
                 map_nhwc = hip.upsample_concat_nhwc(images, lat[0], lat[1], lat[2])
+            elif compact_map and demand is not None:
+                torch.cuda.current_stream(dev).wait_event(demand[1])       # (the marks were made on the hull stage's stream)
+                map_nhwc = hip.upsample_concat_split(images, lat[0], lat[1], lat[2], demand=demand[0])
             elif compact_map and crop_map and thr >= 0:
                 reach = float(thr) * 1.001 + 1e-6
                 box = hip.map_box(batch["tar_smpl_vertice"][0], batch["input_smpl_vertice"][t][0], cams, scale, H, W, reach)
@@ -242,6 +248,35 @@ class Renderer:
         frame.stem_flag = stem_flag if (fused_encoder_tail and hasattr(enc, "trunk")) else None
         return frame
 
+    def predemand(self, batch, pts, token_exchange=None, sharded=False):
+        """Behind ``hip.render_prepass(pts, ...)``, on the current stream (the prepass's): the demand buffer of the frame's map
+        (hip.render_predemand) + the event prepare_frame(demand=...) waits for, or None where the demand-driven map does not apply
+        (TH_MAP_DEMAND=0, no fused encoder tail, an image width that is not a multiple of 64, more than three views)."""
+        # Default: for the shards of a multi-rank job only.  On one GPU the frame reads ~70 % of the box's row spans: marking 2 M
+        # samples costs more side-stream time (0.6 ms) than the smaller map and fold give back, and the side stream is not what
+        # bounds that frame; a rank of 8 reads a sixth of the spans and IS bound by its per-frame front (DESIGN.md 7).
+        # TH_MAP_DEMAND=1 / 0 forces it on / off.
+        mode = os.environ.get("TH_MAP_DEMAND", "auto")
+        if mode == "0" or (mode != "1" and not sharded) or not hasattr(self.net.encoder, "trunk"):
+            return None
+        t = 0
+        imgs = batch["input_imgs"][t]
+        V, H, W = int(np.prod(imgs.shape[:-3])), int(imgs.shape[-2]), int(imgs.shape[-1])
+        dev = imgs.device
+        if not (hip.tex_rows_enabled(dev) and hip.mlp_is_fused(dev)) or V > 3 or V * H * W >= (1 << 22):
+            return None                     # (frames that take K5's rows read the latents of every corner: keep the box)
+        cams = hip.pack_cams(batch["input_R"][t].reshape(-1, 3, 3), batch["input_T"][t].reshape(-1, 3, 1),
+                             batch["input_K"][t].reshape(-1, 3, 3))
+        scale = hip.feat_scale(self.net.encoder.feat_scale(H, W), imgs.shape[-2:], dev)
+        paints = token_exchange is None or token_exchange.will_compute()
+        buf = hip.render_predemand(pts, cams, scale, V, H, W,
+                                   verts_paint=batch["input_smpl_vertice"][t][0] if paints else None)
+        if buf is None:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        return buf, ev
+
     # ---- reference API -------------------------------------------------------------------
     def render_fast(self, batch, is_train=True, frame=None, ray_slice=None, small_frame_rays=2400):
         """:429-484.  ``frame`` lets callers reuse per-frame constants; ``ray_slice`` renders a sub-range of
@@ -270,9 +305,10 @@ class Renderer:
                 with torch.cuda.stream(side):
                     hip.render_prepass(pts, batch["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
                                        n_clusters=len(self.csr_offsets) - 1)
+                    dm = self.predemand(batch, pts)
                 for t in (pts.ray_o, pts.ray_d, pts.near, pts.far):
                     t.record_stream(side)
-                frame = self.prepare_frame(batch, pregather=(pts, 0))
+                frame = self.prepare_frame(batch, pregather=(pts, 0), demand=dm)
             else:
                 frame = self.prepare_frame(batch)
         # (the threshold applies to THIS call whether or not the frame constants were handed in)
@@ -367,9 +403,23 @@ class Renderer:
                                  n_samples=cfg.N_samples)
                 V = b["input_imgs"][0].reshape(-1, *b["input_imgs"][0].shape[2:]).shape[0]
                 if V <= 4 and pts.R > 0:
-                    hip.render_prepass(pts, b["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
-                                       n_clusters=len(self.csr_offsets) - 1, slot=1 + j % nslots)
-                frame = self.prepare_frame(b, token_exchange=token_exchange, defer_tokens=split, stem_exchange=stem_exchange)
+                    # the ray-only hull stage (grid, hull test, compaction: ~10 dependent launches, 0.3 ms) shares nothing with
+                    # the frame constants: on a stream of its own beside them, not in front of them -- the side stream's chain of
+                    # ~55 dependent launches is what bounds a rank of 8 (2.7 ms against a 2.3 ms shard of the fused MLP)
+                    hs = hull_side if hull_side is not None else side
+                    hs.wait_stream(side)
+                    with torch.cuda.stream(hs):
+                        hip.render_prepass(pts, b["tar_smpl_vertice"][0], V, cfg_hull(), small_frame_rays,
+                                           n_clusters=len(self.csr_offsets) - 1, slot=1 + j % nslots)
+                        dm = self.predemand(b, pts, token_exchange, sharded=token_exchange is not None or ray_slice is not None)
+                    for t in (pts.ray_o, pts.ray_d, pts.near, pts.far):
+                        t.record_stream(hs)
+                else:
+                    dm = None
+                frame = self.prepare_frame(b, token_exchange=token_exchange, defer_tokens=split, stem_exchange=stem_exchange,
+                                           demand=dm)
+                if V <= 4 and pts.R > 0:
+                    side.wait_stream(hs)
                 if V <= 4 and pts.R > 0 and os.environ.get("TH_PREGRID", "1") != "0":
                     hip.render_pregrid(frame, pts)         # K4's candidate grid: here, not in front of K4
                 ready = torch.cuda.Event()
@@ -396,6 +446,11 @@ class Renderer:
             # TH_SIDE_PRIORITY=-1: high-priority side stream (A/B switch; measured: see DESIGN.md 6)
             side = self._dev[("side_stream", str(dev))] = torch.cuda.Stream(dev, priority=int(os.environ.get("TH_SIDE_PRIORITY", "0")))
         side.wait_stream(torch.cuda.current_stream(dev))
+        hull_side = None
+        if os.environ.get("TH_HULL_STREAM", "1") != "0":
+            hull_side = self._dev.get(("hull_side_stream", str(dev)))
+            if hull_side is None:
+                hull_side = self._dev[("hull_side_stream", str(dev))] = torch.cuda.Stream(dev)
         queue = collections.deque([front(first, 0, side)])
         tokens(queue[0], side)
         queued, more = 1, True
