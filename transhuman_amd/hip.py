@@ -244,7 +244,9 @@ def ctx(device=None):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (torch.cuda.current_stream() builds a Stream object through three Python layers: 4-8 us, ~40 times per frame; the raw
+    # handle of the current stream of the current device is one C call)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _p(t):
@@ -253,6 +255,8 @@ def _p(t):
 
 def _f32(t):
     assert t.is_cuda, "expected a device tensor"
+    if t.dtype is torch.float32 and t.is_contiguous():       # (the common case: no new tensor objects)
+        return t.detach() if t.requires_grad else t
     return t.detach().to(torch.float32).contiguous()
 
 
@@ -1125,12 +1129,14 @@ def _cached_ws(nbytes, device, slot=0):
 _pool_cache = {}
 
 
-def _shade_pool(frame_c, n_valid, with_pregather, device):
+def _shade_pool(frame_c, n_valid, with_pregather, device, slot=None):
     """The context's shading pool (include/transhuman_hip.h: th_shade_pool_bytes), ONE per device, grown on demand to what
     ``n_valid`` valid samples need in the context's current mode.  Growth allocates on the current stream; the old pool
     goes back to torch's allocator, which hands it out again only behind the work already queued on it."""
     need = int(load_library().th_shade_pool_bytes(ctx(device), C.byref(frame_c), int(n_valid), int(with_pregather)))
-    key = str(device)
+    # (slot: a frame pipeline that forms the NEXT frame's records while this frame shades gives every frame in flight a pool of
+    # its own -- Renderer.render_sequence; None: the context's one shared pool)
+    key = str(device) if slot is None else (str(device), int(slot))
     cur = _pool_cache.get(key)
     if cur is None or cur.numel() < need:
         _pool_cache[key] = None
@@ -1155,9 +1161,10 @@ def drop_workspaces(device=None):
     """Forget the cached render workspaces and the shading pool (GBs at full frame size) -- e.g. between unrelated
     workloads of one process; pending prepasses of those workspaces are cancelled."""
     lib = load_library()
-    for dev in list(_pool_cache.keys()):
+    for key in list(_pool_cache.keys()):
+        dev = key if isinstance(key, str) else key[0]
         if device is None or str(device) == dev:
-            _pool_cache.pop(dev, None)
+            _pool_cache.pop(key, None)
     for (dev, _slot) in list(_ws_cache.keys()):
         if device is None or str(device) == dev:
             _ws_cache.pop((dev, _slot), None)
@@ -1221,7 +1228,7 @@ def render_pregrid(frame, points):
                                             _stream()))
 
 
-def render_pregather(net, frame, points, slot=0, early=False):
+def render_pregather(net, frame, points, slot=0, early=False, pool_slot=None):
     """th_render_pregather: behind a render_prepass of the same ``points`` / workspace ``slot``, queue the pixel-feature
     gather and the neighbour records of the first chunks -- ``frame`` may still lack its tokens (Frame(tokens=None)),
     so TransHE can run on another stream meanwhile.  ``early=True`` (th_render_pregather_early): the caller has made the
@@ -1236,13 +1243,13 @@ def render_pregather(net, frame, points, slot=0, early=False):
     cnt = _prepass_counts(ws, dev)
     if cnt is None:
         return
-    pool = _shade_pool(frame.c, cnt[2], True, dev)
+    pool = _shade_pool(frame.c, cnt[2], True, dev, pool_slot)
     points._pregathered = True
     fn = lib.th_render_pregather_early if early else lib.th_render_pregather
     _check(fn(ctx(dev), C.byref(frame.c), C.byref(points.c), _p(ws), ws.numel(), _p(pool), pool.numel(), _stream()))
 
 
-def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_frame_rays=None):
+def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_frame_rays=None, pool_slot=None):
     """th_render_rays: rays -> (rgb [R,3], acc [R], depth [R], stats).
     Range guard: the frame's snapshot of the split-arithmetic maxima is read back after the call (a host wait for
     the frame) and, if a tensor left the resolvable range, the frame is rendered again on the fp32 path.
@@ -1278,7 +1285,7 @@ def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_f
     points._pregathered = False
     # the shading pool: sized from the valid-sample count when a prepass has put it on the host, else for the chunk
     # buffers only (the count bounds the chunk, not the pool)
-    pool = _shade_pool(fc, n_bound, pre, dev)
+    pool = _shade_pool(fc, n_bound, pre, dev, pool_slot)
     stats = (C.c_int64 * 4)()
     _check(lib.th_render_rays(ctx(dev), C.byref(fc), C.byref(points.c), _p(rgb), _p(acc), _p(dep), int(white_bkgd),
                               _p(ws), ws.numel(), _p(pool), pool.numel(), stats, _stream()))
@@ -1298,7 +1305,7 @@ def render_rays(net, frame, points, white_bkgd=False, defer_guard=False, small_f
             fc = ThFrame.from_buffer_copy(frame.c)
             fc.small_frame_rays = keep_sfr
         _check(lib.th_render_prepass_drop(ctx(dev), _p(ws)))
-        pool = _shade_pool(fc, st["valid_samples"], False, dev)   # (the guard may have changed the mode: other row formats)
+        pool = _shade_pool(fc, st["valid_samples"], False, dev, pool_slot)   # (the guard may have changed the mode: other row formats)
         _check(lib.th_render_rays(ctx(dev), C.byref(fc), C.byref(points.c), _p(rgb), _p(acc), _p(dep),
                                   int(white_bkgd), _p(ws), ws.numel(), _p(pool), pool.numel(), stats, _stream()))
         st = dict(hit_rays=stats[0], valid_samples=stats[1], unmasked=stats[3])

@@ -94,7 +94,7 @@ class SpatialEncoder(nn.Module):
         self.PE_color = _PEBuffers(10)                                                 # encoder.py:93 (unused)
         self.upsample_color = nn.Conv2d(3, 128, 1)                                     # encoder.py:95
 
-    def trunk(self, x, fused_bn=None):
+    def trunk(self, x, fused_bn=None, graph=False):
         """ResNet18 stem -> the three latents (64ch @H/2, 64ch @H/4, 128ch @H/8), encoder.py:114-126.
         On a GPU with the network in train() (run.py:29) the stem is hand-written HIP end to end: convolutions as K12
         (hip.conv2d: fp16-split MFMA implicit GEMMs; TH_STOCK_CONV=1 keeps torch/MIOpen), max pooling, and the
@@ -105,6 +105,10 @@ class SpatialEncoder(nn.Module):
         if fused_bn is None:
             fused_bn = x.is_cuda and os.environ.get("TH_STOCK_BN") != "1"
         if fused_bn and self._bn_sites_fusable():
+            if graph and os.environ.get("TH_STEM_GRAPH", "1") != "0" and not torch.is_grad_enabled():
+                lat = self._trunk_graphed(x)
+                if lat is not None:
+                    return lat
             return self._trunk_fused_bn(x)
         x = m.relu(m.bn1(m.conv1(x)))
         lat = [x]
@@ -151,6 +155,56 @@ class SpatialEncoder(nn.Module):
                     if b.training and b.track_running_stats and b.num_batches_tracked is not None]
         if counters:
             torch._foreach_add_(counters, 1)            # one launch for the ten counters
+        return lat
+
+    # ---- the stem as a hipGraph ------------------------------------------------------------------------------------------
+    # The HIP stem is 31 dependent launches (10 convolutions, 20 BatchNorm passes, the pooling) of 10 - 100 us each: for a frame
+    # pipeline that is 0.35 ms of host time per frame (a third of what a rank of an 8-rank job can spend) and 31 launch latencies
+    # on the side stream's dependent chain.  Frames of one shape run the same launches on the same parameter storage, so the
+    # chain is captured once per instance and replayed: one graph launch per frame.  GRAPH_RING instances rotate (static input
+    # copy + latents each): a frame's latents stay valid while the next GRAPH_RING - 1 frames' constants are built -- the frame
+    # pipeline holds at most three frames of constants, and a cropped map's completion (th_map_source) reads the latents at
+    # shading time.  Any change of the parameters' storage or version, of a BatchNorm's mode or of the range guard's
+    # convolution fallback drops the instances.  BatchNorm running statistics and num_batches_tracked advance once per frame
+    # exactly as in the eager form (they are written by the captured kernels).  TH_STEM_GRAPH=0 switches it off.
+    GRAPH_RING = 4
+
+    def _graph_version(self, x):
+        from .. import hip
+        m = self.model
+        convs = [m.conv1] + [c for layer in (m.layer1, m.layer2) for blk in layer
+                             for c in ([blk.downsample[0]] if blk.downsample is not None else []) + [blk.conv1, blk.conv2]]
+        if os.environ.get("TH_STOCK_CONV") == "1" or not all(hip.conv2d_supported(c) for c in convs):
+            return None
+        v = [(c.weight._version, c.weight.data_ptr()) for c in convs]
+        for b in self._bn_sites():
+            v.append((b.training, None if b.weight is None else (b.weight.data_ptr(), b.bias.data_ptr()),
+                      None if b.running_mean is None else b.running_mean.data_ptr()))
+        return (tuple(x.shape), str(x.device), tuple(v))
+
+    def _trunk_graphed(self, x):
+        ver = self._graph_version(x)
+        if ver is None or x.dtype != torch.float32:
+            return None
+        st = getattr(self, "_stem_graphs", None)
+        if st is None or st["ver"] != ver:
+            # first frame of a version: eagerly (it also packs the convolution weights, which must not happen under capture)
+            self._stem_graphs = {"ver": ver, "inst": [], "next": 0}
+            return None
+        inst, k = st["inst"], st["next"]
+        st["next"] = (k + 1) % self.GRAPH_RING
+        if k >= len(inst):
+            xs = torch.empty_like(x, memory_format=torch.contiguous_format)
+            xs.copy_(x)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                lat = self._trunk_fused_bn(xs)
+            inst.append((g, xs, lat))
+            g.replay()                       # (capture records, it does not run)
+            return lat
+        g, xs, lat = inst[k]
+        xs.copy_(x)
+        g.replay()
         return lat
 
     @staticmethod

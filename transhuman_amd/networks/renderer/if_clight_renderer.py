@@ -102,7 +102,7 @@ class Renderer:
 
     # ---- per-frame constants ---------------------------------------------------------
     def prepare_frame(self, batch, hull_thresh=None, fused_encoder_tail=True, compact_map=True, token_exchange=None,
-                      pregather=None, defer_tokens=False, stem_exchange=None, crop_map=None, demand=None):
+                      pregather=None, defer_tokens=False, stem_exchange=None, crop_map=None, demand=None, stem_graph=False):
         """paint -> group -> TransHE -> DPaRF tables (:531-547).  Returns hip.Frame.
 
         fused_encoder_tail=True (default): the ResNet stem runs through SpatialEncoder.trunk (K12 / K11), its tail
@@ -158,7 +158,9 @@ class Renderer:
             # from another rank -- computes its own latents from here on: the owner rank may not have switched yet)
             # -- it still takes part in the exchange (a collective: the other ranks wait for its turn as owner) but drops what
             # it receives
-            lat = enc.trunk(images) if stem_exchange is None else stem_exchange.latents(enc.trunk, images)
+            # (stem_graph: the stem's 31 launches replayed as one hipGraph -- the callers that render a stream of frames)
+            trunk = (lambda im: enc.trunk(im, graph=True)) if stem_graph else enc.trunk
+            lat = trunk(images) if stem_exchange is None else stem_exchange.latents(trunk, images)
             stem_flag = None if stem_exchange is None else stem_exchange.last_flag
             if stem_exchange is not None and hip.conv_fallback(dev) and not stem_exchange.last_mine:
                 lat, stem_flag = enc.trunk(images), None
@@ -308,7 +310,7 @@ class Renderer:
                     dm = self.predemand(batch, pts)
                 for t in (pts.ray_o, pts.ray_d, pts.near, pts.far):
                     t.record_stream(side)
-                frame = self.prepare_frame(batch, pregather=(pts, 0), demand=dm)
+                frame = self.prepare_frame(batch, pregather=(pts, 0), demand=dm, stem_graph=True)
             else:
                 frame = self.prepare_frame(batch)
         # (the threshold applies to THIS call whether or not the frame constants were handed in)
@@ -417,7 +419,7 @@ class Renderer:
                 else:
                     dm = None
                 frame = self.prepare_frame(b, token_exchange=token_exchange, defer_tokens=split, stem_exchange=stem_exchange,
-                                           demand=dm)
+                                           demand=dm, stem_graph=True)
                 if V <= 4 and pts.R > 0:
                     side.wait_stream(hs)
                 if V <= 4 and pts.R > 0 and os.environ.get("TH_PREGRID", "1") != "0":
@@ -506,6 +508,9 @@ class Renderer:
             # in 512 Ki-sample chunks as in render_fast).  The side stream's front of the next frame starts with this
             # frame's shading: its ~130 small launches share the chip with the producers (which leave LDS / registers /
             # the matrix pipe free) instead of time-slicing with MLP tiles that own whole CUs.
+            # (Built and removed in round 5: the NEXT frame's producers on a stream of their own BESIDE this frame's fused MLP,
+            # every frame in flight with its own pool -- the window between two MLP launches closes, and the MLP slows down by
+            # exactly what K4 / K5t take: they fill the chip, the window was never idle time.  profiles/r05_h.)
             if os.environ.get("TH_PREGATHER") != "0":
                 hip.render_pregather(self.net, frame, pts, early=early)
             # The NEXT frame's neighbour records (K4, the long pole of its producers) may start the moment this frame's
