@@ -33,7 +33,14 @@ struct ThProf {
 struct ProfScope {
     ThProf* p; int phase; hipStream_t s; hipEvent_t a = nullptr;
     ProfScope(ThProf* p_, int phase_, hipStream_t s_) : p(p_), phase(phase_), s(s_) {
-        if (p && p->on) { a = p->get(); if (a) (void)hipEventRecord(a, s); }
+        if (p && p->on) {
+            // (a stream under capture -- the callers that replay the stem / TransHE as hipGraphs -- is not timed: an event node
+            // recorded in a graph has no timestamp of its own)
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
+            a = p->get();
+            if (a) (void)hipEventRecord(a, s);
+        }
     }
     void close() {
         if (a) { hipEvent_t b = p->get(); if (b) { (void)hipEventRecord(b, s); p->spans.push_back({phase, a, b}); } }
