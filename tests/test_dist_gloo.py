@@ -157,8 +157,11 @@ def test_token_exchange_emulation_counts_the_owned_frames():
             def vit(fr=fr):
                 calls.append(fr)
                 return torch.full((1, 2, 192), float(fr))
+            before = len(calls)
+            predicted = tx.will_compute()            # (the renderer marks the painted vertices' texels only on such frames)
             tok = tx(vit, (1, 2, 192), torch.device("cpu"))
             assert tok.shape == (1, 2, 192)
+            assert predicted == (len(calls) > before), fr
         owned = [fr for fr in range(17) if fr % world == rank]
         assert calls == ([0] if rank != 0 else []) + owned
 
