@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import th_oracle as O                       # noqa: E402
 from transhuman_amd import synth, hip                   # noqa: E402
 from transhuman_amd.config import get_cfg               # noqa: E402
-from util import make_sd, make_net, synth_assign, csr, can_centres64, can64      # noqa: E402
+from util import make_sd, make_net, synth_assign, real_assign, csr, can_centres64, can64      # noqa: E402
 
 EDGES = [0.0, 1e-7, 3e-7, 1e-6, 3e-6, 1e-5, 2e-5, 3e-5, 5e-5, 7e-5, 1e-4, 1.5e-4, 2e-4, 3e-4, 1e-3, 1.0]
 
@@ -145,7 +145,8 @@ def main():
     cfg.N_samples, cfg.num_class = 64, args.nc
     from transhuman_amd.networks.renderer import if_clight_renderer
     net = make_net(12).to(dev)
-    assign = synth_assign(args.nc)
+    # (N_c = 1500: the reference's own ragged kmeans_dict_1500, tests/golden/kmeans_pc2voxel.npz)
+    assign = real_assign(args.nc) if args.nc == 1500 else synth_assign(args.nc)
     r = if_clight_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=assign)
     if args.frame == "dense":
         bc = synth.make_batch(512, 512, 3, seed=0, all_rays=True, dense=True, focal=6000.0, dilate=64)
