@@ -450,6 +450,15 @@ __global__ __launch_bounds__(64) void attn2_kernel(const float* __restrict__ qkv
 
 static int vit_npad(int N) { return (N + 63) / 64 * 64; }
 
+// zero fill of the K / V^T planes as a KERNEL, not hipMemsetAsync: this forward is also replayed as a hipGraph (hip.vit_forward(
+// graph=True)), and a graph holding a memset node in front of its kernel nodes produced non-finite tokens in a third of the runs
+// of tests/test_gpu_parity.py::test_render_sequence_equals_per_frame_render on ROCm 7.2 (0 of 15 with
+// DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; the stem's graph -- kernel nodes only -- never failed).  profiles/r05_l_vit_graph_memset_node.txt
+__global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, long long n16) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256)
+        p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 size_t th_vit_ws(int V, int N, int dim, int heads) {
     size_t T = (size_t)V * N;
     // X, Y, qkv / hidden, and the split K / V^T planes of one layer (2 x [V][heads][2][Npad][64] halves)
@@ -497,7 +506,11 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
     const bool fuse_split = h3 && !attn_lds && !no_fuse_split;
     const ThQkvSplit qs{Kp, Vp, N, Npad, heads, dim};
     if (fuse_split && Npad != N)
-        TH_HIP(hipMemsetAsync(Kp, 0, ((char*)Vp - (char*)Kp) + (size_t)V * heads * 2 * Npad * 64 * sizeof(_Float16), s));   // Kp .. end of Vp
+    {
+        const long long n16 = (long long)((((char*)Vp - (char*)Kp) + (size_t)V * heads * 2 * Npad * 64 * sizeof(_Float16)) / 16);   // Kp .. end of Vp
+        hipLaunchKernelGGL(zero16_kernel, dim3((unsigned)(th_cdiv(n16, 256) < 1024 ? th_cdiv(n16, 256) : 1024)), dim3(256), 0, s,
+                           reinterpret_cast<uint4*>(Kp), n16);
+    }
     for (int b = 0; b < W.depth; ++b) {
         const ThVitBlockPacked& B = W.blocks[b];
         if (h3) {

@@ -354,6 +354,8 @@ def _sync_weights(mod, kind):
             torch.cuda.synchronize(dev)
         (set_mlp_weights if kind == "mlp" else set_vit_weights)(mod)
         _ctx_owner[key] = (weakref.ref(mod), ver)
+        if kind == "vit":
+            _vit_graph_epoch[0] += 1
         # new weights: back to the modes the caller asked for (the guard re-checks them).  The Network's parameter set
         # includes the encoder, so the stem convolutions return to the HIP kernels with it (th_set_mlp_weights clears
         # their sticky range slot, th_set_vit_weights TransHE's).
@@ -362,6 +364,7 @@ def _sync_weights(mod, kind):
                 _check(load_library().th_set_mlp_mode(ctx(dev), _user_mode.get(key[0], 1)))
             _conv_fallback.pop(key[0], None)
         elif _vit_fallback.pop(key[0], None):
+            _vit_graph_epoch[0] += 1
             _check(load_library().th_set_vit_mode(ctx(dev), _user_vit_mode.get(key[0], 1)))
 
 
@@ -478,6 +481,7 @@ def _guard(device, slot):
         warnings.warn("transhuman_amd: an operand of TransHE's dense layers left the fp16 range; using the fp32 MFMA "
                       "GEMMs until new weights are uploaded", RuntimeWarning)
         _check(load_library().th_set_vit_mode(ctx(device), 0))
+        _vit_graph_epoch[0] += 1
         _vit_fallback[d] = True
         _range_epoch[d] = _range_epoch.get(d, 0) + 1
         ok = False
@@ -844,10 +848,75 @@ def segment_mean_rot(blend, off, mem):
     return out
 
 
-def vit_forward(vit, x, pe):
+def graph_capture(fn):
+    """Record the launches ``fn()`` queues on the current stream into a hipGraph (torch.cuda.CUDAGraph, private memory pool)
+    -> (graph, fn's result).  TH_GRAPH_CAPTURE=raw: capture_begin / capture_end on a stream of our own, without the
+    synchronize / gc / empty_cache torch.cuda.graph() performs."""
+    g = torch.cuda.CUDAGraph()
+    if os.environ.get("TH_GRAPH_CAPTURE") == "raw":
+        cur = torch.cuda.current_stream()
+        cs = torch.cuda.Stream()
+        cs.wait_stream(cur)
+        with torch.cuda.stream(cs):
+            g.capture_begin()
+            try:
+                out = fn()
+            finally:
+                g.capture_end()
+        cur.wait_stream(cs)
+        return g, out
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+
+_vit_graphs = {}
+_vit_graph_epoch = [0]      # bumped whenever the context's TransHE weights or arithmetic change: captured graphs are dropped
+VIT_GRAPH_RING = 4
+
+
+def _vit_forward_graphed(vit, x, pe):
+    """TransHE's 63 launches replayed as one hipGraph (the frame paths: Renderer.render_fast / render_sequence).  Per (module,
+    shape, device): the first call of a version runs eagerly and captures VIT_GRAPH_RING instances (static input copy + output
+    in the graph's private pool), later calls copy the input into the next instance and replay it.  The tokens returned stay valid
+    until VIT_GRAPH_RING - 1 further graphed calls of the shape have been made (the frame pipeline holds three frames).
+    The captured forward holds kernel nodes only (k_vit.hip: zero16_kernel, profiles/r05_l_vit_graph_memset_node.txt).
+    None = not applicable (TH_VIT_GRAPH=0, autograd input)."""
+    if os.environ.get("TH_VIT_GRAPH", "1") == "0" or (torch.is_grad_enabled() and x.requires_grad):
+        return None
+    key = (id(vit), tuple(x.shape), str(x.device))
+    ver = (_vit_graph_epoch[0], pe.data_ptr(), _ctx_owner.get((_dev_index(x.device), "vit"), (None, None))[1])
+    st = _vit_graphs.get(key)
+    if st is None or st["ver"] != ver:
+        # first call of a version: eagerly (the kernels' first launches must not happen under capture), then every instance of
+        # the ring is captured at once -- the cost of capturing (a device synchronisation each) lands in this one call, not in
+        # the next VIT_GRAPH_RING frames of a stream (a rank of N computes TransHE every N-th frame only)
+        if len(_vit_graphs) > 8:
+            _vit_graphs.clear()
+        st = _vit_graphs[key] = {"ver": ver, "inst": [], "next": 0, "mod": vit, "pe": pe}     # (the graphs hold pe's address)
+        out = vit_forward(vit, x, pe, graph=False, _checked=True)
+        for _ in range(VIT_GRAPH_RING):
+            xs = torch.empty_like(x)
+            g, o = graph_capture(lambda: vit_forward(vit, xs, pe, graph=False, _checked=True))
+            st["inst"].append((g, xs, o))
+        return out
+    k = st["next"]
+    st["next"] = (k + 1) % VIT_GRAPH_RING
+    g, xs, out = st["inst"][k]
+    xs.copy_(x)
+    g.replay()
+    return out
+
+
+def vit_forward(vit, x, pe, graph=False, _checked=False):
     lib = load_library()
-    _sync_weights(vit, "vit")
+    if not _checked:
+        _sync_weights(vit, "vit")
     x, pe = _f32(x), _f32(pe)
+    if graph:
+        out = _vit_forward_graphed(vit, x, pe)
+        if out is not None:
+            return out
     V, N, D = x.shape
     out = torch.empty_like(x)
     ws = _ws(lib.th_vit_workspace_bytes(V, N, D, vit.num_heads), x.device)
@@ -1414,6 +1483,7 @@ def set_vit_mode(mode, device=None):
     """th_set_vit_mode: 0 = TransHE's dense layers on the fp32 MFMA GEMMs, 1 (default) = fp16-split arithmetic."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     _check(load_library().th_set_vit_mode(ctx(dev), int(mode)))
+    _vit_graph_epoch[0] += 1
     _user_vit_mode[_dev_index(dev)] = int(mode)
     if int(mode) != 0:
         _vit_fallback.pop(_dev_index(dev), None)

@@ -188,21 +188,19 @@ class SpatialEncoder(nn.Module):
             return None
         st = getattr(self, "_stem_graphs", None)
         if st is None or st["ver"] != ver:
-            # first frame of a version: eagerly (it also packs the convolution weights, which must not happen under capture)
-            self._stem_graphs = {"ver": ver, "inst": [], "next": 0}
-            return None
-        inst, k = st["inst"], st["next"]
-        st["next"] = (k + 1) % self.GRAPH_RING
-        if k >= len(inst):
-            xs = torch.empty_like(x, memory_format=torch.contiguous_format)
-            xs.copy_(x)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                lat = self._trunk_fused_bn(xs)
-            inst.append((g, xs, lat))
-            g.replay()                       # (capture records, it does not run)
+            # first frame of a version: eagerly (it also packs the convolution weights, which must not happen under capture),
+            # then every instance of the ring is captured at once: the cost of capturing lands in this one frame
+            from .. import hip
+            st = self._stem_graphs = {"ver": ver, "inst": [], "next": 0}
+            lat = self._trunk_fused_bn(x)
+            for _ in range(self.GRAPH_RING):
+                xs = torch.empty_like(x, memory_format=torch.contiguous_format)
+                g, l = hip.graph_capture(lambda: self._trunk_fused_bn(xs))       # (capture records, it does not run)
+                st["inst"].append((g, xs, l))
             return lat
-        g, xs, lat = inst[k]
+        k = st["next"]
+        st["next"] = (k + 1) % self.GRAPH_RING
+        g, xs, lat = st["inst"][k]
         xs.copy_(x)
         g.replay()
         return lat

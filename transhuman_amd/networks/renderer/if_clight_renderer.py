@@ -205,7 +205,7 @@ class Renderer:
 
         def make_tokens():
             self.last_grouped = group()
-            return self.net.ViT(self.last_grouped, self._pe_norm(V, dev), mask=None)    # :538
+            return self.net.ViT(self.last_grouped, self._pe_norm(V, dev), mask=None, graph=stem_graph)    # :538
 
         centres = hip.segment_mean(batch["tar_smpl_vertice_smplcoord"][0], off, mem)   # :543
         rot = hip.segment_mean_rot(batch["blend_mtx"][0], off, mem)                 # :544 + cross_transformer.py:185
@@ -219,7 +219,7 @@ class Renderer:
             self.last_grouped = grouped = group()
             pe_norm = self._pe_norm(V, dev)
             frame = mk_frame(None)
-            frame.finish_tokens = lambda: frame.set_tokens(self.net.ViT(grouped, pe_norm, mask=None))   # :538
+            frame.finish_tokens = lambda: frame.set_tokens(self.net.ViT(grouped, pe_norm, mask=None, graph=stem_graph))   # :538
         elif pregather is None or os.environ.get("TH_PREGATHER") == "0":
             frame = mk_frame(make_tokens())
         else:
@@ -236,7 +236,7 @@ class Renderer:
             # launches must not queue behind that wait); on the device it runs beside K5 + K4 of the first chunks
             with torch.cuda.stream(vs):
                 vs.wait_event(grouped_ready)
-                tokens = self.net.ViT(grouped, self._pe_norm(V, dev), mask=None)    # :538
+                tokens = self.net.ViT(grouped, self._pe_norm(V, dev), mask=None, graph=stem_graph)    # :538
             hip.render_pregather(self.net, frame, pts_pg, slot_pg)
             grouped.record_stream(vs)
             tokens.record_stream(cur)
@@ -373,7 +373,10 @@ class Renderer:
         for a coming frame (ray generation, SMPL skinning, uploads) also runs under the shading of the current one.
         ``token_exchange`` (transhuman_amd.dist.TokenExchange, multi-GPU): TransHE of frame j runs on rank j % world
         only and its tokens are broadcast from the side stream; ``stem_exchange`` (dist.StemExchange): the same for the
-        encoder stem's latents."""
+        encoder stem's latents.
+        The stem and TransHE of these frames are replayed hipGraphs (encoder.trunk(graph=True), hip.vit_forward(graph=True)):
+        the latents and tokens of ``self.last_frame`` live in the graphs' rotating buffers and stay valid until three more
+        frames have been yielded -- ``self.last_frame.rebuild()`` returns a frame that owns its memory."""
         import collections
         cfg = get_cfg()
         self._check_sampling_options(cfg)

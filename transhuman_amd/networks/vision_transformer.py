@@ -80,13 +80,13 @@ class VisionTransformer(nn.Module):
         self._pe_cache = (key, tab)
         return tab
 
-    def forward(self, x, PE, mask=None):
+    def forward(self, x, PE, mask=None, graph=False):
         from .. import hip
         if mask is not None and bool(mask.sum() != 0):
             x = x.clone()
             x[mask] = self.mask_token.to(x.dtype)
         pe = self.get_PE(PE)
-        return hip.vit_forward(self, x, pe)
+        return hip.vit_forward(self, x, pe, graph=graph)
 
 
 def vit_tiny(depth, **kw):
