@@ -848,26 +848,33 @@ def segment_mean_rot(blend, off, mem):
     return out
 
 
+_graphs_off = [False]
+
+
 def graph_capture(fn):
     """Record the launches ``fn()`` queues on the current stream into a hipGraph (torch.cuda.CUDAGraph, private memory pool)
-    -> (graph, fn's result).  TH_GRAPH_CAPTURE=raw: capture_begin / capture_end on a stream of our own, without the
-    synchronize / gc / empty_cache torch.cuda.graph() performs."""
+    -> (graph, fn's result).  Capture mode "thread_local": API calls other threads make meanwhile (the process group's
+    watchdog polling its events in a multi-rank job) neither fail nor invalidate the capture.  A capture that fails raises
+    GraphCaptureFailed after switching the replayed-graph forms off for the process (callers run their eager form)."""
     g = torch.cuda.CUDAGraph()
-    if os.environ.get("TH_GRAPH_CAPTURE") == "raw":
-        cur = torch.cuda.current_stream()
-        cs = torch.cuda.Stream()
-        cs.wait_stream(cur)
-        with torch.cuda.stream(cs):
-            g.capture_begin()
-            try:
-                out = fn()
-            finally:
-                g.capture_end()
-        cur.wait_stream(cs)
-        return g, out
-    with torch.cuda.graph(g):
-        out = fn()
+    try:
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            out = fn()
+    except Exception as e:           # (nothing of fn ran; the capture is over either way)
+        _graphs_off[0] = True
+        import warnings
+        warnings.warn(f"transhuman_amd: hipGraph capture failed ({type(e).__name__}: {e}); the stem and TransHE run as "
+                      "separate launches from here on", RuntimeWarning)
+        raise GraphCaptureFailed(str(e)) from e
     return g, out
+
+
+class GraphCaptureFailed(RuntimeError):
+    pass
+
+
+def graphs_enabled():
+    return not _graphs_off[0]
 
 
 _vit_graphs = {}
@@ -882,7 +889,7 @@ def _vit_forward_graphed(vit, x, pe):
     until VIT_GRAPH_RING - 1 further graphed calls of the shape have been made (the frame pipeline holds three frames).
     The captured forward holds kernel nodes only (k_vit.hip: zero16_kernel, profiles/r05_l_vit_graph_memset_node.txt).
     None = not applicable (TH_VIT_GRAPH=0, autograd input)."""
-    if os.environ.get("TH_VIT_GRAPH", "1") == "0" or (torch.is_grad_enabled() and x.requires_grad):
+    if os.environ.get("TH_VIT_GRAPH", "1") == "0" or _graphs_off[0] or (torch.is_grad_enabled() and x.requires_grad):
         return None
     key = (id(vit), tuple(x.shape), str(x.device))
     ver = (_vit_graph_epoch[0], pe.data_ptr(), _ctx_owner.get((_dev_index(x.device), "vit"), (None, None))[1])
@@ -895,10 +902,13 @@ def _vit_forward_graphed(vit, x, pe):
             _vit_graphs.clear()
         st = _vit_graphs[key] = {"ver": ver, "inst": [], "next": 0, "mod": vit, "pe": pe}     # (the graphs hold pe's address)
         out = vit_forward(vit, x, pe, graph=False, _checked=True)
-        for _ in range(VIT_GRAPH_RING):
-            xs = torch.empty_like(x)
-            g, o = graph_capture(lambda: vit_forward(vit, xs, pe, graph=False, _checked=True))
-            st["inst"].append((g, xs, o))
+        try:
+            for _ in range(VIT_GRAPH_RING):
+                xs = torch.empty_like(x)
+                g, o = graph_capture(lambda: vit_forward(vit, xs, pe, graph=False, _checked=True))
+                st["inst"].append((g, xs, o))
+        except GraphCaptureFailed:
+            _vit_graphs.pop(key, None)
         return out
     k = st["next"]
     st["next"] = (k + 1) % VIT_GRAPH_RING

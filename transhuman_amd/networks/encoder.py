@@ -24,6 +24,11 @@ from torch import nn
 from ..config import get_cfg
 
 
+def _graphs_enabled():
+    from .. import hip
+    return hip.graphs_enabled()
+
+
 class _PEBuffers(nn.Module):
     """Buffer-only twin of the reference's PositionalEncoding
     (lib/networks/vision_transformer.py:100-122): keeps the `_freqs` /
@@ -105,7 +110,7 @@ class SpatialEncoder(nn.Module):
         if fused_bn is None:
             fused_bn = x.is_cuda and os.environ.get("TH_STOCK_BN") != "1"
         if fused_bn and self._bn_sites_fusable():
-            if graph and os.environ.get("TH_STEM_GRAPH", "1") != "0" and not torch.is_grad_enabled():
+            if graph and os.environ.get("TH_STEM_GRAPH", "1") != "0" and not torch.is_grad_enabled() and _graphs_enabled():
                 lat = self._trunk_graphed(x)
                 if lat is not None:
                     return lat
@@ -193,15 +198,20 @@ class SpatialEncoder(nn.Module):
             from .. import hip
             st = self._stem_graphs = {"ver": ver, "inst": [], "next": 0}
             lat = self._trunk_fused_bn(x)
-            for _ in range(self.GRAPH_RING):
-                xs = torch.empty_like(x, memory_format=torch.contiguous_format)
-                g, l = hip.graph_capture(lambda: self._trunk_fused_bn(xs))       # (capture records, it does not run)
-                st["inst"].append((g, xs, l))
+            try:
+                for _ in range(self.GRAPH_RING):
+                    xs = torch.empty_like(x, memory_format=torch.contiguous_format)
+                    g, l = hip.graph_capture(lambda: self._trunk_fused_bn(xs))       # (capture records, it does not run)
+                    st["inst"].append((g, xs, l))
+            except hip.GraphCaptureFailed:
+                self._stem_graphs = None
             return lat
         k = st["next"]
         st["next"] = (k + 1) % self.GRAPH_RING
         g, xs, lat = st["inst"][k]
-        xs.copy_(x)
+        # (an elementwise kernel, not xs.copy_(x): the runtime's device-to-device copy of the 9.4 MB of three 512 x 512 images took
+        # 180 - 240 us -- 45 GB/s -- in front of the first convolution, tools/dropin_trace.sh)
+        torch.mul(x, 1.0, out=xs)
         g.replay()
         return lat
 

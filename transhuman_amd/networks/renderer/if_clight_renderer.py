@@ -151,6 +151,7 @@ class Renderer:
         off, mem = self._csr(dev)
         viz = batch["input_vizmaps"][t][0] if cfg.rasterize else None               # :103-119
         enc = self.net.encoder
+        fold_done = None
         if fused_encoder_tail and hasattr(enc, "trunk"):
             H, W = images.shape[2:]
             V = images.shape[0]
@@ -186,7 +187,23 @@ class Renderer:
             # :316, :334, :346) are applied to the map's texels here, once per frame -- bilinear sampling commutes with them
             if (isinstance(map_nhwc, hip.SplitMap) and hip.tex_rows_enabled(dev) and V <= 3 and V * H * W < (1 << 22)
                     and hip.mlp_is_fused(dev)):
-                hip.map_fold(self.net, map_nhwc)
+                if pregather is not None and os.environ.get("TH_FOLD_STREAM", "1") != "0":
+                    # a single frame (render_fast) is bound by its chain of dependent stages: stem -> map -> paint / group ->
+                    # TransHE -> fused MLP.  The fold (0.35 ms) is needed by the fused MLP only: beside that chain on a stream
+                    # of its own, not inside it.  (A stream of frames is bound by the chip's total work: render_sequence keeps
+                    # the fold on the side stream, measured -- no gain there, LOG.md.)
+                    cur = torch.cuda.current_stream(dev)
+                    fs = self._dev.get(("fold_stream", str(dev)))
+                    if fs is None:
+                        fs = self._dev[("fold_stream", str(dev))] = torch.cuda.Stream(dev)
+                    fs.wait_stream(cur)
+                    with torch.cuda.stream(fs):
+                        fold = hip.map_fold(self.net, map_nhwc)
+                        fold_done = torch.cuda.Event()
+                        fold_done.record(fs)
+                    fold.record_stream(cur)
+                else:
+                    hip.map_fold(self.net, map_nhwc)
 
             def group():
                 return hip.paint_group_nhwc(map_nhwc, batch["input_smpl_vertice"][t][0], cams, scale, viz,
@@ -242,6 +259,8 @@ class Renderer:
             tokens.record_stream(cur)
             cur.wait_stream(vs)
             frame.set_tokens(tokens)
+        if fold_done is not None:
+            torch.cuda.current_stream(dev).wait_event(fold_done)
         # (range guard, hip.render_rays: the same constants again -- through the stock convolutions -- if the stem's
         # input left the fp16 range)
         # (a rebuilt frame computes its own tokens: the exchange's frame counter must not advance twice)
@@ -280,12 +299,46 @@ class Renderer:
         return buf, ev
 
     # ---- reference API -------------------------------------------------------------------
+    def _own_stream(self, dev):
+        """The stream a frame's shading chain is queued on when the caller sits on the device's DEFAULT stream (every
+        unchanged caller of the reference's loop does): the default (null) stream orders itself against work it has nothing to do
+        with -- measured on the single-frame chain: the neighbour records (K4, on the context's second stream behind an event of
+        the calling stream) started 0.6 ms late, with TransHE's last launches on a third stream, whenever the calling stream was
+        the null stream; on a stream of our own they start when their inputs are ready (render_fast 18.3 -> 17.6 ms on one box,
+        17.85 -> 17.65 on another, profiles/r05_m).  render_sequence stays on the caller's stream: its steady state was 0.17 ms per
+        frame SLOWER on a stream of its own (14.79 -> 14.96 ms, same profile).  None = stay on the caller's stream (it is not the
+        default stream, or TH_OWN_STREAM=0)."""
+        if not torch.cuda.is_available() or os.environ.get("TH_OWN_STREAM", "1") == "0":
+            return None
+        if torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev):
+            return None
+        m = self._dev.get(("main_stream", str(dev)))
+        if m is None:
+            m = self._dev[("main_stream", str(dev))] = torch.cuda.Stream(dev)
+        return m
+
     def render_fast(self, batch, is_train=True, frame=None, ray_slice=None, small_frame_rays=2400):
         """:429-484.  ``frame`` lets callers reuse per-frame constants; ``ray_slice`` renders a sub-range of
         rays (multi-GPU sharding); ``small_frame_rays`` is the R' threshold of :551 (-1 pins the masked
         branch, used when a frame is sharded).
         Without a ready ``frame`` the ray-only stage (hull mask, compaction) is queued first, then the
-        per-frame constants, then the shading: the sample count is on the host by the time it is needed."""
+        per-frame constants, then the shading: the sample count is on the host by the time it is needed.
+        Called on the device's default stream the frame is queued on a stream of the renderer's own (``_own_stream``), ordered
+        behind everything the caller has queued; the caller's stream waits for the frame before this returns."""
+        dev = batch["ray_o"].device
+        own = self._own_stream(dev) if dev.type == "cuda" else None
+        if own is None:
+            return self._render_fast(batch, frame, ray_slice, small_frame_rays)
+        caller = torch.cuda.current_stream(dev)
+        own.wait_stream(caller)
+        with torch.cuda.stream(own):
+            out = self._render_fast(batch, frame, ray_slice, small_frame_rays)
+        caller.wait_stream(own)
+        for v in out.values():
+            v.record_stream(caller)
+        return out
+
+    def _render_fast(self, batch, frame, ray_slice, small_frame_rays):
         cfg = get_cfg()
         self._check_sampling_options(cfg)
         sl = slice(None) if ray_slice is None else ray_slice
