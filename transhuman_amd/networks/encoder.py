@@ -110,7 +110,9 @@ class SpatialEncoder(nn.Module):
         if fused_bn is None:
             fused_bn = x.is_cuda and os.environ.get("TH_STOCK_BN") != "1"
         if fused_bn and self._bn_sites_fusable():
-            if graph and os.environ.get("TH_STEM_GRAPH", "1") != "0" and not torch.is_grad_enabled() and _graphs_enabled():
+            # (the HIP stem carries no autograd in either grad mode: the reference's inference loop runs under no_grad, a caller
+            # that forgot it gets the same replayed graph)
+            if graph and os.environ.get("TH_STEM_GRAPH", "1") != "0" and _graphs_enabled():
                 lat = self._trunk_graphed(x)
                 if lat is not None:
                     return lat
