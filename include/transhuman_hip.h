@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 9
+#define TH_ABI_VERSION 10
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -174,6 +174,12 @@ typedef struct {
     const float* t_vals;       /* [S] torch.linspace(0,1,S)                */
     const float* one_minus_t;  /* [S] 1 - t_vals                           */
     int R, S;                  /* rays, samples per ray (S=1 with pts)     */
+    /* ABI 10 -- the reference's two sampling randomisations (NULL = off, what run.py:22,68,123 renders with):          */
+    const float* z_vals;       /* [R,S] explicit sample depths: the stratified jitter of get_sampling_points            */
+                               /* (if_clight_renderer.py:276-283, cfg.perturb > 0 in train() mode) replaces            */
+                               /* near*(1-t)+far*t in every stage (hull test, neighbour records, texel lists, deltas)  */
+    const float* sigma_noise;  /* [R,S] added to sigma in front of the relu of raw2alpha (nerf_net_utils.py:39-44,      */
+                               /* cfg.raw_noise_std > 0: randn * std) on the rays that are composited (hit rays)       */
 } th_points;
 
 size_t th_hull_workspace_bytes(int n_verts);

@@ -42,10 +42,16 @@ def widen(obj, dtype=torch.float64):
 # ---------------------------------------------------------------------------
 # a-1  sample placement   lib/networks/renderer/if_clight_renderer.py:271-287
 # ---------------------------------------------------------------------------
-def sampling_points(ray_o, ray_d, near, far, n_samples):
-    """ray_o,ray_d [R,3]; near,far [R] -> pts [R,S,3], z [R,S] (no perturb)."""
+def sampling_points(ray_o, ray_d, near, far, n_samples, t_rand=None):
+    """ray_o,ray_d [R,3]; near,far [R] -> pts [R,S,3], z [R,S].
+    t_rand [R,S] (the draws of torch.rand, :282): the stratified jitter of cfg.perturb > 0 in train() mode, :276-283."""
     t = torch.linspace(0.0, 1.0, steps=n_samples).to(near)
     z = near[..., None] * (1.0 - t) + far[..., None] * t          # :274
+    if t_rand is not None:
+        mids = .5 * (z[..., 1:] + z[..., :-1])                    # :278
+        upper = torch.cat([mids, z[..., -1:]], -1)
+        lower = torch.cat([z[..., :1], mids], -1)
+        z = lower + (upper - lower) * t_rand.to(upper)            # :283
     pts = ray_o[:, None] + ray_d[:, None] * z[..., None]          # :285
     return pts, z
 
@@ -328,13 +334,15 @@ def network_forward(sd, pixel_feat, viewdir, pts_s, centres, blend, tokens, pts_
 # ---------------------------------------------------------------------------
 # a-10  compositing  lib/networks/renderer/nerf_net_utils.py:14-59
 # ---------------------------------------------------------------------------
-def raw2outputs(raw, z, ray_d, white_bkgd=False):
-    """raw [R,S,4]; z [R,S]; ray_d [R,3] -> rgb [R,3], acc [R], depth [R], weights [R,S]."""
+def raw2outputs(raw, z, ray_d, white_bkgd=False, noise=None):
+    """raw [R,S,4]; z [R,S]; ray_d [R,3] -> rgb [R,3], acc [R], depth [R], weights [R,S].
+    noise [R,S]: randn * raw_noise_std, :39-41 (added to sigma in front of the relu)."""
     d = z[..., 1:] - z[..., :-1]
     d = torch.cat([d, torch.full_like(d[..., :1], 1e10)], -1)      # :31-35
     d = d * torch.norm(ray_d[..., None, :], dim=-1)                # :37
     c = torch.sigmoid(raw[..., :3])
-    a = 1.0 - torch.exp(-F.relu(raw[..., 3]) * d)                  # :27-28,:44
+    sig = raw[..., 3] if noise is None else raw[..., 3] + noise.to(raw)     # :44
+    a = 1.0 - torch.exp(-F.relu(sig) * d)                          # :27-28,:44
     T = torch.cumprod(torch.cat([torch.ones((a.shape[0], 1), dtype=a.dtype, device=a.device), 1.0 - a + 1e-10], -1), -1)[:, :-1]
     w = a * T                                                      # :46-49
     rgb = torch.sum(w[..., None] * c, -2)
@@ -375,19 +383,23 @@ def pixel_aligned(pixel_feat_map, xyz_w, batch):
 
 
 def render_fast(sd, batch, holder_feat_map, pixel_feat_map, offsets, members, can_centres64,
-                n_samples=64, vit_depth=12, small_frame_rays=2400, hull=0.1, chunk=32768, white_bkgd=False):
+                n_samples=64, vit_depth=12, small_frame_rays=2400, hull=0.1, chunk=32768, white_bkgd=False,
+                t_rand=None, sigma_noise=None):
     """Renderer.render_fast, if_clight_renderer.py:429-484 (+ _render :500-605,
     batchify_rays :607-656).  Encoder outputs are inputs here.
+    t_rand [R,S]: the draws of the depth jitter (:276-283); sigma_noise [R,S]: randn * raw_noise_std of raw2outputs, indexed
+    by the frame's rays (the reference draws it for the hit rays only; the rows of the other rays are not used).
     Returns dict rgb_map [1,R,3], acc_map [1,R], depth_map [1,R]."""
     ray_o, ray_d = batch["ray_o"][0], batch["ray_d"][0]
     near, far = batch["near"][0], batch["far"][0]
     R = ray_o.shape[0]
     dt = ray_o.dtype
-    pts, z = sampling_points(ray_o, ray_d, near, far, n_samples)
+    pts, z = sampling_points(ray_o, ray_d, near, far, n_samples, t_rand)
     # float64 "truth" mode (every floating tensor of `batch` / `sd` / the feature maps handed in as float64: the exact
     # arithmetic of the same graph on the same fp32 inputs): discrete decisions -- this hull mask, the 7-NN sets of
     # dparf -- are taken from the fp32 pass, as the reference would take them
-    pts32 = pts if dt == torch.float32 else sampling_points(ray_o.float(), ray_d.float(), near.float(), far.float(), n_samples)[0]
+    pts32 = pts if dt == torch.float32 else sampling_points(ray_o.float(), ray_d.float(), near.float(), far.float(), n_samples,
+                                                            None if t_rand is None else t_rand.float())[0]
     vm = hull_mask(pts32.reshape(-1, 3), batch["tar_smpl_vertice"][0].float(), hull).view(R, n_samples)
     hit = vm.sum(-1) > 0                                           # :443
     dv = ray_o.device
@@ -412,7 +424,8 @@ def render_fast(sd, batch, holder_feat_map, pixel_feat_map, offsets, members, ca
             raws.append(network_forward(sd, pf, vd[s:s + chunk], ps[s:s + chunk], fc["centres"],
                                         fc["blend"], fc["tokens"], mm[s:s + chunk]))
         raw = torch.cat(raws, 0)
-    rgb, acc, depth, _ = raw2outputs(raw.view(Rp, n_samples, 4), zz, d, white_bkgd)       # :593 (hit rays only)
+    rgb, acc, depth, _ = raw2outputs(raw.view(Rp, n_samples, 4), zz, d, white_bkgd,       # :593 (hit rays only)
+                                     None if sigma_noise is None else sigma_noise[hit])
     fc = dict(fc, hit=hit, raw=raw.view(Rp, n_samples, 4), mask=m)      # (test diagnostics: per-sample outputs of the hit rays)
     out["rgb_map"][0, hit] = rgb
     out["acc_map"][0, hit] = acc

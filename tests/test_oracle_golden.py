@@ -187,6 +187,33 @@ def test_g11_render_fast_large_frame_branch():
     assert np.array_equal(np.packbits(vm[hit].numpy()), g["mask_bits"])
 
 
+@pytest.mark.parametrize("tag", ["small", "large"])
+def test_g19_render_fast_with_depth_jitter_and_density_noise(tag):
+    """cfg.perturb = 1 in train() mode (if_clight_renderer.py:276-283) and cfg.raw_noise_std = 0.4 (nerf_net_utils.py:39-44)
+    through the REAL reference's render_fast, on the draws it took from torch.rand / torch.randn (oracle/gen_golden_perturb.py):
+    the oracle on the same draws; 'small' = un-masked branch (R' <= 2400), 'large' = masked"""
+    g = gold(f"g19_perturb_{tag}")
+    H, S, focal = int(g["H"]), int(g["n_samples"]), float(g["focal"])
+    b = synth.make_batch(H, H, 3, seed=0, focal=None if focal < 0 else focal)
+    pts, z = O.sampling_points(b["ray_o"][0], b["ray_d"][0], b["near"][0], b["far"][0], S, g["t_rand"])
+    assert torch.equal(z, g["z_vals"])                                   # the jittered depths, bit for bit
+    assert float((z[:, 1:] - z[:, :-1]).min()) >= 0.0                    # stratified: still ordered along the ray
+    sd = make_sd()
+    hol, pix = O.encoder_forward(sd, b["input_imgs"][0][0])
+    off, mem = csr(synth_assign(300))
+    out, fc = O.render_fast(sd, b, hol, pix, off, mem, can_centres64(synth_assign(300)), n_samples=S, t_rand=g["t_rand"],
+                            sigma_noise=g["raw_noise"] * float(g["noise_std"]))
+    hit = torch.as_tensor(np.asarray(g["hit"])).bool()
+    assert torch.equal(fc["hit"], hit)
+    assert (int(hit.sum()) > 2400) == (tag == "large")
+    assert maxdiff(out["rgb_map"][0], g["rgb"]) < 2e-5
+    assert maxdiff(out["acc_map"][0], g["acc"]) < 2e-5
+    assert maxdiff(out["depth_map"][0], g["depth"]) < 1e-4
+    # the randomisations are live: the same frame without them differs
+    plain, _ = O.render_fast(sd, b, hol, pix, off, mem, can_centres64(synth_assign(300)), n_samples=S)
+    assert maxdiff(plain["rgb_map"][0], g["rgb"]) > 1e-3
+
+
 def test_g12_mesh_cube():
     g = gold("g12_mesh_cube")
     b = synth.make_batch(32, 32, 3, seed=0)

@@ -25,6 +25,8 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict
     nd = __fsqrt_rn(nd + dz * dz);                       // torch.norm(rays_d)
     float carryT = 1.0f;
     float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    // (render_fast composites the rays that hit the hull only, if_clight_renderer.py:467-476: a ray that misses stays zero)
+    const bool noisy = ps.noise != nullptr && (ray_hit == nullptr || ray_hit[ray] != 0);
     for (int base = 0; base < S; base += 64) {
         int s = base + lane;
         bool ok = s < S;
@@ -38,6 +40,8 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict
         // mask given: samples outside the hull carry raw = 0 (cross_transformer.py:231) without being stored or read
         const bool live = ok && (mask == nullptr || mask[(long long)ray * S + s] != 0);
         float4 r = live ? raw[(long long)ray * S + s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // density noise (nerf_net_utils.py:39-44): on every sample of a composited ray, the zeros outside the hull included
+        if (noisy && ok) r.w = r.w + ps.noise[(long long)ray * S + s];
         float alpha = ok ? 1.0f - expf(-fmaxf(r.w, 0.0f) * delta) : 0.0f;
         float t = (1.0f - alpha) + 1e-10f;                // factor contributed to later samples
         if (!ok) t = 1.0f;

@@ -113,11 +113,14 @@ struct ThPointSrc {
     const float* tv;
     const float* omt;
     int R, S;
+    const float* zv;           // th_points.z_vals (explicit depths [R,S]) or nullptr
+    const float* noise;        // th_points.sigma_noise [R,S] or nullptr
 };
 static inline ThPointSrc th_src(const th_points* p) {
     ThPointSrc s;
     s.pts = p->pts; s.ray_o = p->ray_o; s.ray_d = p->ray_d; s.near = p->near; s.far = p->far;
     s.tv = p->t_vals; s.omt = p->one_minus_t; s.R = p->R; s.S = p->S;
+    s.zv = p->z_vals; s.noise = p->sigma_noise;
     return s;
 }
 
@@ -149,6 +152,7 @@ __device__ __forceinline__ float th_row16_max(float m) {
 }
 
 __device__ __forceinline__ float th_sample_z(const ThPointSrc& ps, int ray, int s) {
+    if (ps.zv != nullptr) return ps.zv[(long long)ray * ps.S + s];      // (wave-uniform: one scalar test)
     return ps.near[ray] * ps.omt[s] + ps.far[ray] * ps.tv[s];
 }
 __device__ __forceinline__ void th_get_point(const ThPointSrc& ps, long long i, float& x, float& y, float& z) {

@@ -40,7 +40,7 @@ class ThVitBlock(C.Structure):
 class ThPoints(C.Structure):
     _fields_ = [("pts", C.c_void_p), ("ray_o", C.c_void_p), ("ray_d", C.c_void_p), ("near", C.c_void_p),
                 ("far", C.c_void_p), ("t_vals", C.c_void_p), ("one_minus_t", C.c_void_p), ("R", C.c_int),
-                ("S", C.c_int)]
+                ("S", C.c_int), ("z_vals", C.c_void_p), ("sigma_noise", C.c_void_p)]
 
 
 class ThFrame(C.Structure):
@@ -202,7 +202,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 9:
+    if lib.th_abi_version() != 10:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -520,7 +520,9 @@ def linear(x, weight, bias=None, act=0):
 class Points:
     """Host-side holder of a th_points (keeps the tensors alive)."""
 
-    def __init__(self, ray_o=None, ray_d=None, near=None, far=None, n_samples=1, pts=None):
+    def __init__(self, ray_o=None, ray_d=None, near=None, far=None, n_samples=1, pts=None, z_vals=None, sigma_noise=None):
+        """``z_vals`` [R,S]: explicit sample depths (the reference's stratified jitter, if_clight_renderer.py:276-283) instead of
+        near (1 - t) + far t; ``sigma_noise`` [R,S]: added to sigma in front of raw2alpha's relu (nerf_net_utils.py:39-44)."""
         if pts is not None:
             self.pts = _f32(pts).reshape(-1, 3)
             self.R, self.S = self.pts.shape[0], 1
@@ -533,8 +535,10 @@ class Points:
         # t_vals exactly as torch.linspace builds them (if_clight_renderer.py:273-274); cached per (S, device)
         self.t, self.omt = _t_vals(n_samples, dev)
         self.R, self.S = self.ray_o.shape[0], n_samples
+        self.z_vals = None if z_vals is None else _f32(z_vals).reshape(self.R, self.S)
+        self.sigma_noise = None if sigma_noise is None else _f32(sigma_noise).reshape(self.R, self.S)
         self.c = ThPoints(None, _p(self.ray_o), _p(self.ray_d), _p(self.near), _p(self.far), _p(self.t), _p(self.omt),
-                          self.R, self.S)
+                          self.R, self.S, _p(self.z_vals), _p(self.sigma_noise))
 
 
 _t_cache = {}

@@ -340,10 +340,9 @@ class Renderer:
 
     def _render_fast(self, batch, frame, ray_slice, small_frame_rays):
         cfg = get_cfg()
-        self._check_sampling_options(cfg)
         sl = slice(None) if ray_slice is None else ray_slice
         pts = hip.Points(batch["ray_o"][0][sl], batch["ray_d"][0][sl], batch["near"][0][sl], batch["far"][0][sl],
-                         n_samples=cfg.N_samples)
+                         n_samples=cfg.N_samples, **self._sampling_randoms(batch, sl, cfg))
         if frame is None:
             V = batch["input_imgs"][0].reshape(-1, *batch["input_imgs"][0].shape[2:]).shape[0]
             if V <= 4 and pts.R > 0:
@@ -372,19 +371,36 @@ class Renderer:
         self.last_stats = stats
         return {"depth_map": depth[None], "rgb_map": rgb[None], "acc_map": acc[None]}
 
-    def _check_sampling_options(self, cfg):
-        """The reference jitters the sample depths when cfg.perturb > 0 and the network is in train() mode
-        (:276-283) and adds noise to sigma when cfg.raw_noise_std > 0 (nerf_net_utils.py:39-46).  run.py sets
-        cfg.perturb = 0 for every inference entry point (run.py:22,68,123) although it keeps network.train(); the
-        YAML default is perturb: 1.  Neither randomisation exists in the HIP path: refuse instead of silently
-        rendering deterministic samples."""
+    def _sampling_randoms(self, batch, sl, cfg):
+        """The reference's two randomisations of the sampling, as keyword arguments of hip.Points (empty when both are off, which
+        is what run.py renders with: cfg.perturb = 0 at run.py:22,68,123 although it keeps network.train(); the YAML default is
+        perturb: 1):
+          * cfg.perturb > 0 with the network in train() mode: stratified jitter of the sample depths, get_sampling_points :276-283
+            -- the same torch expressions on the device, the kernels read the depths from ``z_vals`` instead of computing
+            near (1 - t) + far t;
+          * cfg.raw_noise_std > 0: randn * std added to sigma in front of raw2alpha's relu (nerf_net_utils.py:39-44), on every
+            sample of the composited rays.
+        The draws come from torch's generator of the batch's device (the reference draws from its default device's: streams of
+        different devices are not reproducible against each other either).  A caller that wants given draws puts them into the
+        batch: ``batch["t_rand"]`` ([1,R,S] uniform draws) / ``batch["raw_noise"]`` ([1,R,S] standard-normal draws) -- the
+        parity tests do."""
+        kw = {}
+        S = int(cfg.N_samples)
+        near, far = batch["near"][0][sl], batch["far"][0][sl]
         if float(getattr(cfg, "perturb", 0.0)) > 0.0 and self.net.training:
-            raise NotImplementedError("cfg.perturb > 0 with the network in train() mode asks for stratified depth jitter "
-                                      "(if_clight_renderer.py:276-283): training-time sampling is outside this inference "
-                                      "path (Renderer.render serves it through its autograd form) -- set cfg.perturb = 0 "
-                                      "like run.py:22,68,123 do")
-        if float(getattr(cfg, "raw_noise_std", 0.0)) > 0.0:
-            raise NotImplementedError("cfg.raw_noise_std > 0 (density noise, nerf_net_utils.py:39-46) is a training option")
+            t_vals = torch.linspace(0., 1., steps=S).to(near)                                      # :273
+            z_vals = near[..., None] * (1. - t_vals) + far[..., None] * t_vals                     # :274
+            mids = .5 * (z_vals[..., 1:] + z_vals[..., :-1])                                       # :278
+            upper = torch.cat([mids, z_vals[..., -1:]], -1)
+            lower = torch.cat([z_vals[..., :1], mids], -1)
+            t_rand = batch["t_rand"][0][sl].to(upper) if "t_rand" in batch else torch.rand(z_vals.shape, device=near.device).to(upper)
+            kw["z_vals"] = lower + (upper - lower) * t_rand                                        # :283
+        std = float(getattr(cfg, "raw_noise_std", 0.0))
+        if std > 0.0:
+            shape = (near.shape[0], S)
+            draw = batch["raw_noise"][0][sl].to(near) if "raw_noise" in batch else torch.randn(shape, device=near.device, dtype=near.dtype)
+            kw["sigma_noise"] = draw * std                                                         # nerf_net_utils.py:41
+        return kw
 
     def render_fast_sharded(self, batch, my_idx, gatherer, hit_sum, frame=None):
         """One rank's part of a ray-sharded frame with the reference's WHOLE-FRAME R' <= 2400 rule (:551): the shard
@@ -432,7 +448,6 @@ class Renderer:
         frames have been yielded -- ``self.last_frame.rebuild()`` returns a frame that owns its memory."""
         import collections
         cfg = get_cfg()
-        self._check_sampling_options(cfg)
         sl = slice(None) if ray_slice is None else ray_slice
         it = iter(batches)
         lookahead = max(1, min(int(os.environ.get("TH_LOOKAHEAD", lookahead)), 3))    # (th_render_prepass keeps at most 4 tokens)
@@ -458,7 +473,7 @@ class Renderer:
             ep = hip.range_epoch(b["ray_o"].device)
             with torch.cuda.stream(side):
                 pts = hip.Points(b["ray_o"][0][sl], b["ray_d"][0][sl], b["near"][0][sl], b["far"][0][sl],
-                                 n_samples=cfg.N_samples)
+                                 n_samples=cfg.N_samples, **self._sampling_randoms(b, sl, cfg))
                 V = b["input_imgs"][0].reshape(-1, *b["input_imgs"][0].shape[2:]).shape[0]
                 if V <= 4 and pts.R > 0:
                     # the ray-only hull stage (grid, hull test, compaction: ~10 dependent launches, 0.3 ms) shares nothing with
