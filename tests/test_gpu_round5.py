@@ -211,3 +211,40 @@ def test_render_fast_with_depth_jitter_and_density_noise(hip, gpu, tag):
     finally:
         cfg.perturb, cfg.raw_noise_std, cfg.N_samples = 0.0, 0.0, 64
         net.train()
+
+
+def test_graph_capture_failure_falls_back_to_separate_launches(hip, gpu, monkeypatch):
+    """The frame paths replay the stem and TransHE as hipGraphs; a capture that fails (another thread's API call under a global
+    capture mode, a runtime that refuses) must leave a renderer that works: the forms are switched off for the process and the
+    frame is rendered through the separate launches -- same image, bit for bit."""
+    import warnings
+    from transhuman_amd.config import get_cfg
+    net = make_net(12).to(gpu)
+    r = _renderer(net, 300, 32, synth_assign(300))
+    b = synth.batch_to(synth.make_batch(64, 64, 3, seed=1, focal=200.0), gpu)
+    try:
+        with torch.no_grad():
+            ref = {k: v.clone() for k, v in r.render_fast(b).items()}
+            ref2 = {k: v.clone() for k, v in r.render_fast(b).items()}          # (second call: replayed graphs)
+            for k in ref:
+                assert torch.equal(ref[k], ref2[k]), k
+            # a fresh network: new parameter storage, so both forms capture again -- and this time the capture fails
+            net2 = make_net(12).to(gpu)
+            r2 = _renderer(net2, 300, 32, synth_assign(300))
+            real = torch.cuda.CUDAGraph.capture_begin
+
+            def refuse(self, *a, **k):
+                raise RuntimeError("capture refused (test)")
+            monkeypatch.setattr(torch.cuda.CUDAGraph, "capture_begin", refuse)
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                o1 = {k: v.clone() for k, v in r2.render_fast(b).items()}
+            assert any("hipGraph capture failed" in str(x.message) for x in w)
+            assert not hip.graphs_enabled()
+            monkeypatch.setattr(torch.cuda.CUDAGraph, "capture_begin", real)
+            o2 = r2.render_fast(b)
+            for k in ref:
+                assert torch.equal(o1[k], ref[k]) and torch.equal(o2[k], ref[k]), k
+    finally:
+        hip._graphs_off[0] = False
+        get_cfg().N_samples = 64
