@@ -714,8 +714,9 @@ def main():
             "host_wait_ms_per_step": host_wait_ms / max(args.steps, 1),
             "shader_clock_GHz": shader_clock(clk, n_probe),
             "stage_ms_per_step": {k: v[0] / max(args.steps, 1) for k, v in prof.items()},
-            "stage_note": "HIP-event spans per stage; with the frame pipeline hull / vit run on the side stream under the "
-                          "other stages (their spans are stretched by the overlap and do not add to the frame time)",
+            "stage_note": "HIP-event spans per stage; with the frame pipeline hull / fold run on the side stream under the "
+                          "other stages (their spans are stretched by the overlap and do not add to the frame time); vit = 0: "
+                          "TransHE is a replayed hipGraph in the frame paths, its launches carry no stage events",
         }
         res["peak_device_GiB"] = {"headline_allocated": torch.cuda.max_memory_allocated(dev) / 2**30,
                                   "headline_reserved": torch.cuda.max_memory_reserved(dev) / 2**30}
