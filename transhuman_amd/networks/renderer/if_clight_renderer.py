@@ -524,6 +524,18 @@ class Renderer:
             hull_side = self._dev.get(("hull_side_stream", str(dev)))
             if hull_side is None:
                 hull_side = self._dev[("hull_side_stream", str(dev))] = torch.cuda.Stream(dev)
+        if token_exchange is not None and os.environ.get("TH_GRAPH_PRIME", "1") != "0":
+            # multi-rank job: a rank runs TransHE (and, with the stem exchange, the stem) only for the frames it owns, so the
+            # first-call capture of their graphs (a device synchronisation + a garbage collection per instance: tens of
+            # milliseconds) would land on its first OWNED frame -- frame r of rank r, inside a short run's timed frames.  One
+            # local set of frame constants up front (no exchange, result dropped) captures both rings on every rank at once.
+            # (Train-mode BatchNorm running statistics advance by this one extra frame; they do not enter the rendering.)
+            shape = tuple(first["input_imgs"][0].shape)
+            primed = self._dev.setdefault(("graphs_primed", str(dev)), set())
+            if shape not in primed and hip.graphs_enabled():
+                primed.add(shape)
+                with torch.cuda.stream(side):
+                    self.prepare_frame(first, stem_graph=True)
         queue = collections.deque([front(first, 0, side)])
         tokens(queue[0], side)
         queued, more = 1, True
