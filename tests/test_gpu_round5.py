@@ -248,3 +248,41 @@ def test_graph_capture_failure_falls_back_to_separate_launches(hip, gpu, monkeyp
     finally:
         hip._graphs_off[0] = False
         get_cfg().N_samples = 64
+
+
+def test_graphs_back_off_when_the_weights_change_with_every_frame(hip, gpu):
+    """rendering inside a training loop: the weights change between every two frames, so a captured graph would never be replayed
+    -- after three such captures the stem and TransHE stay on separate launches (no 70 ms capture per frame), the images stay
+    right, and once the weights have settled the graphs come back"""
+    from transhuman_amd.config import get_cfg
+    net = make_net(12).to(gpu)
+    r = _renderer(net, 300, 32, synth_assign(300))
+    b = synth.batch_to(synth.make_batch(48, 48, 3, seed=0, focal=150.0), gpu)
+    real = torch.cuda.CUDAGraph.capture_begin
+    n_cap = [0]
+
+    def counting(self, *a, **k):
+        n_cap[0] += 1
+        return real(self, *a, **k)
+    torch.cuda.CUDAGraph.capture_begin = counting
+    try:
+        with torch.no_grad():
+            per_frame = []
+            for i in range(7):
+                net.encoder.model.conv1.weight.mul_(1.0)            # (a no-op update: the version counter moves, the values do not)
+                net.ViT.norm.weight.mul_(1.0)
+                before = n_cap[0]
+                o = r.render_fast(b)
+                per_frame.append(n_cap[0] - before)
+            assert per_frame[0] > 0 and sum(per_frame[4:]) == 0, per_frame        # backed off
+            ref = {k: v.clone() for k, v in o.items()}
+            for i in range(4):                                                    # settled: captured once more, then replayed
+                before = n_cap[0]
+                o = r.render_fast(b)
+                per_frame.append(n_cap[0] - before)
+                for k in ref:
+                    assert torch.equal(o[k], ref[k]), (i, k)
+            assert sum(per_frame[7:]) > 0 and per_frame[-1] == 0, per_frame
+    finally:
+        torch.cuda.CUDAGraph.capture_begin = real
+        get_cfg().N_samples = 64

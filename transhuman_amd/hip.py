@@ -898,13 +898,26 @@ def _vit_forward_graphed(vit, x, pe):
     key = (id(vit), tuple(x.shape), str(x.device))
     ver = (_vit_graph_epoch[0], pe.data_ptr(), _ctx_owner.get((_dev_index(x.device), "vit"), (None, None))[1])
     st = _vit_graphs.get(key)
+    if st is not None and st.get("eager_only"):
+        st["same"] = st["same"] + 1 if st["ver"] == ver else 0          # (a version that has settled gets its graphs back)
+        st["ver"] = ver
+        if st["same"] < 2:
+            return None
+        st = None
     if st is None or st["ver"] != ver:
         # first call of a version: eagerly (the kernels' first launches must not happen under capture), then every instance of
         # the ring is captured at once -- the cost of capturing (a device synchronisation each) lands in this one call, not in
         # the next VIT_GRAPH_RING frames of a stream (a rank of N computes TransHE every N-th frame only)
+        # (a version that changes with every call -- weights updated between frames, a positional table converted anew each time --
+        # would capture on every call: after three captures that were never replayed the module stays on separate launches)
+        thrash = 0 if st is None or st["replays"] > 0 else st["thrash"] + 1
+        if thrash >= 3:
+            _vit_graphs[key] = {"eager_only": True, "mod": vit, "ver": ver, "same": 0}
+            return None
         if len(_vit_graphs) > 8:
             _vit_graphs.clear()
-        st = _vit_graphs[key] = {"ver": ver, "inst": [], "next": 0, "mod": vit, "pe": pe}     # (the graphs hold pe's address)
+        st = _vit_graphs[key] = {"ver": ver, "inst": [], "next": 0, "mod": vit, "pe": pe,     # (the graphs hold pe's address)
+                                 "replays": 0, "thrash": thrash}
         out = vit_forward(vit, x, pe, graph=False, _checked=True)
         try:
             for _ in range(VIT_GRAPH_RING):
@@ -916,6 +929,7 @@ def _vit_forward_graphed(vit, x, pe):
         return out
     k = st["next"]
     st["next"] = (k + 1) % VIT_GRAPH_RING
+    st["replays"] += 1
     g, xs, out = st["inst"][k]
     xs.copy_(x)
     g.replay()

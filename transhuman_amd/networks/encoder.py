@@ -194,11 +194,23 @@ class SpatialEncoder(nn.Module):
         if ver is None or x.dtype != torch.float32:
             return None
         st = getattr(self, "_stem_graphs", None)
+        if st is not None and st.get("eager_only"):
+            st["same"] = st["same"] + 1 if st["ver"] == ver else 0      # (a version that has settled gets its graphs back)
+            st["ver"] = ver
+            if st["same"] < 2:
+                return None
+            st = None
         if st is None or st["ver"] != ver:
             # first frame of a version: eagerly (it also packs the convolution weights, which must not happen under capture),
             # then every instance of the ring is captured at once: the cost of capturing lands in this one frame
+            # (weights that change between every two frames -- rendering inside a training loop -- would capture on every call:
+            # after three captures that were never replayed the stem stays on separate launches)
             from .. import hip
-            st = self._stem_graphs = {"ver": ver, "inst": [], "next": 0}
+            thrash = 0 if st is None or st["replays"] > 0 else st["thrash"] + 1
+            if thrash >= 3:
+                self._stem_graphs = {"eager_only": True, "ver": ver, "same": 0}
+                return None
+            st = self._stem_graphs = {"ver": ver, "inst": [], "next": 0, "replays": 0, "thrash": thrash}
             lat = self._trunk_fused_bn(x)
             try:
                 for _ in range(self.GRAPH_RING):
@@ -210,6 +222,7 @@ class SpatialEncoder(nn.Module):
             return lat
         k = st["next"]
         st["next"] = (k + 1) % self.GRAPH_RING
+        st["replays"] += 1
         g, xs, lat = st["inst"][k]
         # (an elementwise kernel, not xs.copy_(x): the runtime's device-to-device copy of the 9.4 MB of three 512 x 512 images took
         # 180 - 240 us -- 45 GB/s -- in front of the first convolution, tools/dropin_trace.sh)
