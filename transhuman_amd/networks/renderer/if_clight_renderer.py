@@ -569,7 +569,9 @@ class Renderer:
                                              "the owner rank's convolutions)")
             # (bad_stem on its own is a reason to rebuild: once the device is in conv fallback the epoch does not move again)
             if not ok or bad_stem or epoch != hip.range_epoch(dev):
-                if bad_stem or hip.conv_fallback(dev) or hip.vit_fallback(dev):
+                # (look-ahead 3: five frames are alive when this one is finished, one more than the graphs' rings of four hold --
+                # its latents / tokens may have been handed to the frame three ahead: constants again in that case too)
+                if bad_stem or hip.conv_fallback(dev) or hip.vit_fallback(dev) or lookahead >= 3:
                     frame = frame.rebuild()                 # constants again, through the paths the guard switched to
                 rgb, acc, depth, stats = hip.render_rays(self.net, frame, pts, white_bkgd=bool(cfg.white_bkgd),
                                                          small_frame_rays=small_frame_rays)
