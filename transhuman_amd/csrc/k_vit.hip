@@ -451,9 +451,10 @@ __global__ __launch_bounds__(64) void attn2_kernel(const float* __restrict__ qkv
 static int vit_npad(int N) { return (N + 63) / 64 * 64; }
 
 // zero fill of the K / V^T planes as a KERNEL, not hipMemsetAsync: this forward is also replayed as a hipGraph (hip.vit_forward(
-// graph=True)), and a graph holding a memset node in front of its kernel nodes produced non-finite tokens in a third of the runs
-// of tests/test_gpu_parity.py::test_render_sequence_equals_per_frame_render on ROCm 7.2 (0 of 15 with
-// DEBUG_CLR_GRAPH_PACKET_CAPTURE=0; the stem's graph -- kernel nodes only -- never failed).  profiles/r05_l_vit_graph_memset_node.txt
+// graph=True)), and with the clear as a memset node the replayed graph produced non-finite tokens in a third of the runs of
+// tests/test_gpu_parity.py::test_render_sequence_equals_per_frame_render on ROCm 7.2 (0 of 15 with
+// DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, 0 of 40 with this kernel; the stem's graph -- kernel nodes only -- never failed; a stand-alone
+// memset -> kernel graph does not fail either: tools/ubench/graph_memset_node.py).  profiles/r05_l_vit_graph_memset_node.txt
 __global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, long long n16) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256)
         p[i] = make_uint4(0u, 0u, 0u, 0u);
