@@ -480,8 +480,8 @@ def run_extras(dev, net, args, H, W, V):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)          # (1.5 s of timed frames at N = 1)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="real", choices=["real", "dense", "orbit", "mesh"],
                     help="real/dense: the headline frame (SURVEY 8d C2); orbit: C3, a new target camera every step, rays "
                          "made on device (th_gen_rays); mesh: C5, sigma on a --grid^3 voxel grid (voxels/s)")
