@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 10
+#define TH_ABI_VERSION 11
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -41,6 +41,11 @@ int         th_abi_version(void);
 const char* th_last_error(void);
 int         th_ctx_create(int device, th_ctx** out);
 void        th_ctx_destroy(th_ctx* ctx);
+/* sizeof() of a struct of this header as the LIBRARY was compiled with it: "th_points", "th_frame", "th_map_source",
+ * "th_linear", "th_mlp_weights", "th_vit_block", "th_smpl_model"; 0 for an unknown name.  A binding written in another language
+ * (INTEGRATION.md's ctypes stub) checks its own struct definitions against it -- a struct that is short by one field
+ * makes the library read garbage pointers (ABI 10 grew th_points by two). */
+size_t      th_sizeof(const char* type_name);
 
 /* ---- stage timing (HIP events on the launch stream) --------------------- */
 /* When enabled, the frame-level entry points bracket their stages with

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_binding_table_matches_header(lib):
     from transhuman_amd import hip
     assert sorted(hip.SYMBOLS) == header_functions()
-    assert lib.th_abi_version() == 10
+    assert lib.th_abi_version() == 11
 
 
 def test_workspace_queries_are_pure_host_calls(lib):
@@ -70,3 +70,38 @@ def test_errors_are_reported_not_crashed(lib):
     bad = lib.th_set_chunk_samples(3)
     assert bad != 0 and b"chunk" in lib.th_last_error()
     assert lib.th_set_chunk_samples(524288) == 0
+
+
+def _integration_snippet_structs():
+    """The ctypes Structure classes of INTEGRATION.md's python stub, executed as written."""
+    import ctypes as C
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    assert blocks, "INTEGRATION.md lost its ctypes stub"
+    out = {}
+    for blk in blocks:
+        for m in re.finditer(r"^class (\w+)\(C\.Structure\):.*?\n(?:[ \t]+.*\n)+", blk, flags=re.M):
+            ns = {"C": C}
+            exec(m.group(0), ns)                      # (documentation of this repository, not reference content)
+            out[m.group(1)] = ns[m.group(1)]
+    return out
+
+
+def test_integration_md_structs_match_the_library(lib):
+    """the document's ThPoints once had 9 fields against the ABI's 11 -- a maintainer who copied it
+    handed th_composite a struct 16 bytes short.  The snippet is now executed and held to th_sizeof()."""
+    import ctypes as C
+    from transhuman_amd import hip
+    structs = _integration_snippet_structs()
+    assert "ThPoints" in structs
+    cname = {"ThPoints": b"th_points", "ThFrame": b"th_frame", "ThMapSource": b"th_map_source"}
+    for name, cls in structs.items():
+        want = lib.th_sizeof(cname[name])
+        assert want > 0 and C.sizeof(cls) == want, (name, C.sizeof(cls), want)
+        ours = getattr(hip, name)
+        assert [f[0] for f in cls._fields_] == [f[0] for f in ours._fields_], name
+    # the binding's own structs against the library as compiled
+    assert C.sizeof(hip.ThPoints) == lib.th_sizeof(b"th_points")
+    assert C.sizeof(hip.ThFrame) == lib.th_sizeof(b"th_frame")
+    assert C.sizeof(hip.ThMapSource) == lib.th_sizeof(b"th_map_source")
+    assert lib.th_sizeof(b"no_such_struct") == 0

@@ -66,6 +66,13 @@ extern "C" {
 
 int th_abi_version(void) { return TH_ABI_VERSION; }
 const char* th_last_error(void) { return g_err.c_str(); }
+size_t th_sizeof(const char* type_name) {
+    if (type_name == nullptr) return 0;
+#define TH_SZ(T) if (strcmp(type_name, #T) == 0) return sizeof(T)
+    TH_SZ(th_points); TH_SZ(th_frame); TH_SZ(th_map_source); TH_SZ(th_linear); TH_SZ(th_mlp_weights); TH_SZ(th_vit_block); TH_SZ(th_smpl_model);
+#undef TH_SZ
+    return 0;
+}
 
 int th_ctx_create(int device, th_ctx** out) {
     TH_REQUIRE(out != nullptr, "null out");
@@ -1037,7 +1044,9 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
     const bool demand_miss = f->map_source != nullptr && f->map_source->demand != nullptr &&
                              !(tk && tk->demand == f->map_source->demand);
     if (f->map_source != nullptr && n > 0 && !(tk && tk->map_done == f->pixel_map_nhwc) &&
-        !(c->map_completed != nullptr && c->map_completed == f->pixel_map_nhwc) &&
+        !(f->map_source->demand != nullptr && c->map_completed != nullptr && c->map_completed == f->pixel_map_nhwc &&
+          c->map_completed_demand == (const void*)f->map_source->demand) &&       // (demand maps only, keyed on the PAIR: a freed
+                                                                                   // block handed to a later cropped map must not match)
         (f->map_source->demand != nullptr ? demand_miss      // (a demand made from THIS sample list covers every branch)
                                           : (unmasked || f->hull_thresh < 0.f || f->hull_thresh > f->map_source->reach))) {
         const th_map_source* ms = f->map_source;
@@ -1048,7 +1057,10 @@ static int shade_points(th_ctx* c, const th_frame* f, const ThPointSrc& ps, long
         if (tex) TH_TRY(th_map_fold_launch(c->fused, f->pixel_map_nhwc, V, f->H, f->W, nullptr, const_cast<float*>(f->map_fold),
                                            c->range_dev, s));
         if (tk) tk->map_done = f->pixel_map_nhwc;
-        if (f->map_source->demand != nullptr) c->map_completed = f->pixel_map_nhwc;      // (until the next th_render_predemand)
+        if (f->map_source->demand != nullptr) {                                          // (until the next th_render_predemand / prepass)
+            c->map_completed = f->pixel_map_nhwc;
+            c->map_completed_demand = (const void*)f->map_source->demand;
+        }
     }
     const bool can_pre = ray_mode && tok_gather(c, V) && fmt == TH_ROWS_SPLIT;
     char* pb = (char*)pool;
@@ -1394,6 +1406,7 @@ int th_render_predemand(th_ctx* c, const th_frame* f, const th_points* rays, voi
     th_ctx::Prepass& t = c->prepass[slot];
     t.demand = nullptr;
     c->map_completed = nullptr;
+    c->map_completed_demand = nullptr;
     TH_HIP(hipStreamWaitEvent(s, t.ev, 0));                      // the prepass may have run on another stream
     TH_TRY(th_demand_launch(th_src(rays), w.idx, w.info, f->cams, f->scale_xy, f->V, f->H, f->W, verts_paint, n_paint, demand, s));
     t.demand = demand;

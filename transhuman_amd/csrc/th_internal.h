@@ -358,7 +358,8 @@ struct th_ctx {
     int n_cu = 256;
     // second stream of the pre-gather stage: K4 (neighbour records: VALU / LDS work, no row gather since TH_ROWS_NBR)
     // runs beside K5 (pixel-feature gather: texture-path bound) instead of behind it
-    const void* map_completed = nullptr;    // a demand-driven map that a later call had to write in full (shade_points)
+    const void* map_completed = nullptr;    // a demand-driven map that a later call had to write in full (shade_points) ...
+    const void* map_completed_demand = nullptr;   // ... and the demand buffer it was made from (the pair identifies the frame)
     hipStream_t aux = nullptr, aux2 = nullptr;
     hipEvent_t aux_fork = nullptr, aux_join = nullptr, aux2_join = nullptr;
     // th_render_pregather_early: the point of the last th_render_rays' stream where its per-sample stage (fused MLP +

@@ -60,6 +60,7 @@ class ThMapSource(C.Structure):
 SYMBOLS = {
     "th_abi_version": (C.c_int, []),
     "th_last_error": (C.c_char_p, []),
+    "th_sizeof": (C.c_size_t, [C.c_char_p]),
     "th_ctx_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "th_ctx_destroy": (None, [C.c_void_p]),
     "th_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
@@ -202,7 +203,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 10:
+    if lib.th_abi_version() != 11:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
