@@ -106,6 +106,13 @@ int th_set_mlp_weights(th_ctx* ctx, const th_mlp_weights* w, th_stream stream);
  * v_mfma_f32_32x32x16_f16 with fp16 hi/lo operand splitting (3 products, fp32 accumulate: fp32-class
  * accuracy); 0 = one fp32-MFMA GEMM launch per layer (exact fp32 products; also the path for V = 4). */
 int th_set_mlp_mode(th_ctx* ctx, int mode);
+/* Form of the fused kernel (mode 1) on the frame-level path (texel lists + neighbour records): 8 (default) = 512-thread
+ * workgroups, two waves per SIMD, every wave owning half the output columns of a layer, dense layers on
+ * v_mfma_f32_16x16x32_f16 (k_mlp_fused8_kernel.h, round 6); 4 = the 256-thread form of rounds 2-5 (one wave per SIMD,
+ * v_mfma_f32_32x32x16_f16), which also serves every other hand-over (row operands, V = 1..3).  Same tile, same
+ * arithmetic (three fp16 products per fp32 MAC); results differ by fp32 summation order only.  New contexts read
+ * TH_FUSED_WAVES. */
+int th_set_fused_waves(th_ctx* ctx, int waves);
 /* K4 -> K6 hand-over of the token branch on the fused path (Network.get_human_representation, cross_transformer.py:151-205,
  * feeding fc_0, :291-295): 1 (default) = K4 writes, per sample, its 7 nearest token centres (as slots of the per-tile
  * union) and their softmax weights, and the fused kernel blends the rows of the per-frame table tokens fc_0[:, :192]^T on

@@ -30,6 +30,7 @@
 #include <string.h>
 
 #include "k_mlp_fused_kernel.h"
+#include "k_mlp_fused8_kernel.h"
 
 // ---- host: packing -------------------------------------------------------------------
 // cols[] gives, for every (wave, ct), the first output column of that 32-wide tile.
@@ -59,6 +60,36 @@ __global__ void pack_fused_kernel(const float* __restrict__ W, int N, int K, int
     }
 }
 
+// 16x16x32 form (8 waves): lane = 16 g + l holds column cols[wave][ct] + l, the 8 k of 16-byte slot `sigma` of the operand row:
+// natural order sigma = 4 t + g; PERM (K = 256 operands, see k_mlp_fused8_kernel.h) sigma = 2 t + (g >> 1) + 16 (g & 1)
+struct Cols24 { int c[24]; };
+__global__ void pack_fused16_kernel(const float* __restrict__ W, int N, int K, int T, int CT, Cols24 cols, float scale, int perm,
+                                    uint4* __restrict__ out) {
+    long long total = 8LL * T * CT * 2 * 64;
+    for (long long o = blockIdx.x * (long long)blockDim.x + threadIdx.x; o < total; o += (long long)gridDim.x * blockDim.x) {
+        int lane = (int)(o & 63);
+        long long q = o >> 6;
+        int plane = (int)(q & 1); q >>= 1;
+        int ct = (int)(q % CT); q /= CT;
+        int t = (int)(q % T);
+        int wave = (int)(q / T);
+        int col = cols.c[wave * CT + ct] + (lane & 15);
+        int g = lane >> 4;
+        int sigma = perm ? 2 * t + (g >> 1) + 16 * (g & 1) : 4 * t + g;
+        int k0 = 8 * sigma;
+        h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int k = k0 + j;
+            float x = (col < N && k < K) ? W[(long long)col * K + k] * scale : 0.f;
+            _Float16 hi, lo;
+            split_h(x, hi, lo);
+            v[j] = plane == 0 ? hi : lo;
+        }
+        out[o] = *reinterpret_cast<uint4*>(&v);
+    }
+}
+
 __global__ void absmax_kernel(const float* __restrict__ w, long long n, unsigned int* __restrict__ out) {
     float m = 0.f;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -74,6 +105,9 @@ size_t th_fused_pack_bytes() {
                            {128, 256}, {128, 32},  {256, 384}, {256, 272}, {128, 128}};
     // fc_0pe, ar0, ar0c, kv1, kv0, fc_2, fc_3, vfA, vfD, rst, rstc, fc_4
     for (auto& d : dims) halves += (size_t)d[0] * d[1] * 2 + 4096;
+    // the 16x16x32 images of the 8-wave kernel: fc_0pe, kv1, kv0, fc_2, fc_3, vfA, vfD, fc_4 (K padded to 32)
+    const int dims16[][2] = {{256, 64}, {384, 256}, {384, 256}, {256, 256}, {256, 256}, {128, 256}, {128, 32}, {128, 128}};
+    for (auto& d : dims16) halves += (size_t)d[0] * d[1] * 2 + 4096;
     return th_align(halves * 2) + 16 * 256 + 64 * 1024;
 }
 
@@ -117,6 +151,24 @@ static int pack_layer(const float* w, const float* b, int N, int K, int CT, cons
     cur.w += th_align((size_t)total * 16);
     cur.bias += (N + 3) & ~3;
     cur.cols += 16;
+    return 0;
+}
+
+// the same layer (same source, same power-of-two scale, same bias storage) as 16x16x32 fragments for 8 waves
+static int pack_layer16(const float* w, int N, int K, int CT, const int* cols_host, const FusedLayer& base, int sl2, PackCursor& cur,
+                        FusedLayer* out, hipStream_t s) {
+    const int T = (K + 31) / 32;
+    Cols24 cols{};
+    for (int i = 0; i < 8 * CT; ++i) cols.c[i] = cols_host[i];
+    uint4* dst = (uint4*)cur.w;
+    const long long total = 8LL * T * CT * 2 * 64;
+    hipLaunchKernelGGL(pack_fused16_kernel, dim3(256), dim3(256), 0, s, w, N, K, T, CT, cols, ldexpf(1.f, sl2), K == 256 ? 1 : 0, dst);
+    TH_LAUNCH_CHECK();
+    *out = base;
+    out->w = dst;
+    out->CT = CT;
+    out->KB = T;
+    cur.w += th_align((size_t)total * 16);
     return 0;
 }
 
@@ -188,6 +240,12 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
     PackCursor cur{(char*)store, (float*)tail, (int*)(tail + 40 * 1024)};
     unsigned int* amax = (unsigned int*)(tail + 60 * 1024);
     int c256[8], c128[4], ckv[12], cst[8];
+    int c256_16[16], c128_16[8], ckv16[24];       // 8 waves, 16-wide column tiles (k_mlp_fused8_kernel.h)
+    for (int wv = 0; wv < 8; ++wv) {
+        c256_16[wv * 2] = wv * 32; c256_16[wv * 2 + 1] = wv * 32 + 16;
+        c128_16[wv] = wv * 16;
+        ckv16[wv * 3] = wv * 16; ckv16[wv * 3 + 1] = 128 + wv * 32; ckv16[wv * 3 + 2] = 128 + wv * 32 + 16;
+    }
     for (int wv = 0; wv < 4; ++wv) {
         c256[wv * 2] = wv * 64; c256[wv * 2 + 1] = wv * 64 + 32;
         c128[wv] = wv * 32;
@@ -216,11 +274,15 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
         TH_HIP(hipMemcpy2DAsync(wpe, 63 * 4, w->fc_0.w + 192, 255 * 4, 63 * 4, 256, hipMemcpyDeviceToDevice, s));
         TH_TRY(layer_scale_log2(wpe, 256LL * 63, amax, &sl2, s));
         TH_TRY(pack_layer(wpe, w->fc_0.b, 256, 63, 2, c256, sl2, cur, &out->fc_0pe, s));
+        TH_TRY(pack_layer16(wpe, 256, 63, 2, c256_16, out->fc_0pe, sl2, cur, &out->w16.fc_0pe, s));
     }
     PACK_SIMPLE(ar0, w->alpha_res_0, 256, 384, 2, c256);
     PACK_SIMPLE(fc_2, w->fc_2, 256, 256, 2, c256);
+    TH_TRY(pack_layer16(w->fc_2.w, 256, 256, 2, c256_16, out->fc_2, sl2, cur, &out->w16.fc_2, s));
     PACK_SIMPLE(fc_3, w->fc_3, 256, 256, 2, c256);
+    TH_TRY(pack_layer16(w->fc_3.w, 256, 256, 2, c256_16, out->fc_3, sl2, cur, &out->w16.fc_3, s));
     PACK_SIMPLE(fc_4, w->fc_4, 128, 128, 1, c128);
+    TH_TRY(pack_layer16(w->fc_4.w, 128, 128, 1, c128_16, out->fc_4, sl2, cur, &out->w16.fc_4, s));
 #undef PACK_SIMPLE
     out->compact_ready = false;
     if (folded) {
@@ -248,9 +310,11 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
             TH_TRY(layer_scale_log2(st, 128LL * 27, amax, &sl2b, s));
             if (sl2b < sl2) sl2 = sl2b;
             TH_TRY(pack_layer(st, nullptr, 128, 27, 1, c128, sl2, cur, &out->vfD, s));
+            TH_TRY(pack_layer16(st, 128, 27, 1, c128_16, out->vfD, sl2, cur, &out->w16.vfD, s));
         }
         const int s_vf = sl2;
         TH_TRY(pack_layer(XF, nullptr, 128, 256, 1, c128, s_vf, cur, &out->vfA, s));
+        TH_TRY(pack_layer16(XF, 128, 256, 1, c128_16, out->vfA, s_vf, cur, &out->w16.vfA, s));
         for (int variant = 0; variant < (folded ? 2 : 1); ++variant) {
             const int K = variant ? 260 : 384;
             const float* xr = variant ? XRc : XR;
@@ -288,6 +352,7 @@ int th_fused_pack(const th_mlp_weights* w, const th_linear* folded, void* store,
         TH_HIP(hipMemsetAsync(tb + 128, 0, 256 * 4, s));
         TH_TRY(layer_scale_log2(tw, 384LL * 256, amax, &sl2, s));
         TH_TRY(pack_layer(tw, tb, 384, 256, 3, ckv, sl2, cur, which == 0 ? &out->kv1 : &out->kv0, s));
+        TH_TRY(pack_layer16(tw, 384, 256, 3, ckv16, which == 0 ? out->kv1 : out->kv0, sl2, cur, which == 0 ? &out->w16.kv1 : &out->w16.kv0, s));
     }
     // folded bias of fc_1 (fc_1 itself lives inside the value projections)
     hipLaunchKernelGGL(fold_bias_kernel, dim3(1), dim3(256), 0, s, w->fc_1.w, w->fc_1.b, w->val1.b, w->val0.b, cur.bias);
@@ -414,6 +479,14 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
 #undef FM_ATTR_T
     }
     dim3 grid(tex ? 8 * th_cdiv(th_cdiv(P, FM_PTS), 8) : th_cdiv(P, FM_PTS));     // (TEX: XCD-contiguous tile order)
+    // the 8-wave kernel (two waves per SIMD) serves the hand-overs the frame-level entry points run: texel lists + neighbour records
+    const bool eight = base.waves == 8 && tex && tsplit != nullptr;
+    static unsigned long long attr8_done = 0ull;
+    if (eight && th_lds_attr_needed(&attr8_done)) {
+        TH_HIP(hipFuncSetAttribute((const void*)mlp_fused8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_BYTES));
+        TH_HIP(hipFuncSetAttribute((const void*)mlp_fused8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_BYTES));
+        TH_HIP(hipFuncSetAttribute((const void*)mlp_fused8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, F8_LDS_BYTES));
+    }
     // developer aid: TH_FUSED_DBG=1 -> average cycles between barriers over every 16th tile (first big launch only)
     static int dbg_state = getenv("TH_FUSED_DBG") ? 1 : 0;
     static long long* dbg_dev = nullptr;
@@ -426,7 +499,10 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     }
 #define FM_LAUNCH(V_, F_) hipLaunchKernelGGL((mlp_fused_kernel<V_, F_>), grid, dim3(256), FUSED_LDS_BYTES, s, p)
 #define FM_LAUNCH_T(V_) hipLaunchKernelGGL((mlp_fused_kernel<V_, 1, true>), grid, dim3(256), FUSED_LDS_BYTES, s, p)
-    if (tex) {
+#define FM_LAUNCH_8(V_) hipLaunchKernelGGL((mlp_fused8_kernel<V_>), grid, dim3(F8_THREADS), F8_LDS_BYTES, s, p)
+    if (eight) {
+        if (V == 1) FM_LAUNCH_8(1); else if (V == 2) FM_LAUNCH_8(2); else FM_LAUNCH_8(3);
+    } else if (tex) {
         if (V == 1) FM_LAUNCH_T(1); else if (V == 2) FM_LAUNCH_T(2); else FM_LAUNCH_T(3);
     } else
     switch (V * 2 + (cf ? 1 : 0)) {
@@ -438,7 +514,48 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
         default: FM_LAUNCH(3, 1); break;
     }
 #undef FM_LAUNCH
+    // developer aid: TH_FUSED_CHECK=1 -> the first big 8-wave launch is repeated by the 4-wave kernel into a scratch buffer and the two
+    // raw outputs are compared on the host (per channel: max difference, worst sample)
+    static int chk_state = getenv("TH_FUSED_CHECK") ? 1 : 0;
+    if (eight && chk_state == 1 && P >= 4096) {
+        chk_state = 2;
+        float* raw4 = nullptr;
+        TH_HIP(hipMalloc((void**)&raw4, (size_t)P * 16));
+        FusedParams q = p;
+        q.raw_c = raw4; q.dbg = nullptr; q.range = nullptr;
+        if (V == 1) hipLaunchKernelGGL((mlp_fused_kernel<1, 1, true>), grid, dim3(256), FUSED_LDS_BYTES, s, q);
+        else if (V == 2) hipLaunchKernelGGL((mlp_fused_kernel<2, 1, true>), grid, dim3(256), FUSED_LDS_BYTES, s, q);
+        else hipLaunchKernelGGL((mlp_fused_kernel<3, 1, true>), grid, dim3(256), FUSED_LDS_BYTES, s, q);
+        TH_HIP(hipStreamSynchronize(s));
+        float* h8v = (float*)malloc((size_t)P * 16);
+        float* h4v = (float*)malloc((size_t)P * 16);
+        TH_HIP(hipMemcpy(h8v, raw_c, (size_t)P * 16, hipMemcpyDeviceToHost));
+        TH_HIP(hipMemcpy(h4v, raw4, (size_t)P * 16, hipMemcpyDeviceToHost));
+        double mx[4] = {0, 0, 0, 0};
+        long long wi[4] = {0, 0, 0, 0}, nbad[4] = {0, 0, 0, 0};
+        for (long long i = 0; i < P; ++i)
+            for (int ch = 0; ch < 4; ++ch) {
+                const double d = fabs((double)h8v[i * 4 + ch] - (double)h4v[i * 4 + ch]);
+                if (!(d <= mx[ch])) { mx[ch] = d; wi[ch] = i; }
+                if (!(d <= 1e-4)) ++nbad[ch];
+            }
+        for (int ch = 0; ch < 4; ++ch)
+            fprintf(stderr, "[TH_FUSED_CHECK] raw ch %d: max |8w - 4w| = %.3e at sample %lld (tile %lld, row %lld): %.6f vs %.6f; %lld of %d above 1e-4\n", ch,
+                    mx[ch], wi[ch], wi[ch] / 32, wi[ch] % 32, h8v[wi[ch] * 4 + ch], h4v[wi[ch] * 4 + ch], nbad[ch], P);
+        // the first tile with a bad green value, row by row
+        for (long long i = 0; i < P; ++i)
+            if (fabs(h8v[i * 4 + 1] - h4v[i * 4 + 1]) > 1e-4) {
+                const long long t0 = i / 32 * 32;
+                for (long long r = t0; r < t0 + 32 && r < P; ++r)
+                    fprintf(stderr, "   row %2lld  8w %9.5f %9.5f %9.5f %9.5f   4w %9.5f %9.5f %9.5f %9.5f\n", r - t0, h8v[r * 4], h8v[r * 4 + 1], h8v[r * 4 + 2],
+                            h8v[r * 4 + 3], h4v[r * 4], h4v[r * 4 + 1], h4v[r * 4 + 2], h4v[r * 4 + 3]);
+                break;
+            }
+        free(h8v); free(h4v);
+        TH_HIP(hipFree(raw4));
+    }
 #undef FM_LAUNCH_T
+#undef FM_LAUNCH_8
     TH_LAUNCH_CHECK();
     if (dbg_now) {
         long long st[64];

@@ -246,7 +246,14 @@ struct FusedLayer {
     int CT, KB;
     float inv_scale2;    // stacked layers: scale of the second column-tile family (rows N/2 ..)
 };
+// the dense layers of the 8-wave kernel (k_mlp_fused8_kernel.h) as v_mfma_f32_16x16x32_f16 fragments: [wave 8][k-step][column tile]
+// [hi | lo][64 lanes][8 halves]; KB = number of 32-deep k-steps; bias / scales are those of the 32x32x16 images
+struct Fused16 {
+    FusedLayer fc_0pe, kv1, kv0, fc_2, fc_3, fc_4, vfA, vfD;
+};
 struct FusedParams {
+    Fused16 w16;
+    int waves;                     // 4: mlp_fused_kernel, 8: mlp_fused8_kernel where the hand-overs allow it (th_set_mlp_mode 1 | 2)
     FusedLayer fc_0pe;             // fc_0[:, 192:255] (the positional-encoding columns) + the fc_0 bias
     FusedLayer kv1, ar0, kv0, fc_1, fc_2, fc_3, fc_4;
     // RGB branch after the view_fc fold (k_mlp_fused_host.hip): vfA = view_fc[:, :256] feature_fc (K 256, on inter),

@@ -69,6 +69,7 @@ SYMBOLS = {
     "th_clock_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "th_set_mlp_weights": (C.c_int, [C.c_void_p, C.POINTER(ThMlpWeights), C.c_void_p]),
     "th_set_mlp_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "th_set_fused_waves": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_vit_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_tok_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "th_set_tex_rows": (C.c_int, [C.c_void_p, C.c_int]),
@@ -1472,6 +1473,12 @@ def set_mlp_mode(mode, device=None):
     d = _dev_index(device)
     _user_mode[d] = int(mode)
     _range_fallback.pop(d, None)
+
+
+def set_fused_waves(waves, device=None):
+    """Form of the fused MLP kernel on the frame-level path: 8 = two waves per SIMD (512-thread workgroups, default), 4 = the
+    256-thread form of rounds 2-5."""
+    _check(load_library().th_set_fused_waves(ctx(device), int(waves)))
 
 
 def set_chunk_samples(n):
