@@ -26,7 +26,8 @@ typedef float f8_f4 __attribute__((ext_vector_type(4)));
 
 #define F8_THREADS 512
 #define F8_PART_FLOATS (3 * 8 * 32)                        // [3 outputs][8 waves][32 samples] cross-wave partial sums
-#define F8_MISC_FLOATS (9 * 32 + F8_PART_FLOATS + 32 + 8)  // probs | part | sig | flag
+#define F8_PSTR 12                                         // floats per sample of the softmax table ([j][i], 9 used)
+#define F8_MISC_FLOATS (F8_PSTR * 32 + F8_PART_FLOATS + 32 + 8)  // probs | part | sig | flag
 #define F8_LDS_BYTES (ABUF_BYTES + MBUF_BYTES + F8_MISC_FLOATS * 4)
 static_assert(F8_LDS_BYTES <= 163840, "the 8-wave tile must fit the CU's LDS");
 
@@ -42,9 +43,7 @@ __device__ __forceinline__ void f8_load_w(const uint4* __restrict__ wl, int t, u
         w[c][1] = p[(c * 2 + 1) * 64];
     }
 }
-__device__ __forceinline__ const uint4* f8_wslice(const FusedLayer& L, int wave, int ct) {
-    return L.w + (long long)wave * L.KB * (ct * 2 * 64);          // (KB = number of 32-deep k-steps of a 16-form image)
-}
+#define F8_WSLICE(L, wave, ct) ((L).w + (long long)(wave) * (L).KB * ((ct) * 2 * 64))   // (KB = number of 32-deep k-steps of a 16-form image)
 
 // NR row tiles (16 rows each, ROWSTEP bytes apart) of one k-step
 template <int NR, int ROWSTEP, bool PERM>
@@ -152,52 +151,59 @@ __device__ __forceinline__ void f8_store_h(const f8_f4& t, int row, int col0, ch
 }
 // y = acc * inv_scale + bias (inv_scale a power of two: the fused form rounds like mul + add), optional relu
 __device__ __forceinline__ f8_f4 f8_finish(const f8_f4& a, const float4& b, float inv_scale, bool relu) {
-    f8_f4 y;
-    y[0] = fmaf(a[0], inv_scale, b.x);
-    y[1] = fmaf(a[1], inv_scale, b.y);
-    y[2] = fmaf(a[2], inv_scale, b.z);
-    y[3] = fmaf(a[3], inv_scale, b.w);
+    const f32x2 sc = {inv_scale, inv_scale};
+    f32x2 y01 = __builtin_elementwise_fma((f32x2){a[0], a[1]}, sc, (f32x2){b.x, b.y});
+    f32x2 y23 = __builtin_elementwise_fma((f32x2){a[2], a[3]}, sc, (f32x2){b.z, b.w});
     if (relu) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+        y01 = __builtin_elementwise_max(y01, (f32x2){0.f, 0.f});
+        y23 = __builtin_elementwise_max(y23, (f32x2){0.f, 0.f});
     }
-    return y;
+    return (f8_f4){y01[0], y01[1], y23[0], y23[1]};
+}
+// value of lane (lane ^ mask): ds_bpermute addressed from the kernel's own (per-tile) lane number (__shfl_xor derives the lane from
+// mbcnt: loop-invariant, kept live across the tile loop)
+__device__ __forceinline__ float f8_xor(float v, int lane, int mask) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ mask) << 2, __builtin_bit_cast(int, v)));
 }
 __device__ __forceinline__ float4 f8_bias(const float* __restrict__ bias, int col0, int lane) {
     return *reinterpret_cast<const float4*>(bias + col0 + 4 * (lane >> 4));
 }
 
 template <int V>
-__global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P) {
+__global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P_arg) {
+#define PK P_arg
+    struct F8Dbg { long long* dbg; };
+    const F8Dbg P{PK.dbg};                                // (the cycle-accounting macros of k_mlp_fused_kernel.h read P.dbg)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* abuf = lds;
     char* mbuf = lds + ABUF_BYTES;
     float* misc = reinterpret_cast<float*>(lds + ABUF_BYTES + MBUF_BYTES);
-    float* probs = misc;                       // [V*V][32]
-    float* part = misc + 9 * 32;               // [3][8 waves][32]  (probs + part take the tile's 3 KB of row records while a
+    float* probs = misc;                       // [32][F8_PSTR]
+    float* part = misc + F8_PSTR * 32;         // [3][8 waves][32]  (probs + part take the tile's 3 KB of row records while a
     float* sig = part + F8_PART_FLOATS;        // [32]               filling runs: both are dead then, sig is not)
     int* flag = reinterpret_cast<int*>(sig + 32);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g4 = lane >> 4;
-    // XCD-contiguous tile order (see mlp_fused_kernel)
+    // One workgroup per tile, XCD-contiguous order: the tiles of an XCD (workgroups b, b + 8, ... share an L2) are CONSECUTIVE tiles of
+    // the sample list -- their texel rows overlap, so a row missing in L2 is fetched once per XCD instead of once per tile.
+    // (A persistent form -- 256 workgroups claiming 2 .. 255 tiles each from per-XCD counters -- was built and measured: the same
+    // launch time when the kernel has the device to itself, and a LONGER frame in the pipeline, because a resident workgroup holds
+    // all of a CU's LDS and registers and the other streams' kernels live on the CUs that change hands between tiles:
+    // profiles/r06_o_tiles_per_workgroup.txt.)
     const int tile = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     const int pbase = tile * FM_PTS;
-    if (pbase >= P.P) return;
-    const int npts = min(FM_PTS, P.P - pbase);
+    if (pbase >= PK.P) return;
+    const int npts = min(FM_PTS, PK.P - pbase);
+    const int fm_dbg_tile = tile;                       // (cycle accounting samples every 16th TILE)
+    const int zoff = 0;
     constexpr int ROWS = 32 * V, RT = 2 * V;
     constexpr int RS256 = 16 * STR256;           // bytes between row tiles of a K = 256 plane
     int dbg_i = 1;
     long long dbg_t = 0;
-    if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {
-        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg), 1ull);
-        dbg_t = clock64();
-    }
     constexpr float inv_v = 1.0f / (float)V;
     unsigned rmax = 0u;
-    const unsigned seen_s = P.range ? P.range[TH_RANGE_S] : 0u, seen_p = P.range ? P.range[TH_RANGE_P] : 0u,
-                   seen_n = P.range ? P.range[TH_RANGE_N] : 0u, seen_i = P.range ? P.range[TH_RANGE_INTER] : 0u,
-                   seen_4 = P.range ? P.range[TH_RANGE_F4] : 0u;
+    unsigned seen_s = 0u, seen_p = 0u, seen_n = 0u, seen_i = 0u, seen_4 = 0u;
     char* a256_lo = abuf + ROWS * STR256;
 
     // ---- texel hand-over (see mlp_fused_kernel: fill_tex); 8 waves: texel row i of the list is copied by wave i & 7, operand
@@ -207,11 +213,11 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         int tl = tile;
         asm volatile("" : "+s"(tl));
         TexPre t;
-        const unsigned* hb = P.tex_hdr + (long long)tl * 512;
+        const unsigned* hb = PK.tex_hdr + (long long)tl * 512;
         t.h0 = hb[lane];
         t.h1 = hb[64 + lane];
         t.rq = (fm_u4){0u, 0u, 0u, 0u};
-        if (tid < 64 * V) t.rq = *reinterpret_cast<const fm_u4*>(P.tex_rec + (long long)tl * V * 32 * 8 + tid * 4);
+        if (tid < 64 * V) t.rq = *reinterpret_cast<const fm_u4*>(PK.tex_rec + (long long)tl * V * 32 * 8 + tid * 4);
         return t;
     };
     auto fill_tex = [&](const TexPre& pre, auto rgb, auto&& under) __attribute__((always_inline)) {
@@ -220,15 +226,15 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         static_assert(TMAX * TSTR <= ABUF_BYTES, "a pass of texel rows must fit the operand buffer");
         int wv = __builtin_amdgcn_readfirstlane(wave), tl = tile;
         asm volatile("" : "+s"(wv), "+s"(tl));
-        const unsigned* hb = P.tex_hdr + (long long)tl * 512;
+        const unsigned* hb = PK.tex_hdr + (long long)tl * 512;
         unsigned h0 = pre.h0, h1 = pre.h1;
         const int npass = __builtin_amdgcn_readfirstlane((int)(h0 >> 16));
         char* recl = reinterpret_cast<char*>(misc);
-        static_assert(32 * V * 32 <= (9 * 32 + F8_PART_FLOATS) * 4, "row records must fit probs + part");
+        static_assert(32 * V * 32 <= (F8_PSTR * 32 + F8_PART_FLOATS) * 4, "row records must fit probs + part");
         unsigned fv[NR][4] = {};
         f32x2 bias_lo = {0.f, 0.f}, bias_hi = {0.f, 0.f};
         if constexpr (!RGB) {
-            const float4 b4 = *reinterpret_cast<const float4*>(P.ar0.bias + 4 * lane);
+            const float4 b4 = *reinterpret_cast<const float4*>(PK.ar0.bias + 4 * lane);
             bias_lo = (f32x2){b4.x, b4.y};
             bias_hi = (f32x2){b4.z, b4.w};
         }
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
                 // rows wv, wv + 8, ...: the first 7 of a wave always (list entries 0 .. 55: header word 8 + i is in h0), 3 more for
                 // lists longer than 56, the last 3 for lists longer than 80 (entries 56 ..: word i - 56 of h1)
                 constexpr int NA = 7, NB = 10;
-                const char* mbase = reinterpret_cast<const char*>(RGB ? P.tex_map2 : P.tex_map);
+                const char* mbase = reinterpret_cast<const char*>(RGB ? PK.tex_map2 : PK.tex_map);
                 const unsigned loff = (unsigned)lane * 16u;
                 const int last = U - 1;
                 fm_u4 ta[NA], tb[NB - NA], tc[NK - NB];
@@ -358,7 +364,6 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
             for (int k = 0; k < NR; ++k)
                 *reinterpret_cast<fm_u4*>(abuf + (wv + 8 * k) * TSTR + lane * 16) = (fm_u4){fv[k][0], fv[k][1], fv[k][2], fv[k][3]};
         } else {
-            const unsigned seen_p2 = P.range ? P.range[TH_RANGE_P] : 0u;
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
                 range_acc<true>(rmax, fv[k][0]);
@@ -366,11 +371,24 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
                 *reinterpret_cast<uint2*>(abuf + (wv + 8 * k) * STR256 + lane * 8) = make_uint2(fv[k][0], fv[k][1]);
                 *reinterpret_cast<uint2*>(a256_lo + (wv + 8 * k) * STR256 + lane * 8) = make_uint2(fv[k][2], fv[k][3]);
             }
-            range_commit(P.range, TH_RANGE_P, seen_p2, rmax);
+            range_commit(PK.range, TH_RANGE_P, seen_p, rmax);
         }
     };
 
-    TexPre tex_pre = tex_fetch(), tex_pre2{};
+    if (PK.dbg != nullptr && tid == 0 && (tile & 15) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long*>(PK.dbg), 1ull);
+        dbg_t = clock64();
+    }
+    // range guard: launch-wide maxima as they stand when this tile starts (scalar loads through the constant address space: the
+    // table is only a hint here -- a stale smaller value costs an atomic, never a result)
+    const unsigned* rtab = PK.range;
+    // (uniform values: moved to scalar registers)
+    seen_s = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_S]) : 0u;
+    seen_p = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_P]) : 0u;
+    seen_n = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_N]) : 0u;
+    seen_i = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_INTER]) : 0u;
+    seen_4 = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_F4]) : 0u;
+    TexPre tex_pre = tex_fetch(), tex_pre2;
 
     // ================= token branch: s = relu(fc_0 h); ks|vs = kv1(s) =================
     // (mlp_fused_kernel, TH_ROWS_NBR form: the 7-neighbour blend of T' rows on the matrix pipe + W_pe pe)
@@ -387,26 +405,27 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         // pe: 32 rows x (64 hi | 64 lo halves): one 16-byte piece per thread
         const int pt = tid & 255, prow = pt >> 3, pc = pt & 7, ppl = tid >> 8;
         const int psrc = min(prow, npts - 1);
-        const uint4 pe_v = *reinterpret_cast<const uint4*>(P.pe + (long long)(pbase + psrc) * 128 + 64 * ppl + 8 * pc);
+        const uint4 pe_v = *reinterpret_cast<const uint4*>(PK.pe + (long long)(pbase + psrc) * 128 + 64 * ppl + 8 * pc);
         char* wsp_hi = mbuf + 16384;                                     // W [sample][slot] halves, K = 32 per pass
         char* wsp_lo = wsp_hi + 32 * STRVD;
-        const unsigned* hdr = reinterpret_cast<const unsigned*>(P.stok) + (long long)((P.P + 31) / 32 * 32) * 16 + (long long)tile * 128;
+        const unsigned* hdr = reinterpret_cast<const unsigned*>(PK.stok) + (long long)((PK.P + 31) / 32 * 32) * 16 + (long long)tile * 128;
         const unsigned h0 = hdr[lane], h1 = hdr[64 + lane];
         const int ns = tid / 7, nk = tid - 7 * ns;
         int slot = -1;
         float nw = 0.f;
         if (tid < 224) {
-            const unsigned* rec = reinterpret_cast<const unsigned*>(P.stok) + (long long)(pbase + min(ns, npts - 1)) * 16;
+            const unsigned* rec = reinterpret_cast<const unsigned*>(PK.stok) + (long long)(pbase + min(ns, npts - 1)) * 16;
             slot = (int)rec[nk];
             nw = __builtin_bit_cast(float, rec[8 + nk]);
         }
-        const float inv_t = P.t_inv[0];
+        const unsigned zq = 0u;
+        const float inv_t = PK.t_inv[zoff];
         uint4 wq[2][2][2];
-        const uint4* wl = f8_wslice(P.w16.fc_0pe, wave, 2) + lane;
+        const uint4* wl = F8_WSLICE(PK.w16.fc_0pe, wave, 2) + lane;
         f8_load_w<2>(wl, 0, wq[0]);
         f8_load_w<2>(wl, 1, wq[1]);
-        const float4 b0[2] = {f8_bias(P.fc_0pe.bias, wave * 32, lane), f8_bias(P.fc_0pe.bias, wave * 32 + 16, lane)};
-        if (tid < 2 * 32 * STRVD / 16) reinterpret_cast<uint4*>(wsp_hi)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        const float4 b0[2] = {f8_bias(PK.fc_0pe.bias, wave * 32, lane), f8_bias(PK.fc_0pe.bias, wave * 32 + 16, lane)};
+        if (tid < 2 * 32 * STRVD / 16) reinterpret_cast<uint4*>(wsp_hi)[tid] = make_uint4(zq, zq, zq, zq);
         *reinterpret_cast<uint4*>((ppl ? pe_lo : pe_hi) + prow * STR64 + 16 * pc) = pe_v;
         const int U = __builtin_amdgcn_readfirstlane((int)h0);
         FM_SB();
@@ -419,21 +438,21 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < RT; ++r) acc2[c][r] = (f8_f4){0.f, 0.f, 0.f, 0.f};
-        f8_f4 a1[2][2];
+        f8_f4 a1[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const int aoffw = f8_aoff<false>(lane, STRVD), aoffp = f8_aoff<false>(lane, STR64);
         for (int u0 = 0; u0 < U; u0 += 32) {
             const int nU = min(32, U - u0);
             if (u0 > 0) {
                 FM_SYNCL();
-                if (tid < 2 * 32 * STRVD / 16) reinterpret_cast<uint4*>(wsp_hi)[tid] = make_uint4(0u, 0u, 0u, 0u);
+                if (tid < 2 * 32 * STRVD / 16) reinterpret_cast<uint4*>(wsp_hi)[tid] = make_uint4(zq, zq, zq, zq);
             }
             for (int u = wv; u < nU; u += 8) {
                 const int cu = slot_centre(u0 + u);
-                const char* g = reinterpret_cast<const char*>(P.tsplit) + (long long)cu * 1024 + lane * 16;
+                const char* g = reinterpret_cast<const char*>(PK.tsplit) + (long long)cu * 1024 + lane * 16;
 #pragma unroll
                 for (int vw = 0; vw < V; ++vw)
-                    __builtin_amdgcn_global_load_lds((fm_gptr)(g + (long long)vw * P.t_nc * 1024),
+                    __builtin_amdgcn_global_load_lds((fm_gptr)(g + (long long)vw * PK.t_nc * 1024),
                                                      (fm_lptr)(abuf + (vw * 32 + u) * STOK_STR), 16, 0, 0);
             }
             FM_SYNCL();                                          // W is cleared (and the pe rows are in place)
@@ -484,35 +503,38 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         for (int c = 0; c < 2; ++c) {
             f8_f4 pe2[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) pe2[h] = f8_finish(a1[c][h], b0[c], P.fc_0pe.inv_scale, false);
+            for (int h = 0; h < 2; ++h) pe2[h] = f8_finish(a1[c][h], b0[c], PK.fc_0pe.inv_scale, false);
 #pragma unroll
             for (int r = 0; r < RT; ++r) {
-                f8_f4 u;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) u[e] = fmaxf(fmaf(acc2[c][r][e], inv_t, pe2[r & 1][e]), 0.f);
+                const f32x2 it2 = {inv_t, inv_t};
+                f32x2 u01 = __builtin_elementwise_fma((f32x2){acc2[c][r][0], acc2[c][r][1]}, it2, (f32x2){pe2[r & 1][0], pe2[r & 1][1]});
+                f32x2 u23 = __builtin_elementwise_fma((f32x2){acc2[c][r][2], acc2[c][r][3]}, it2, (f32x2){pe2[r & 1][2], pe2[r & 1][3]});
+                u01 = __builtin_elementwise_max(u01, (f32x2){0.f, 0.f});
+                u23 = __builtin_elementwise_max(u23, (f32x2){0.f, 0.f});
+                const f8_f4 u = {u01[0], u01[1], u23[0], u23[1]};
                 f8_store_h<STR256>(u, r * 16 + l15, wave * 32 + c * 16, abuf, a256_lo, lane, rmax);
             }
         }
-        range_commit(P.range, TH_RANGE_S, seen_s, rmax);
+        range_commit(PK.range, TH_RANGE_S, seen_s, rmax);
     }
     uint4 wk3[2][3][2];
     FM_SB();
-    f8_load_w<3>(f8_wslice(P.w16.kv1, wave, 3) + lane, 0, wk3[0]);
+    f8_load_w<3>(F8_WSLICE(PK.w16.kv1, wave, 3) + lane, 0, wk3[0]);
     FM_SYNCL();
     // kv layers: column tile 0 = key cols 16 wave .., tiles 1, 2 = value cols 128 + 32 wave ..
     f8_f4 vs[2][RT];
     float* ksb = reinterpret_cast<float*>(mbuf);                    // [ROWS][KSTR] fp32 keys of the token branch
     {
         f8_f4 acc3[3][RT];
-        f8_gemm<RT, 3, RS256, true, true>(abuf, a256_lo, STR256, f8_wslice(P.w16.kv1, wave, 3), 8, lane, acc3, wk3);
-        const float4 bk = f8_bias(P.kv1.bias, wave * 16, lane), bv0 = f8_bias(P.kv1.bias, 128 + wave * 32, lane),
-                     bv1 = f8_bias(P.kv1.bias, 128 + wave * 32 + 16, lane);
+        f8_gemm<RT, 3, RS256, true, true>(abuf, a256_lo, STR256, F8_WSLICE(PK.w16.kv1, wave, 3), 8, lane, acc3, wk3);
+        const float4 bk = f8_bias(PK.kv1.bias, wave * 16, lane), bv0 = f8_bias(PK.kv1.bias, 128 + wave * 32, lane),
+                     bv1 = f8_bias(PK.kv1.bias, 128 + wave * 32 + 16, lane);
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            const f8_f4 k = f8_finish(acc3[0][r], bk, P.kv1.inv_scale, false);
+            const f8_f4 k = f8_finish(acc3[0][r], bk, PK.kv1.inv_scale, false);
             *reinterpret_cast<float4*>(ksb + (r * 16 + l15) * KSTR + wave * 16 + 4 * g4) = make_float4(k[0], k[1], k[2], k[3]);
-            vs[0][r] = f8_finish(acc3[1][r], bv0, P.kv1.inv_scale, false);
-            vs[1][r] = f8_finish(acc3[2][r], bv1, P.kv1.inv_scale, false);
+            vs[0][r] = f8_finish(acc3[1][r], bv0, PK.kv1.inv_scale, false);
+            vs[1][r] = f8_finish(acc3[2][r], bv1, PK.kv1.inv_scale, false);
         }
     }
     FM_SYNCL();
@@ -521,22 +543,22 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     FM_SB();
     fill_tex(tex_pre, std::false_type{}, [] {});
     FM_SB();
-    f8_load_w<3>(f8_wslice(P.w16.kv0, wave, 3) + lane, 0, wk3[0]);
+    f8_load_w<3>(F8_WSLICE(PK.w16.kv0, wave, 3) + lane, 0, wk3[0]);
     FM_SYNCL();
     f8_f4 vp[2][RT];
     {
         f8_f4 acc3[3][RT];
-        f8_gemm<RT, 3, RS256, true, true>(abuf, a256_lo, STR256, f8_wslice(P.w16.kv0, wave, 3), 8, lane, acc3, wk3);
-        const float4 bk = f8_bias(P.kv0.bias, wave * 16, lane), bv0 = f8_bias(P.kv0.bias, 128 + wave * 32, lane),
-                     bv1 = f8_bias(P.kv0.bias, 128 + wave * 32 + 16, lane);
+        f8_gemm<RT, 3, RS256, true, true>(abuf, a256_lo, STR256, F8_WSLICE(PK.w16.kv0, wave, 3), 8, lane, acc3, wk3);
+        const float4 bk = f8_bias(PK.kv0.bias, wave * 16, lane), bv0 = f8_bias(PK.kv0.bias, 128 + wave * 32, lane),
+                     bv1 = f8_bias(PK.kv0.bias, 128 + wave * 32 + 16, lane);
         FM_SYNCL();                                                  // every wave is done reading p from ABUF
         float* kpb = reinterpret_cast<float*>(abuf);                // [ROWS][KSTR]
 #pragma unroll
         for (int r = 0; r < RT; ++r) {
-            const f8_f4 k = f8_finish(acc3[0][r], bk, P.kv0.inv_scale, false);
+            const f8_f4 k = f8_finish(acc3[0][r], bk, PK.kv0.inv_scale, false);
             *reinterpret_cast<float4*>(kpb + (r * 16 + l15) * KSTR + wave * 16 + 4 * g4) = make_float4(k[0], k[1], k[2], k[3]);
-            vp[0][r] = f8_finish(acc3[1][r], bv0, P.kv0.inv_scale, false);
-            vp[1][r] = f8_finish(acc3[2][r], bv1, P.kv0.inv_scale, false);
+            vp[0][r] = f8_finish(acc3[1][r], bv0, PK.kv0.inv_scale, false);
+            vp[1][r] = f8_finish(acc3[2][r], bv1, PK.kv0.inv_scale, false);
         }
     }
     FM_SYNCL();
@@ -544,14 +566,16 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     // ================= cross-view attention (cross_transformer.py:128-149) =================
     {
         const float* kpb = reinterpret_cast<const float*>(abuf);
-        const float4 bn[2] = {f8_bias(P.fc_1.bias, wave * 32, lane), f8_bias(P.fc_1.bias, wave * 32 + 16, lane)};
-        // A[j][i] = kp_j . ks_i / sqrt(128).  Thread (p = tid >> 4, c16 = tid & 15) owns float4 columns c16, c16 + 16 of sample p;
-        // the 16 partials of a sample are summed with four DPP steps; every lane of the group forms the softmax, one writes it
+        float4 bn[2];
+        // A[j][i] = kp_j . ks_i / sqrt(128).  Thread (p = tid >> 4, c16 = tid & 15) owns float4 columns c16, c16 + 16 of sample p
+        // (packed FMAs over the component pairs); the 16 partials of a sample are summed with four DPP steps.  The softmax over j of
+        // column i is formed by lane c16 = i ONLY (selects, no indexed register array): three exponentials per wave instruction
+        // stream instead of nine -- with every lane forming all of them this phase took longer on 8 waves than on 4.
         {
             const int p = tid >> 4, c16 = tid & 15;
-            float acc[V * V];
+            f32x2 acc2[V * V];
 #pragma unroll
-            for (int ji = 0; ji < V * V; ++ji) acc[ji] = 0.f;
+            for (int ji = 0; ji < V * V; ++ji) acc2[ji] = (f32x2){0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 float4 kx[V], sx[V];
@@ -561,93 +585,103 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
                     sx[v] = *reinterpret_cast<const float4*>(ksb + (v * 32 + p) * KSTR + 4 * (c16 + 16 * q));
                 }
 #pragma unroll
-                for (int comp = 0; comp < 4; ++comp)
+                for (int j = 0; j < V; ++j)
 #pragma unroll
-                    for (int j = 0; j < V; ++j)
-#pragma unroll
-                        for (int i = 0; i < V; ++i) {
-                            const float a = comp == 0 ? kx[j].x : comp == 1 ? kx[j].y : comp == 2 ? kx[j].z : kx[j].w;
-                            const float b = comp == 0 ? sx[i].x : comp == 1 ? sx[i].y : comp == 2 ? sx[i].z : sx[i].w;
-                            acc[j * V + i] = fmaf(a, b, acc[j * V + i]);
-                        }
+                    for (int i = 0; i < V; ++i) {
+                        acc2[j * V + i] = __builtin_elementwise_fma((f32x2){kx[j].x, kx[j].y}, (f32x2){sx[i].x, sx[i].y}, acc2[j * V + i]);
+                        acc2[j * V + i] = __builtin_elementwise_fma((f32x2){kx[j].z, kx[j].w}, (f32x2){sx[i].z, sx[i].w}, acc2[j * V + i]);
+                    }
             }
+            float acc[V * V];
 #pragma unroll
             for (int ji = 0; ji < V * V; ++ji) {
-                float s = acc[ji];
+                float s = acc2[ji][0] + acc2[ji][1];
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x141, 0xF, 0xF, true));  // row_half_mirror
                 s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0x140, 0xF, 0xF, true));  // row_mirror
-                acc[ji] = s / 11.313708498984761f;
+                acc[ji] = s;
             }
+            float a[V], m = -3.0e38f;
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                float m = -3.0e38f;
+            for (int j = 0; j < V; ++j) {
+                float x = acc[j * V];
 #pragma unroll
-                for (int j = 0; j < V; ++j) m = fmaxf(m, acc[j * V + i]);
-                float e[V], se = 0.f;
+                for (int i = 1; i < V; ++i) x = c16 == i ? acc[j * V + i] : x;
+                a[j] = x / 11.313708498984761f;
+                m = fmaxf(m, a[j]);
+            }
+            float e[V], se = 0.f;
 #pragma unroll
-                for (int j = 0; j < V; ++j) { e[j] = expf(acc[j * V + i] - m); se = se + e[j]; }
+            for (int j = 0; j < V; ++j) { e[j] = expf(a[j] - m); se = se + e[j]; }
+            if (c16 < V) {
 #pragma unroll
-                for (int j = 0; j < V; ++j)
-                    if (c16 == 0) probs[(j * V + i) * 32 + p] = e[j] / se;
+                for (int j = 0; j < V; ++j) probs[p * F8_PSTR + j * V + c16] = e[j] / se;
             }
         }
+        bn[0] = f8_bias(PK.fc_1.bias, wave * 32, lane);              // (the round trip runs under the barrier)
+        bn[1] = f8_bias(PK.fc_1.bias, wave * 32 + 16, lane);
         FM_SYNCL();
-        // fc_1 pre-activation of view i = vs_i + sum_j vp_j A[j][i] + folded bias; relu; -> operand of fc_2
+        // fc_1 pre-activation of view i = vs_i + sum_j vp_j A[j][i] + folded bias; relu; -> operand of fc_2 (packed FMAs: two
+        // channels per instruction; the probabilities of a sample are 9 consecutive floats: two 16-byte reads and one dword)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            float A[V][V];
-#pragma unroll
-            for (int j = 0; j < V; ++j)
-#pragma unroll
-                for (int i = 0; i < V; ++i) A[j][i] = probs[(j * V + i) * 32 + h * 16 + l15];
+            const float* pr = probs + (h * 16 + l15) * F8_PSTR;
+            const float4 q0 = *reinterpret_cast<const float4*>(pr), q1 = *reinterpret_cast<const float4*>(pr + 4);
+            const float q2 = pr[8];
+            const float A[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2};
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const float bb[4] = {bn[c].x, bn[c].y, bn[c].z, bn[c].w};
-                f8_f4 t[V];
-#pragma unroll
-                for (int i = 0; i < V; ++i)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[i][e] = vs[c][2 * i + h][e] + bb[e];
-#pragma unroll
-                for (int j = 0; j < V; ++j)
-#pragma unroll
-                    for (int i = 0; i < V; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) t[i][e] = fmaf(vp[c][2 * j + h][e], A[j][i], t[i][e]);
+                const f32x2 b01 = {bn[c].x, bn[c].y}, b23 = {bn[c].z, bn[c].w};
+                f32x2 t0[V], t1[V];
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
+                    t0[i] = (f32x2){vs[c][2 * i + h][0], vs[c][2 * i + h][1]} + b01;
+                    t1[i] = (f32x2){vs[c][2 * i + h][2], vs[c][2 * i + h][3]} + b23;
+                }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t[i][e] = fmaxf(t[i][e], 0.f);
-                    f8_store_h<STR256>(t[i], (2 * i + h) * 16 + l15, wave * 32 + c * 16, abuf, a256_lo, lane, rmax);
+                for (int j = 0; j < V; ++j) {
+                    const f32x2 v0 = {vp[c][2 * j + h][0], vp[c][2 * j + h][1]}, v1 = {vp[c][2 * j + h][2], vp[c][2 * j + h][3]};
+#pragma unroll
+                    for (int i = 0; i < V; ++i) {
+                        const f32x2 a2 = {A[j * V + i], A[j * V + i]};
+                        t0[i] = __builtin_elementwise_fma(v0, a2, t0[i]);
+                        t1[i] = __builtin_elementwise_fma(v1, a2, t1[i]);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < V; ++i) {
+                    t0[i] = __builtin_elementwise_max(t0[i], (f32x2){0.f, 0.f});
+                    t1[i] = __builtin_elementwise_max(t1[i], (f32x2){0.f, 0.f});
+                    const f8_f4 n = {t0[i][0], t0[i][1], t1[i][0], t1[i][1]};
+                    f8_store_h<STR256>(n, (2 * i + h) * 16 + l15, wave * 32 + c * 16, abuf, a256_lo, lane, rmax);
                 }
             }
         }
-        range_commit(P.range, TH_RANGE_N, seen_n, rmax);
+        range_commit(PK.range, TH_RANGE_N, seen_n, rmax);
     }
 
     // ================= fc_2 (fc_1 is folded into the value projections) =================
     uint4 wk2[2][2][2];
     FM_SB();
-    f8_load_w<2>(f8_wslice(P.w16.fc_2, wave, 2) + lane, 0, wk2[0]);
+    f8_load_w<2>(F8_WSLICE(PK.w16.fc_2, wave, 2) + lane, 0, wk2[0]);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = tid + F8_THREADS * q, row = i >> 5, c = i & 31;
         int x = pbase + row;
-        if (P.vd_sel != nullptr && P.rgb_all != 2 && c < 27 && row < npts) x = P.vd_sel[pbase + row];
+        if (PK.vd_sel != nullptr && PK.rgb_all != 2 && c < 27 && row < npts) x = PK.vd_sel[pbase + row];
         vsel[q] = x;
     }
     FM_SYNCL();
-    f8_gemm<RT, 2, RS256, true, true>(abuf, a256_lo, STR256, f8_wslice(P.w16.fc_2, wave, 2), 8, lane, acc2, wk2);
-    const float4 bi[2] = {f8_bias(P.fc_2.bias, wave * 32, lane), f8_bias(P.fc_2.bias, wave * 32 + 16, lane)};
+    f8_gemm<RT, 2, RS256, true, true>(abuf, a256_lo, STR256, F8_WSLICE(PK.w16.fc_2, wave, 2), 8, lane, acc2, wk2);
+    const float4 bi[2] = {f8_bias(PK.fc_2.bias, wave * 32, lane), f8_bias(PK.fc_2.bias, wave * 32 + 16, lane)};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = tid + F8_THREADS * q, row = i >> 5, c = i & 31;
         float x = 0.f;
-        if (P.rgb_all != 2 && c < 27 && row < npts) {
-            const long long vr = P.vd_sel ? (long long)(vsel[q] / P.vd_div) : (long long)(pbase + row);
-            x = P.vd[vr * 27 + c];
+        if (PK.rgb_all != 2 && c < 27 && row < npts) {
+            const long long vr = PK.vd_sel ? (long long)(vsel[q] / PK.vd_div) : (long long)(pbase + row);
+            x = PK.vd[vr * 27 + c];
         }
         vdv[q] = x;
     }
@@ -656,7 +690,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int r = 0; r < RT; ++r) acc2[c][r] = f8_finish(acc2[c][r], bi[c], P.fc_2.inv_scale, true);
+        for (int r = 0; r < RT; ++r) acc2[c][r] = f8_finish(acc2[c][r], bi[c], PK.fc_2.inv_scale, true);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f8_f4 m = acc2[c][h];
@@ -668,24 +702,24 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
 #pragma unroll
         for (int r = 0; r < RT; ++r) f8_store_h<STR256>(acc2[c][r], r * 16 + l15, wave * 32 + c * 16, abuf, a256_lo, lane, rmax);
     }
-    range_commit(P.range, TH_RANGE_INTER, seen_i, rmax);
+    range_commit(PK.range, TH_RANGE_INTER, seen_i, rmax);
     FM_SYNCL();
 
     // ================= sigma head: relu(fc_3 m) . alpha_w + b   ||   folded view_fc on inter =================
     char* vd_hi = mbuf + MBUF_VD_OFF;
     char* vd_lo = vd_hi + 32 * STRVD;
-    if (P.rgb_all != 2) tex_pre2 = tex_fetch();          // (for the RGB branch's filling: the round trip runs under fc_3)
+    tex_pre2 = tex_fetch();                              // (for the RGB branch's filling: the round trip runs under fc_3)
     f8_f4 va[1][RT];                                     // this wave's 16 of the 128 view_fc outputs, all rows
     {
         f8_f4 a3[2][2];
-        const float4 aw[2] = {f8_bias(P.alpha_w, wave * 32, lane), f8_bias(P.alpha_w, wave * 32 + 16, lane)};
-        const float4 b3[2] = {f8_bias(P.fc_3.bias, wave * 32, lane), f8_bias(P.fc_3.bias, wave * 32 + 16, lane)};
-        if (P.rgb_all != 2) {
+        const float4 aw[2] = {f8_bias(PK.alpha_w, wave * 32, lane), f8_bias(PK.alpha_w, wave * 32 + 16, lane)};
+        const float4 b3[2] = {f8_bias(PK.fc_3.bias, wave * 32, lane), f8_bias(PK.fc_3.bias, wave * 32 + 16, lane)};
+        if (PK.rgb_all != 2) {
             // fc_3 on the 32 mean rows (MBUF) and the folded view_fc on the 32 V rows of inter (ABUF) in ONE loop (see
             // gemm_dual_fc3_vfa): halves A = {mean rows 0-15, inter row tiles 0 .. V-1}, B = {mean rows 16-31, the other V}
             constexpr int T = 8;
-            const uint4* w3l = f8_wslice(P.w16.fc_3, wave, 2) + lane;
-            const uint4* wal = f8_wslice(P.w16.vfA, wave, 1) + lane;
+            const uint4* w3l = F8_WSLICE(PK.w16.fc_3, wave, 2) + lane;
+            const uint4* wal = F8_WSLICE(PK.w16.vfA, wave, 1) + lane;
             const int aoff = f8_aoff<true>(lane, STR256);
             const char* mhi = mbuf;
             const char* mlo = mbuf + 32 * STR256;
@@ -722,8 +756,10 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
                 step(std::false_type{}, std::integral_constant<int, 1>{}, t + 1);
             }
         } else {
+#pragma unroll
+            for (int r = 0; r < RT; ++r) va[0][r] = (f8_f4){0.f, 0.f, 0.f, 0.f};      // (never read on this path)
             uint4 w3[2][2][2];
-            f8_gemm<2, 2, RS256, true, false>(mbuf, mbuf + 32 * STR256, STR256, f8_wslice(P.w16.fc_3, wave, 2), 8, lane, a3, w3);
+            f8_gemm<2, 2, RS256, true, false>(mbuf, mbuf + 32 * STR256, STR256, F8_WSLICE(PK.w16.fc_3, wave, 2), 8, lane, a3, w3);
         }
         float s2[2];
 #pragma unroll
@@ -731,14 +767,14 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
-                const f8_f4 y = f8_finish(a3[c][h], b3[c], P.fc_3.inv_scale, true);
+                const f8_f4 y = f8_finish(a3[c][h], b3[c], PK.fc_3.inv_scale, true);
                 s = fmaf(y[0], aw[c].x, s);
                 s = fmaf(y[1], aw[c].y, s);
                 s = fmaf(y[2], aw[c].z, s);
                 s = fmaf(y[3], aw[c].w, s);
             }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
+            s += f8_xor(s, lane, 16);
+            s += f8_xor(s, lane, 32);
             s2[h] = s;
         }
         // (every lane group holds both sums: group 0 stores the first half's samples, group 1 the second half's -- two predicated
@@ -748,11 +784,11 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         if (tid == 0) *flag = 0;
         FM_SYNCL();                                  // every wave is done reading the means (MBUF) and inter (ABUF)
         if (tid < 32) {
-            float sg = P.alpha_b[0];
+            float sg = PK.alpha_b[zoff];
 #pragma unroll
             for (int w = 0; w < 8; ++w) sg += part[w * 32 + tid];
             sig[tid] = sg;
-            if (tid < npts && P.rgb_all != 2 && (P.rgb_all == 1 || sg > 0.f)) *flag = 1;
+            if (tid < npts && PK.rgb_all != 2 && (PK.rgb_all == 1 || sg > 0.f)) *flag = 1;
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -771,7 +807,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         //   t = relu((Wa F) inter + Wd viewdir + blend(fold12[:, :128]) + b') ; u = t + blend(fold12[:, 128:]) + b_R1 ; mean over views ;
         //   fc_4 ; rgb_fc
         uint4 wvd[1][2];
-        f8_load_w<1>(f8_wslice(P.w16.vfD, wave, 1) + lane, 0, wvd);
+        f8_load_w<1>(F8_WSLICE(PK.w16.vfD, wave, 1) + lane, 0, wvd);
         FM_SB();
         fill_tex(tex_pre2, std::true_type{}, [&]() __attribute__((always_inline)) {
             h8 xh[2], xl[2];
@@ -787,15 +823,15 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         // fc_4 weights (4 k-steps) and the rgb_fc rows of this wave's channels: requested before the epilogue
         uint4 w4[4][1][2];
         {
-            const uint4* wl4 = f8_wslice(P.w16.fc_4, wave, 1) + lane;
+            const uint4* wl4 = F8_WSLICE(PK.w16.fc_4, wave, 1) + lane;
 #pragma unroll
             for (int t = 0; t < 4; ++t) f8_load_w<1>(wl4, t, w4[t]);
         }
         float4 rw[3];
 #pragma unroll
-        for (int o = 0; o < 3; ++o) rw[o] = f8_bias(P.rgb_w + o * 128, wave * 16, lane);
-        const float4 b4 = f8_bias(P.fc_4.bias, wave * 16, lane);
-        const float4 bt = f8_bias(P.rst.bias, wave * 16, lane), br = f8_bias(P.rst.bias, 128 + wave * 16, lane);
+        for (int o = 0; o < 3; ++o) rw[o] = f8_bias(PK.rgb_w + o * 128, wave * 16, lane);
+        const float4 b4 = f8_bias(PK.fc_4.bias, wave * 16, lane);
+        const float4 bt = f8_bias(PK.rst.bias, wave * 16, lane), br = f8_bias(PK.rst.bias, 128 + wave * 16, lane);
         char* f4_hi = mbuf + MBUF_FC4_OFF;
         char* f4_lo = f4_hi + 32 * STR128;
         {
@@ -805,11 +841,11 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
             for (int r = 0; r < RT; ++r) {
                 const float4 m1 = *reinterpret_cast<const float4*>(mb + r * 16 * 1040);
                 const float4 m2 = *reinterpret_cast<const float4*>(mb + r * 16 * 1040 + 512);
-                const f8_f4 t = f8_finish(va[0][r], bt, P.rst.inv_scale, false);
-                u[r][0] = fmaxf(t[0] + m1.x, 0.f) + (m2.x + br.x);
-                u[r][1] = fmaxf(t[1] + m1.y, 0.f) + (m2.y + br.y);
-                u[r][2] = fmaxf(t[2] + m1.z, 0.f) + (m2.z + br.z);
-                u[r][3] = fmaxf(t[3] + m1.w, 0.f) + (m2.w + br.w);
+                const f8_f4 t = f8_finish(va[0][r], bt, PK.rst.inv_scale, false);
+                const f32x2 z2 = {0.f, 0.f};
+                const f32x2 u01 = __builtin_elementwise_max((f32x2){t[0], t[1]} + (f32x2){m1.x, m1.y}, z2) + ((f32x2){m2.x, m2.y} + (f32x2){br.x, br.y});
+                const f32x2 u23 = __builtin_elementwise_max((f32x2){t[2], t[3]} + (f32x2){m1.z, m1.w}, z2) + ((f32x2){m2.z, m2.w} + (f32x2){br.z, br.w});
+                u[r] = (f8_f4){u01[0], u01[1], u23[0], u23[1]};
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -819,7 +855,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
                 m = m * (f8_f4){inv_v, inv_v, inv_v, inv_v};
                 f8_store_h<STR128, false>(m, h * 16 + l15, wave * 16, f4_hi, f4_lo, lane, rmax);      // (signed: relu(.) + rgb_res_1)
             }
-            range_commit(P.range, TH_RANGE_F4, seen_4, rmax);
+            range_commit(PK.range, TH_RANGE_F4, seen_4, rmax);
         }
         FM_SYNCL();
         f8_f4 a4[1][2];
@@ -836,7 +872,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         float s3[3][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const f8_f4 y = f8_finish(a4[0][h], b4, P.fc_4.inv_scale, true);
+            const f8_f4 y = f8_finish(a4[0][h], b4, PK.fc_4.inv_scale, true);
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
                 float s = 0.f;
@@ -844,8 +880,8 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
                 s = fmaf(y[1], rw[o].y, s);
                 s = fmaf(y[2], rw[o].z, s);
                 s = fmaf(y[3], rw[o].w, s);
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
+                s += f8_xor(s, lane, 16);
+                s += f8_xor(s, lane, 32);
                 s3[o][h] = s;
             }
         }
@@ -858,7 +894,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         if (tid < 32) {
 #pragma unroll
             for (int o = 0; o < 3; ++o) {
-                float s = P.rgb_b[o];
+                float s = PK.rgb_b[zoff + o];
 #pragma unroll
                 for (int w = 0; w < 8; ++w) s += part[(o * 8 + w) * 32 + tid];
                 rgb_out[o] = s;
@@ -866,5 +902,6 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         }
     }
     if (tid < npts)
-        *reinterpret_cast<float4*>(P.raw_c + (long long)(pbase + tid) * 4) = make_float4(rgb_out[0], rgb_out[1], rgb_out[2], sig[tid]);
+        *reinterpret_cast<float4*>(PK.raw_c + (long long)(pbase + tid) * 4) = make_float4(rgb_out[0], rgb_out[1], rgb_out[2], sig[tid]);
+#undef PK
 }

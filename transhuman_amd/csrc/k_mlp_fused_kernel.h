@@ -46,12 +46,14 @@ typedef unsigned fm_u4 __attribute__((ext_vector_type(4)));
 #define FM_SYNC_(BARRIER)                                                                                 \
     do {                                                                                                 \
         BARRIER;                                                                                         \
-        if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {                                    \
+        if (FM_DBG_SAMPLED) {                                                                            \
             long long now_ = clock64();                                                                  \
             atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + dbg_i++), (unsigned long long)(now_ - dbg_t)); \
             dbg_t = now_;                                                                                \
         }                                                                                                \
     } while (0)
+// which workgroups are sampled: a variable `fm_dbg_tile` of the enclosing kernel (its tile number)
+#define FM_DBG_SAMPLED (P.dbg != nullptr && tid == 0 && (fm_dbg_tile & 15) == 0)
 // full barrier (waits for every outstanding memory operation: needed behind LDS-DMA staging, whose LDS writes are
 // tracked by vmcnt)
 #define FM_SYNC() FM_SYNC_(__syncthreads())
@@ -68,7 +70,7 @@ typedef unsigned fm_u4 __attribute__((ext_vector_type(4)));
 // cycle stamp without a barrier (same accounting as FM_SYNC: wave 0 of every 16th tile)
 #define FM_STAMP()                                                                                       \
     do {                                                                                                 \
-        if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {                                    \
+        if (FM_DBG_SAMPLED) {                                                                            \
             long long now_ = clock64();                                                                  \
             atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + dbg_i++), (unsigned long long)(now_ - dbg_t)); \
             dbg_t = now_;                                                                                \
@@ -586,6 +588,7 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     const int myrow = lane & 31;
     int dbg_i = 1;                      // dbg[0] counts sampled tiles, dbg[i] accumulates the cycles of interval i
     long long dbg_t = 0;
+    const int fm_dbg_tile = (int)blockIdx.x;
     if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg), 1ull);
         dbg_t = clock64();
