@@ -200,7 +200,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     constexpr int ROWS = 32 * V, RT = 2 * V;
     constexpr int RS256 = 16 * STR256;           // bytes between row tiles of a K = 256 plane
     int dbg_i = 1;
-    long long dbg_t = 0;
+    long long dbg_t = 0, dbg_w = 0, dbg_t0 = 0;
     constexpr float inv_v = 1.0f / (float)V;
     unsigned rmax = 0u;
     unsigned seen_s = 0u, seen_p = 0u, seen_n = 0u, seen_i = 0u, seen_4 = 0u;
@@ -378,6 +378,8 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     if (PK.dbg != nullptr && tid == 0 && (tile & 15) == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(PK.dbg), 1ull);
         dbg_t = clock64();
+        dbg_t0 = dbg_t;
+        dbg_w = wall_clock64();
     }
     // range guard: launch-wide maxima as they stand when this tile starts (scalar loads through the constant address space: the
     // table is only a hint here -- a stale smaller value costs an atomic, never a result)
@@ -903,5 +905,9 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     }
     if (tid < npts)
         *reinterpret_cast<float4*>(PK.raw_c + (long long)(pbase + tid) * 4) = make_float4(rgb_out[0], rgb_out[1], rgb_out[2], sig[tid]);
+    if (FM_DBG_SAMPLED) {        // dbg[62] / dbg[63]: shader cycles and 100 MHz ticks of the sampled tiles, first stamp to here: the clock INSIDE the launch
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + 62), (unsigned long long)(clock64() - dbg_t0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + 63), (unsigned long long)(wall_clock64() - dbg_w));
+    }
 #undef PK
 }

@@ -492,10 +492,15 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     static long long* dbg_dev = nullptr;
     p.dbg = nullptr;
     const bool dbg_now = dbg_state == 1 && P >= 4096;
+    hipEvent_t dbg_e0 = nullptr, dbg_e1 = nullptr;
     if (dbg_now) {
         if (!dbg_dev) TH_HIP(hipMalloc((void**)&dbg_dev, 64 * sizeof(long long)));
         TH_HIP(hipMemsetAsync(dbg_dev, 0, 64 * sizeof(long long), s));
         p.dbg = dbg_dev;
+        TH_HIP(hipEventCreate(&dbg_e0));
+        TH_HIP(hipEventCreate(&dbg_e1));
+        TH_HIP(hipStreamSynchronize(s));                   // (the launch is timed alone on its stream)
+        TH_HIP(hipEventRecord(dbg_e0, s));
     }
 #define FM_LAUNCH(V_, F_) hipLaunchKernelGGL((mlp_fused_kernel<V_, F_>), grid, dim3(256), FUSED_LDS_BYTES, s, p)
 #define FM_LAUNCH_T(V_) hipLaunchKernelGGL((mlp_fused_kernel<V_, 1, true>), grid, dim3(256), FUSED_LDS_BYTES, s, p)
@@ -559,15 +564,23 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     TH_LAUNCH_CHECK();
     if (dbg_now) {
         long long st[64];
+        TH_HIP(hipEventRecord(dbg_e1, s));
         TH_HIP(hipStreamSynchronize(s));
+        float dbg_ms = 0.f;
+        TH_HIP(hipEventElapsedTime(&dbg_ms, dbg_e0, dbg_e1));
+        fprintf(stderr, "[TH_FUSED_DBG] launch %.3f ms (events), %d tiles\n", dbg_ms, grid.x);
         TH_HIP(hipMemcpy(st, dbg_dev, sizeof(st), hipMemcpyDeviceToHost));
         fprintf(stderr, "[TH_FUSED_DBG] %lld tiles sampled of %d, average cycles between barriers:", st[0], grid.x);
         long long tot = 0;
-        for (int i = 1; i < 64 && st[i] != 0; ++i) {
+        for (int i = 1; i < 62 && st[i] != 0; ++i) {
             fprintf(stderr, " %lld", st[i] / (st[0] > 0 ? st[0] : 1));
             tot += st[i] / (st[0] > 0 ? st[0] : 1);
         }
-        fprintf(stderr, "  | total %lld\n", tot);
+        fprintf(stderr, "  | total %lld", tot);
+        if (st[63] > 0)      // whole sampled tiles: shader cycles per 100 MHz tick = the shader clock the chip ran at INSIDE this launch
+            fprintf(stderr, "  | %.1f us per tile at %.3f GHz inside the launch", (double)st[63] / (double)(st[0] > 0 ? st[0] : 1) * 0.01,
+                    (double)st[62] / ((double)st[63] * 10.0));
+        fprintf(stderr, "\n");
         dbg_state = 2;
     }
     return 0;

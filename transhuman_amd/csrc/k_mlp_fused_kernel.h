@@ -587,11 +587,13 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     constexpr int ROWS = 32 * V;
     const int myrow = lane & 31;
     int dbg_i = 1;                      // dbg[0] counts sampled tiles, dbg[i] accumulates the cycles of interval i
-    long long dbg_t = 0;
+    long long dbg_t = 0, dbg_w = 0, dbg_t0 = 0;
     const int fm_dbg_tile = (int)blockIdx.x;
     if (P.dbg != nullptr && tid == 0 && (blockIdx.x & 15) == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg), 1ull);
         dbg_t = clock64();
+        dbg_t0 = dbg_t;
+        dbg_w = wall_clock64();
     }
 
     // view means multiply by 1/V (one rounding away from torch.mean's division; 10 VALU instructions less per value)
@@ -1491,6 +1493,10 @@ __global__ __launch_bounds__(256, 1) FM_VGPR_ATTR void mlp_fused_kernel(FusedPar
     if (tid < npts)
         *reinterpret_cast<float4*>(P.raw_c + (long long)(pbase + tid) * 4) =
             make_float4(rgb_out[0], rgb_out[1], rgb_out[2], sig[tid]);
+    if (FM_DBG_SAMPLED) {        // dbg[62] / dbg[63]: shader cycles and 100 MHz ticks of the sampled tiles: the clock INSIDE the launch
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + 62), (unsigned long long)(clock64() - dbg_t0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + 63), (unsigned long long)(wall_clock64() - dbg_w));
+    }
 }
 
 // ---- the f-consuming layers applied to the MAP (TH_ROWS_TEX, late round 4) ------------------------------------------------------

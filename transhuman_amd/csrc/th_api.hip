@@ -89,8 +89,8 @@ int th_ctx_create(int device, th_ctx** out) {
     c->n_cu = prop.multiProcessorCount;
     if (const char* e = getenv("TH_TOK_GATHER")) c->tok_gather = e[0] == '0' ? 0 : 1;
     if (const char* e = getenv("TH_ROWS_TEX")) c->tex_rows = e[0] == '0' ? 0 : 1;
-    c->fused.waves = 4;                                      // (8 once validated: see th_set_fused_waves)
-    if (const char* e = getenv("TH_FUSED_WAVES")) c->fused.waves = e[0] == '8' ? 8 : 4;
+    c->fused.waves = 8;                                      // (th_set_fused_waves)
+    if (const char* e = getenv("TH_FUSED_WAVES")) c->fused.waves = e[0] == '4' ? 4 : 8;
     TH_HIP(hipHostMalloc((void**)&c->host_pinned, 64 * sizeof(int32_t), hipHostMallocDefault));
     TH_HIP(hipMalloc((void**)&c->range_dev, TH_RANGE_SLOTS * sizeof(unsigned int)));
     TH_HIP(hipMemset(c->range_dev, 0, TH_RANGE_SLOTS * sizeof(unsigned int)));
