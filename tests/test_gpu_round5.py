@@ -74,7 +74,7 @@ def test_headline_frame_every_ray_against_the_oracle(hip, gpu):
     # the HIP path is not further from the exact result than the reference's fp32 arithmetic is (99.99th percentiles)
     assert float(d64.kthvalue(k)[0]) <= float(n64.kthvalue(k)[0]) + 1e-5
     bad = torch.nonzero((d32 > BAR) | (d64 > BAR)).reshape(-1).numpy()
-    assert len(bad) <= 32, len(bad)
+    assert len(bad) <= 8, len(bad)            # (observed: 3 - 5 rays of 262 144, rounds 5 and 6; the reference's own fp32 has 7 against the exact value)
     for rec in D.flips(bc, sd, assign, gpu, bad, img, o32, t64):
         tie = rec["min_gap_7th_8th_neighbour_over_valid_samples"] is not None and rec["min_gap_7th_8th_neighbour_over_valid_samples"] < 1e-6
         flip = len(rec["samples_sign_flip_o32_t64"]) > 0 or len(rec["samples_with_abs_sigma_raw_below_1e-4"]) > 0

@@ -67,6 +67,54 @@ def oracle_frame(bc, sd, assign, dev, dtype, block=8192, pick=None, samples=64):
     return out
 
 
+def oracle_sigma_points(bc, sd, assign, pts, dev, dtype, block=65536):
+    """sigma_raw of the oracle on `dev` in `dtype` at the points `pts` [N, 3] (all taken as inside the hull): the per-point part of
+    if_mesh_renderer.Renderer.render :46-100 (oracle.render_sigma_grid without its host-side mask / zero view directions)"""
+    off, mem = csr(assign)
+    b, s = to_dev(bc, dev), to_dev(sd, dev)
+    if dtype != torch.float32:
+        b, s = O.widen(b, dtype), O.widen(s, dtype)
+    cc = can_centres64(assign).to(dev)
+    pts = pts.to(dev).to(dtype)
+    out = torch.zeros(pts.shape[0], dtype=torch.float64)
+    with torch.no_grad():
+        hol, pix = O.encoder_forward(s, b["input_imgs"][0][0])
+        fc = O.frame_constants(s, b, hol, off, mem, cc, 12)
+        ps = O.world2smpl(pts, b["Rh"][0], b["Th"][0])
+        for a in range(0, pts.shape[0], block):
+            x = pts[a:a + block]
+            pf = O.pixel_aligned(pix, x, b)
+            vd = torch.zeros((x.shape[0], 27), device=dev, dtype=dtype)
+            m = torch.ones(x.shape[0], dtype=torch.bool, device=dev)
+            raw = O.network_forward(s, pf, vd, ps[a:a + block], fc["centres"], fc["blend"], fc["tokens"], m)
+            out[a:a + block] = raw[:, 3].double().cpu()
+    return out
+
+
+def tail_report(r, bc, sd, assign, dev, host_rays=768, host64_every=4, seed=5, hits_only=True):
+    """One frame three ways (HIP path through Renderer.render_fast, oracle fp32 and float64 on the device, tied to the host oracle on a
+    subset): the distances over ALL rays.  Returns a dict of tensors / numbers; the caller asserts."""
+    o = r.render_fast(synth.batch_to(bc, dev), is_train=False)
+    img = torch.cat([o["rgb_map"][0], o["acc_map"][0][:, None]], dim=1).double().cpu()
+    stats = dict(r.last_stats)
+    hip.drop_workspaces(dev)
+    torch.cuda.empty_cache()
+    t64 = oracle_frame(bc, sd, assign, dev, torch.float64)
+    o32 = oracle_frame(bc, sd, assign, dev, torch.float32)
+    rs = np.random.RandomState(seed)
+    hits = torch.nonzero(img[:, 3] > 0).reshape(-1).numpy()
+    pool = hits if hits_only else np.arange(img.shape[0])
+    pick = np.sort(rs.choice(pool, min(host_rays, len(pool)), replace=False))
+    c32 = oracle_frame(bc, sd, assign, torch.device("cpu"), torch.float32, pick=pick)
+    c64 = oracle_frame(bc, sd, assign, torch.device("cpu"), torch.float64, pick=pick[::host64_every])
+    d32, d64, n64 = dist(img, o32), dist(img, t64), dist(o32, t64)
+    k = int(round(d32.numel() * 0.9999))
+    return {"img": img, "o32": o32, "t64": t64, "stats": stats, "pick": pick,
+            "tie64": float(dist(t64[pick[::host64_every]], c64).max()), "g_host": dist(img[pick], c32),
+            "d32": d32, "d64": d64, "n64": n64, "p9999": {"d32": float(d32.kthvalue(k)[0]), "d64": float(d64.kthvalue(k)[0]),
+                                                          "n64": float(n64.kthvalue(k)[0])}}
+
+
 def flips(bc, sd, assign, dev, rays, gpu, o32, t64, samples=64):
     off, mem = csr(assign)
     out = []
