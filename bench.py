@@ -95,7 +95,10 @@ def roofline_block(mlp_mode, achieved, flops_step, stage_ms, launches, executed_
     if mlp_mode == 1:
         peak = MFMA_F16_PEAK / 3.0
         from transhuman_amd import hip as _hip
-        kernel = ("mlp_fused_kernel<3,1,true> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16; TH_ROWS_TEX: alpha_res_0 / rgb_res_0 / "
+        k8 = _hip.fused_waves() == 8
+        kernel = (("mlp_fused8_kernel<3> (8 waves per workgroup, two per SIMD; fp16 hi/lo split x3 on v_mfma_f32_16x16x32_f16" if k8 else
+                   "mlp_fused_kernel<3,1,true> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16") +
+                  "; TH_ROWS_TEX: alpha_res_0 / rgb_res_0 / "
                   "rgb_res_1 are applied to the map's texels once per frame (map_fold_kernel) and the kernel blends texel rows of "
                   "the folded maps: the ALGORITHMIC FLOPs still count those layers per sample), rank 0" if _hip.tex_rows_enabled() else
                   "mlp_fused_kernel<3,1> (fp16 hi/lo split x3 on v_mfma_f32_32x32x16_f16), rank 0")
@@ -556,6 +559,18 @@ def main():
     shard = dict(batch)
     for k in ("ray_o", "ray_d", "near", "far"):
         shard[k] = batch[k][:, my_idx].contiguous()
+    # The timed loop alternates TWO synthetic frames (seed 0 / seed 1: another pose, other reference images) so that nothing a
+    # frame leaves behind -- caches, graph-ring instances, demand lists -- can be credited to identical inputs.
+    # TH_BENCH_ONE_FRAME=1: the single repeated frame of rounds 1-5.
+    frames = [shard]
+    batches = [batch]
+    if args.workload in ("real", "dense") and os.environ.get("TH_BENCH_ONE_FRAME") != "1":
+        batch_b = synth.batch_to(synth.make_batch(H, W, V, seed=1, all_rays=True, dense=(args.workload == "dense")), dev)
+        shard_b = dict(batch_b)
+        for k in ("ray_o", "ray_d", "near", "far"):
+            shard_b[k] = batch_b[k][:, my_idx].contiguous()
+        frames.append(shard_b)
+        batches.append(batch_b)
 
     if args.workload in ("orbit", "mesh"):
         return run_secondary(args, world, rank, dev, dist_on, renderer, net, batch, batch_cpu, H, W, V)
@@ -575,7 +590,7 @@ def main():
     stem_x = None
     if (dist_on or emu) and StemExchange.wanted(emu or world):
         stem_x = StemExchange() if dist_on else StemExchange(emulate=(emu, args.emulate_rank))
-    seq = None if args.no_pipeline else renderer.render_sequence(itertools.repeat(shard),
+    seq = None if args.no_pipeline else renderer.render_sequence(itertools.cycle(frames),
                                                                   small_frame_rays=-1 if sharded else 2400,
                                                                   token_exchange=tokens_x, stem_exchange=stem_x)
 
@@ -587,12 +602,18 @@ def main():
     whole_frame_hits = DeferredSum(dev) if dist_on else None
     dist_wait = [0.0]
 
+    step_no = [0]
+    stats_of = {}
+
     def step():
         # per frame: ray-only stage (hull mask, compaction) -> [per-frame constants] -> shading + compositing.
+        shard = frames[step_no[0] % len(frames)]
+        step_no[0] += 1
         if seq is not None:
             out = next(seq)
         else:
             out = renderer.render_fast(shard, small_frame_rays=-1 if sharded else 2400)
+        stats_of[(step_no[0] - 1) % len(frames)] = dict(renderer.last_stats)
         if dist_on:
             whole_frame_hits.start(renderer.last_stats["hit_rays"])
         local = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
@@ -655,11 +676,39 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
 
-    # algorithmic work of the dominant stage on this rank (counts from the rendered frame itself)
-    n_valid = stats["valid_samples"]
-    pts = hip.Points(shard["ray_o"][0], shard["ray_d"][0], shard["near"][0], shard["far"][0], args.samples)
-    frame = renderer.prepare_frame(batch)
-    n_pos = count_sigma_positive(hip, net, frame, pts) if stats["unmasked"] == 0 else n_valid
+    # algorithmic work of the dominant stage on this rank (counts from the rendered frames themselves: the mean over the
+    # alternating frames)
+    per_frame = []
+    for k, sh in enumerate(frames):
+        st_k = stats_of.get(k, stats)
+        pts = hip.Points(sh["ray_o"][0], sh["ray_d"][0], sh["near"][0], sh["far"][0], args.samples)
+        frame = renderer.prepare_frame(batches[k])
+        nv_k = st_k["valid_samples"]
+        per_frame.append({"hit_rays": int(st_k["hit_rays"]), "valid_samples": int(nv_k),
+                          "sigma_pos_samples": int(count_sigma_positive(hip, net, frame, pts) if st_k["unmasked"] == 0 else nv_k)})
+    n_valid = int(round(sum(f["valid_samples"] for f in per_frame) / len(per_frame)))
+    n_pos = int(round(sum(f["sigma_pos_samples"] for f in per_frame) / len(per_frame)))
+    # the fused kernel from inside (th_fused_cycles): cycles per phase and per tile, and the shader clock UNDER the kernel, over
+    # one un-pipelined frame of each kind after the timed region
+    fused_inside = None
+    if args.mlp_mode == 1 and world == 1 and os.environ.get("TH_NO_PROF") != "1":
+        cnt = torch.zeros(64, dtype=torch.int64, device=dev)
+        hip.fused_cycles(cnt)
+        try:
+            for sh in frames:
+                renderer.render_fast(sh, small_frame_rays=-1 if sharded else 2400)
+            torch.cuda.synchronize()
+        finally:
+            hip.fused_cycles(None)
+        cc = cnt.cpu().numpy().astype(np.float64)
+        if cc[0] > 0 and cc[63] > 0:
+            fused_inside = {"sampled_tiles": int(cc[0]), "cycles_per_tile": cc[62] / cc[0], "us_per_tile": cc[63] / cc[0] * 0.01,
+                            "clock_GHz_inside_the_launch": cc[62] / (cc[63] * 10.0),
+                            "cycles_between_barriers": [round(x / cc[0]) for x in cc[1:62] if x > 0],
+                            "mfma_cycles_per_tile_and_simd": 49600.0 if hip.fused_waves(dev) == 8 else 47800.0,
+                            "waves_per_workgroup": hip.fused_waves(dev),
+                            "note": "thread 0 of every 16th tile, one frame of each kind through render_fast after the timed region; "
+                                    "mfma cycles = the tile's MFMA instructions x their issue interval on one SIMD (2 988 x 16.6 / 1 494 x 32)"}
     mlp_ms, mlp_launches = prof["mlp"]
     flops_step = algorithmic_mlp_flops(V, n_valid, n_pos)
     mlp_s_per_step = mlp_ms * 1e-3 / max(args.steps, 1)
@@ -679,7 +728,7 @@ def main():
             "ms_per_step_max": float(step_ms.max()),
             # rays/s depends on the synthetic frame's hit rate (19.5 % of the rays hit the hull here); shaded samples/s does not --
             # the all-valid S_dense_full frame of `extra` runs at the same samples/s and 1/8 of the rays/s
-            "valid_samples_per_s_rank0": float(stats["valid_samples"]) * args.steps / dt,
+            "valid_samples_per_s_rank0": float(n_valid) * args.steps / dt,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -690,6 +739,7 @@ def main():
                             f"samples/ray, V={V} reference views, kmeans N_c={args.nc}, ViT depth 12 "
                             f"(BASELINE.json configs[1] analogue); step = encoder + paint/group + TransHE + "
                             f"hull mask + DPaRF + pixel gather + MLP + compositing",
+                "frames_alternating": per_frame,
                 "rays": R, "hit_rays_rank0": stats["hit_rays"], "valid_samples_rank0": n_valid,
                 "sigma_pos_samples_rank0": n_pos, "parallelism": f"ray-tile x{world}" if world > 1 else "single",
                 "frame_pipeline": "off" if seq is None else "constants(i+1) on a 2nd HIP stream under shading(i)",
@@ -718,6 +768,17 @@ def main():
                           "other stages (their spans are stretched by the overlap and do not add to the frame time); vit = 0: "
                           "TransHE is a replayed hipGraph in the frame paths, its launches carry no stage events",
         }
+        if fused_inside is not None:
+            # the roofline priced at the clock the chip holds under the kernel (the peaks above assume 2.4 GHz)
+            g = fused_inside["clock_GHz_inside_the_launch"]
+            rf = res["roofline"]
+            rf["clock_GHz_inside_the_launch"] = g
+            rf["peak_at_launch_clock"] = rf["peak"] * g / 2.4
+            rf["frac_at_launch_clock"] = rf["frac"] * 2.4 / g
+            if rf.get("frac_executed") is not None:
+                rf["frac_executed_at_launch_clock"] = rf["frac_executed"] * 2.4 / g
+            fused_inside["mfma_busy_by_cycles"] = fused_inside["mfma_cycles_per_tile_and_simd"] / fused_inside["cycles_per_tile"]
+            res["fused_kernel_inside"] = fused_inside
         res["peak_device_GiB"] = {"headline_allocated": torch.cuda.max_memory_allocated(dev) / 2**30,
                                   "headline_reserved": torch.cuda.max_memory_reserved(dev) / 2**30}
         if emu:

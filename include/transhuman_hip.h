@@ -65,6 +65,13 @@ int th_host_wait_read(th_ctx* ctx, double* ms_out);
  * the dominant kernel of every timed step and reports the median: the frequency the chip sustains under the load
  * the roofline is priced at. */
 int th_clock_probe(th_ctx* ctx, int64_t* out_dev /* [3] */, th_stream stream);
+/* Cycle accounting of the fused MLP kernel (K6) from INSIDE its launches: `counters_dev` = 64 zeroed int64 words of device
+ * memory (NULL switches it off).  While set, thread 0 of every 16th tile adds: [0] sampled tiles, [1..61] shader cycles
+ * between consecutive workgroup barriers (the tile's phases, in order), [62] shader cycles and [63] ticks of the constant
+ * 100 MHz counter over the whole tile -- [62] / (10 [63]) is the shader clock in GHz the chip ran at UNDER this kernel (the
+ * probe above runs on whatever CU has room: beside the kernel, not inside it).  Costs ~0.5 % of the launch; bench.py uses it
+ * for a short post-run measurement. */
+int th_fused_cycles(th_ctx* ctx, int64_t* counters_dev);
 
 /* ---- weights ----------------------------------------------------------- */
 /* One dense layer: weight row-major [out_f][in_f] (a Conv1d(k=1)/Linear

@@ -490,8 +490,8 @@ int th_mlp_fused_forward(const FusedParams& base, const ThMlpPacked& heads, int 
     // developer aid: TH_FUSED_DBG=1 -> average cycles between barriers over every 16th tile (first big launch only)
     static int dbg_state = getenv("TH_FUSED_DBG") ? 1 : 0;
     static long long* dbg_dev = nullptr;
-    p.dbg = nullptr;
-    const bool dbg_now = dbg_state == 1 && P >= 4096;
+    p.dbg = base.cycles_buf;                     // (th_fused_cycles: the caller's counters, every launch)
+    const bool dbg_now = dbg_state == 1 && P >= 4096 && base.cycles_buf == nullptr;
     hipEvent_t dbg_e0 = nullptr, dbg_e1 = nullptr;
     if (dbg_now) {
         if (!dbg_dev) TH_HIP(hipMalloc((void**)&dbg_dev, 64 * sizeof(long long)));

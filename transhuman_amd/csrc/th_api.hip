@@ -144,6 +144,12 @@ int th_clock_probe(th_ctx* c, int64_t* out_dev, th_stream stream) {
     return 0;
 }
 
+int th_fused_cycles(th_ctx* c, int64_t* counters_dev) {
+    TH_REQUIRE(c, "null ctx");
+    c->fused.cycles_buf = (long long*)counters_dev;
+    return 0;
+}
+
 int th_host_wait_read(th_ctx* c, double* ms_out) {
     TH_REQUIRE(c && ms_out, "null argument");
     *ms_out = c->host_wait_ms;

@@ -285,7 +285,8 @@ struct FusedParams {
     int P;
     int rgb_all;        // 0: RGB where sigma > 0, 1: everywhere, 2: nowhere (sigma-only consumers)
     unsigned int* range;   // [TH_RANGE_SLOTS] launch-wide max |hi half| (fp16 bits) per split activation, or nullptr
-    long long* dbg;     // optional cycle stamps (TH_FUSED_DBG)
+    long long* dbg;     // optional cycle stamps (TH_FUSED_DBG, th_fused_cycles)
+    long long* cycles_buf;  // th_fused_cycles: the caller's counters (nullptr: off)
 };
 // range-guard table slots (th_range_read): the tensors that pass through the fp16 hi/lo split
 enum { TH_RANGE_F = 0, TH_RANGE_S = 1, TH_RANGE_P = 2, TH_RANGE_N = 3, TH_RANGE_INTER = 4, TH_RANGE_F4 = 5, TH_RANGE_CONV = 6,

@@ -65,6 +65,7 @@ SYMBOLS = {
     "th_ctx_destroy": (None, [C.c_void_p]),
     "th_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "th_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "th_fused_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_host_wait_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "th_clock_probe": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "th_set_mlp_weights": (C.c_int, [C.c_void_p, C.POINTER(ThMlpWeights), C.c_void_p]),
@@ -1475,10 +1476,19 @@ def set_mlp_mode(mode, device=None):
     _range_fallback.pop(d, None)
 
 
+_fused_waves = {}
+
+
 def set_fused_waves(waves, device=None):
     """Form of the fused MLP kernel on the frame-level path: 8 = two waves per SIMD (512-thread workgroups, default), 4 = the
     256-thread form of rounds 2-5."""
     _check(load_library().th_set_fused_waves(ctx(device), int(waves)))
+    _fused_waves[_dev_index(device)] = int(waves)
+
+
+def fused_waves(device=None):
+    """what set_fused_waves last chose on this device (default: TH_FUSED_WAVES, else 8)"""
+    return _fused_waves.get(_dev_index(device), 4 if os.environ.get("TH_FUSED_WAVES", "8")[:1] == "4" else 8)
 
 
 def set_chunk_samples(n):
@@ -1506,6 +1516,15 @@ def clock_probe(out):
     (ticks, 10 ns units, scratch).  GHz = out[0] / (10 * out[1]) once the stream has passed it."""
     assert out.dtype == torch.int64 and out.numel() >= 3 and out.is_cuda
     _check(load_library().th_clock_probe(ctx(out.device), _p(out), _stream()))
+
+
+def fused_cycles(counters, device=None):
+    """th_fused_cycles: cycle accounting of the fused MLP kernel into ``counters`` (64 zeroed int64 words on the device), or None to
+    switch it off.  [0] sampled tiles, [1..61] shader cycles per phase, [62] / [63] shader cycles / 100 MHz ticks per tile."""
+    if counters is not None:
+        assert counters.dtype == torch.int64 and counters.numel() >= 64 and counters.is_cuda
+        device = counters.device
+    _check(load_library().th_fused_cycles(ctx(device), _p(counters) if counters is not None else None))
 
 
 def host_wait_read(device=None):
