@@ -885,6 +885,11 @@ def graphs_enabled():
 
 
 _vit_graphs = {}
+def graph_epoch():
+    """counter bumped whenever captured graphs are dropped for new weights / arithmetic (frame pipelines key their priming on it)"""
+    return _vit_graph_epoch[0]
+
+
 _vit_graph_epoch = [0]      # bumped whenever the context's TransHE weights or arithmetic change: captured graphs are dropped
 VIT_GRAPH_RING = 4
 
@@ -1488,7 +1493,10 @@ def set_fused_waves(waves, device=None):
 
 def fused_waves(device=None):
     """what set_fused_waves last chose on this device (default: TH_FUSED_WAVES, else 8)"""
-    return _fused_waves.get(_dev_index(device), 4 if os.environ.get("TH_FUSED_WAVES", "8")[:1] == "4" else 8)
+    dflt = 4 if os.environ.get("TH_FUSED_WAVES", "8")[:1] == "4" else 8
+    if device is None and not torch.cuda.is_available():
+        return dflt
+    return _fused_waves.get(_dev_index(device), dflt)
 
 
 def set_chunk_samples(n):

@@ -185,8 +185,12 @@ class SpatialEncoder(nn.Module):
             return None
         v = [(c.weight._version, c.weight.data_ptr()) for c in convs]
         for b in self._bn_sites():
+            # (momentum, eps and the statistics' storage are baked into the captured th_bn_act launches as arguments: part of the key)
             v.append((b.training, None if b.weight is None else (b.weight.data_ptr(), b.bias.data_ptr()),
-                      None if b.running_mean is None else b.running_mean.data_ptr()))
+                      None if b.running_mean is None else b.running_mean.data_ptr(),
+                      None if b.running_var is None else b.running_var.data_ptr(),
+                      None if b.num_batches_tracked is None else b.num_batches_tracked.data_ptr(),
+                      b.momentum, b.eps, b.track_running_stats))
         return (tuple(x.shape), str(x.device), tuple(v))
 
     def _trunk_graphed(self, x):

@@ -196,6 +196,10 @@ class Renderer:
                     fs = self._dev.get(("fold_stream", str(dev)))
                     if fs is None:
                         fs = self._dev[("fold_stream", str(dev))] = torch.cuda.Stream(dev)
+                    # (the packed MLP image is uploaded on the CURRENT stream if it is due -- first frame, new weights: uploaded on `fs`
+                    # by map_fold's own check, nothing would order a map completion that th_render_pregather queues on `cur`
+                    # behind it)
+                    hip._sync_weights(self.net, "mlp")
                     fs.wait_stream(cur)
                     with torch.cuda.stream(fs):
                         fold = hip.map_fold(self.net, map_nhwc)
@@ -451,6 +455,10 @@ class Renderer:
         sl = slice(None) if ray_slice is None else ray_slice
         it = iter(batches)
         lookahead = max(1, min(int(os.environ.get("TH_LOOKAHEAD", lookahead)), 3))    # (th_render_prepass keeps at most 4 tokens)
+        if lookahead >= 3 and hip.graphs_enabled():
+            # the stem / TransHE graph rings hold 4 instances = pipeline depth 2 + the frame being shaded + the frame just handed
+            # out: at depth 3 the instance `last_frame` points at has been replayed for a later frame by the time it is yielded
+            lookahead = 2
         # split front (single rank, TH_SPLIT_FRONT=0 switches it off): the front of a frame is issued in two pieces -- A =
         # hull stage, encoder, paint, group (chip-filling kernels) and B = TransHE (63 small dependent launches).  In the
         # shading window of frame i the side stream runs B(i+1) FIRST and then A(i+2): the latency-bound launches of
@@ -530,12 +538,22 @@ class Renderer:
             # milliseconds) would land on its first OWNED frame -- frame r of rank r, inside a short run's timed frames.  One
             # local set of frame constants up front (no exchange, result dropped) captures both rings on every rank at once.
             # (Train-mode BatchNorm running statistics advance by this one extra frame; they do not enter the rendering.)
-            shape = tuple(first["input_imgs"][0].shape)
+            # (keyed on the shape AND the graph epoch: instances dropped for new weights are captured again the same way)
+            shape = (tuple(first["input_imgs"][0].shape), hip.graph_epoch())
             primed = self._dev.setdefault(("graphs_primed", str(dev)), set())
             if shape not in primed and hip.graphs_enabled():
                 primed.add(shape)
                 with torch.cuda.stream(side):
+                    # the extra frame must not show in the network's state: train-mode BatchNorm statistics are put back
+                    bns = [m for m in self.net.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+                    keep = [(m, None if m.running_mean is None else m.running_mean.clone(),
+                             None if m.running_var is None else m.running_var.clone(),
+                             None if m.num_batches_tracked is None else m.num_batches_tracked.clone()) for m in bns]
                     self.prepare_frame(first, stem_graph=True)
+                    for m, rm, rv, nb in keep:
+                        if rm is not None: m.running_mean.copy_(rm)
+                        if rv is not None: m.running_var.copy_(rv)
+                        if nb is not None: m.num_batches_tracked.copy_(nb)
         queue = collections.deque([front(first, 0, side)])
         tokens(queue[0], side)
         queued, more = 1, True
