@@ -29,14 +29,18 @@ def main():
             vals[k] = statistics.median(v)
             n = len(v)
             print(f"{p}  {k:38s} {vals[k]:18.0f}")
-        print(f"#  pass {p}: {n} launches of {gmax // 256} tiles, VGPRs {rows[0]['VGPR_Count']}+{rows[0]['Accum_VGPR_Count']}, "
+        wg = int(rows[0].get("Workgroup_Size", 256) or 256)
+        vals["_waves_per_simd"] = max(1.0, wg / 256.0)
+        print(f"#  pass {p}: {n} launches of {gmax // wg} tiles ({wg}-thread workgroups), VGPRs {rows[0]['VGPR_Count']}+{rows[0]['Accum_VGPR_Count']}, "
               f"scratch {rows[0]['Scratch_Size']} B/lane, LDS {rows[0]['LDS_Block_Size']}")
     g = vals.get
     if g("SQ_WAVE_CYCLES") and g("SQ_VALU_MFMA_BUSY_CYCLES"):
         # SQ_* count quad-cycles (4 clocks) except SQ_VALU_MFMA_BUSY_CYCLES (clocks, summed over the SIMDs)
-        wave_clk = 4.0 * g("SQ_WAVE_CYCLES")
-        print(f"# derived: MFMA busy = {g('SQ_VALU_MFMA_BUSY_CYCLES'):.3e} / (4 * {g('SQ_WAVE_CYCLES'):.3e}) = "
-              f"{100.0 * g('SQ_VALU_MFMA_BUSY_CYCLES') / wave_clk:.1f} % of wave cycles")
+        # time base of the matrix pipe = SIMD cycles: wave cycles / waves per SIMD (one wave per SIMD for 256-thread workgroups, two for 512)
+        wps = g("_waves_per_simd", 1.0)
+        wave_clk = 4.0 * g("SQ_WAVE_CYCLES") / wps
+        print(f"# derived: MFMA busy = {g('SQ_VALU_MFMA_BUSY_CYCLES'):.3e} / (4 * {g('SQ_WAVE_CYCLES'):.3e} / {wps:.0f} waves per SIMD) = "
+              f"{100.0 * g('SQ_VALU_MFMA_BUSY_CYCLES') / wave_clk:.1f} % of SIMD cycles; the percentages below are of WAVE cycles")
         if g("SQ_WAIT_INST_ANY"):
             print(f"#          waiting on any counter {100.0 * g('SQ_WAIT_INST_ANY') / g('SQ_WAVE_CYCLES'):.1f} %, "
                   f"on LDS {100.0 * g('SQ_WAIT_INST_LDS', 0) / g('SQ_WAVE_CYCLES'):.1f} %, "

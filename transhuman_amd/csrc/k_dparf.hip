@@ -74,8 +74,13 @@ __device__ __forceinline__ float dp_sin(float a) {
 // within that radius (plus a rounding margin), in ascending index order: scanning it gives the same 7
 // neighbours, distances and tie order as scanning all N_c centres, with ~70 instead of N_c candidates.  Points
 // outside the grid fall back to the full scan.  Built once per frame (thousands of tiny blocks, ~20 us).
-#define DPG_MAXCELLS 8192
-#define DPG_CELL 0.075f        // cell size asked for; 0.1: lists of ~70 candidates, 0.075: ~55, K4 0.73 -> 0.71 ms; (dpgrid_setup_kernel grows it until the grid fits DPG_MAXCELLS)
+// Round 6: the cell size follows the token density -- g = DPG_CELL cbrt(500 / N_c) -- so a list stays at ~55 candidates whatever N_c
+// (with the fixed 0.075 m cell the lists of the reference's kmeans_dict_1500 held ~3 x as many: K4 3.1 ms against 0.57 at
+// N_c = 500).  Lists live in slots of DPG_STRIDE entries; a cell whose list does not fit is marked (count -1) and its points
+// take the full scan -- exact either way.
+#define DPG_MAXCELLS 32768
+#define DPG_STRIDE 192
+#define DPG_CELL 0.075f        // cell size asked for at N_c = 500; 0.1: lists of ~70 candidates, 0.075: ~55, K4 0.73 -> 0.71 ms; (dpgrid_setup_kernel grows it until the grid fits DPG_MAXCELLS)
 struct DpGrid {
     float gmin[3];
     float g, inv_g;
@@ -102,6 +107,7 @@ __global__ __launch_bounds__(256) void dpgrid_setup_kernel(const float* __restri
     if (threadIdx.x == 0) {
         float ext[3];
         for (int a = 0; a < 3; ++a) ext[a] = (red[3 + a][0] - red[a][0]) + 2.f * margin;
+        g = fminf(fmaxf(g * cbrtf(500.f / (float)nc), 0.04f), 0.12f);
         // grow the cell until the grid fits
         for (int it = 0; it < 32; ++it) {
             long long n = 1;
@@ -161,20 +167,21 @@ __global__ __launch_bounds__(256) void dpgrid_fill_kernel(const float* __restric
     const float h = 0.8660254f * g.g;                    // half diagonal of the cell
     const float rad = sqrtf(pv) * 1.0001f + 2.f * h * 1.0001f + 1e-5f;
     const float r2 = rad * rad;
-    int* dst = cand + (long long)cell * nc;
+    int* dst = cand + (long long)cell * DPG_STRIDE;
     int o = 0;
     for (int base = 0; base < nc; base += 64) {
         const int i = base + lane;
         const bool in = i < nc && dsq[i] <= r2;
         const unsigned long long m = __ballot(in);
-        if (in) dst[o + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        const int pos = o + __popcll(m & ((1ull << lane) - 1ull));
+        if (in && pos < DPG_STRIDE) dst[pos] = i;
         o += __popcll(m);
     }
-    if (lane == 0) cell_count[cell] = o;
+    if (lane == 0) cell_count[cell] = o <= DPG_STRIDE ? o : -1;      // (-1: the list does not fit its slot -> full scan)
 }
 
 size_t th_dparf_grid_ws(int nc) {
-    return th_align(sizeof(DpGrid)) + th_align((size_t)DPG_MAXCELLS * 4) + th_align((size_t)DPG_MAXCELLS * nc * 4);
+    return th_align(sizeof(DpGrid)) + th_align((size_t)DPG_MAXCELLS * 4) + th_align((size_t)DPG_MAXCELLS * DPG_STRIDE * 4);
 }
 
 int th_dparf_grid_build(const float* centres, int nc, void* ws, size_t ws_bytes, hipStream_t s) {
@@ -183,7 +190,7 @@ int th_dparf_grid_build(const float* centres, int nc, void* ws, size_t ws_bytes,
     ThArena ar(ws, ws_bytes);
     DpGrid* gi = ar.take<DpGrid>(1);
     int* cnt = ar.take<int>(DPG_MAXCELLS);
-    int* cand = ar.take<int>((size_t)DPG_MAXCELLS * nc);
+    int* cand = ar.take<int>((size_t)DPG_MAXCELLS * DPG_STRIDE);
     TH_REQUIRE(cand != nullptr, "grid workspace carve failed");
     hipLaunchKernelGGL(dpgrid_setup_kernel, dim3(1), dim3(256), 0, s, centres, nc, DPG_CELL, 0.25f, gi);
     hipLaunchKernelGGL(dpgrid_fill_kernel, dim3(DPG_MAXCELLS / 4), dim3(256), (size_t)nc * 16, s, centres, nc, gi, cnt, cand);
@@ -244,8 +251,11 @@ __global__ __launch_bounds__(DP_THREADS) void dparf_kernel(const float* __restri
                       cz = (int)floorf((z - gi->gmin[2]) * gi->inv_g);
             if (cx >= 0 && cx < gi->dim[0] && cy >= 0 && cy < gi->dim[1] && cz >= 0 && cz < gi->dim[2]) {
                 const int cell = (cz * gi->dim[1] + cy) * gi->dim[0] + cx;
-                list = cand + (long long)cell * nc;
-                nlist = cell_count[cell];
+                const int cnt = cell_count[cell];
+                if (cnt >= 0) {
+                    list = cand + (long long)cell * DPG_STRIDE;
+                    nlist = cnt;
+                }
             }
         }
         for (int j = half; j < nlist; j += 2) {
@@ -522,7 +532,7 @@ int th_dparf_launch(const float* pts_smpl, const ThPointSrc* ps, const float* Rh
         ThArena ar(const_cast<void*>(grid_ws), th_dparf_grid_ws(nc));
         gi = ar.take<DpGrid>(1);
         cnt = ar.take<int>(DPG_MAXCELLS);
-        cand = ar.take<int>((size_t)DPG_MAXCELLS * nc);
+        cand = ar.take<int>((size_t)DPG_MAXCELLS * DPG_STRIDE);
     }
     static const bool per_view = getenv("TH_DPARF_PER_VIEW") != nullptr;       // A/B switch
     if (fmt == TH_ROWS_NBR) {

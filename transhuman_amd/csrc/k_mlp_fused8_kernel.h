@@ -136,6 +136,50 @@ __device__ __forceinline__ void f8_gemm(const char* __restrict__ ahi, const char
     }
 }
 
+// The same product with the row tiles in THREE groups of RT / 3 (V = 3: view by view): two fragment buffers of RT / 3 row tiles
+// ping-pong through the 3 T sub-steps -- 32 fragment registers instead of 48.  With halves the kv0 phase (72 accumulator, 48
+// parked value, 48 weight and 48 fragment registers) spilled 20 registers per wave: 2.4 GB of scratch writes per frame in the
+// round-6 PMC pass (profiles/r06_y_pmc_mlp.txt, WRITE_SIZE).  T even.
+template <int RT, int CT, int ROWSTEP, bool PERM, bool PRE = false>
+__device__ __forceinline__ void f8_gemm3(const char* __restrict__ ahi, const char* __restrict__ alo, int str,
+                                         const uint4* __restrict__ wp, int T, int lane, f8_f4 (&acc)[CT][RT], uint4 (&w)[2][CT][2]) {
+    static_assert(RT % 3 == 0, "row tiles come in thirds");
+    constexpr int NR = RT / 3;
+    const uint4* wl = wp + lane;
+    const int aoff = f8_aoff<PERM>(lane, str);
+    h8 xh[2][NR], xl[2][NR];
+    if (!PRE) f8_load_w<CT>(wl, 0, w[0]);
+    f8_load_x<NR, ROWSTEP, PERM>(ahi, alo, aoff, 0, xh[0], xl[0]);
+    FM_SB();
+    // sub-step S of a pair of k-steps (t, t + 1), t even: group S % 3 of step t + S / 3 out of buffer S & 1
+    auto sub = [&](auto first, auto sidx, int t) __attribute__((always_inline)) {
+        constexpr int S = decltype(sidx)::value, G = S % 3, PB = S / 3, CUR = S & 1;
+        constexpr bool F = decltype(first)::value && S < 3;
+        constexpr int GN = (G + 1) % 3;
+        const int tt = t + PB;
+        const int tx = G == 2 ? (tt + 1 < T ? tt + 1 : T - 1) : tt;          // (clamped: the last sub-step re-requests what nobody consumes)
+        f8_load_x<NR, ROWSTEP, PERM>(ahi + GN * NR * ROWSTEP, alo + GN * NR * ROWSTEP, aoff, tx, xh[CUR ^ 1], xl[CUR ^ 1]);
+        if constexpr (G == 0) f8_load_w<CT>(wl, tt + 1 < T ? tt + 1 : T - 1, w[PB ^ 1]);
+        f8_mfma_half<CT, RT, NR, G * NR, F>(w[PB], xh[CUR], xl[CUR], acc);
+        f8_interleave<2 * NR + (G == 0 ? 2 * CT : 0), 3 * CT * NR>();
+    };
+    auto pair = [&](auto first, int t) __attribute__((always_inline)) {
+        sub(first, std::integral_constant<int, 0>{}, t); sub(first, std::integral_constant<int, 1>{}, t);
+        sub(first, std::integral_constant<int, 2>{}, t); sub(first, std::integral_constant<int, 3>{}, t);
+        sub(first, std::integral_constant<int, 4>{}, t); sub(first, std::integral_constant<int, 5>{}, t);
+    };
+    pair(std::true_type{}, 0);
+#pragma unroll 1
+    for (int t = 2; t < T; t += 2) pair(std::false_type{}, t);
+}
+// (row tiles in thirds where they divide by three, else in halves)
+template <int RT, int CT, int ROWSTEP, bool PERM, bool PRE = false>
+__device__ __forceinline__ void f8_gemm_rt(const char* __restrict__ ahi, const char* __restrict__ alo, int str,
+                                           const uint4* __restrict__ wp, int T, int lane, f8_f4 (&acc)[CT][RT], uint4 (&w)[2][CT][2]) {
+    if constexpr (RT % 3 == 0) f8_gemm3<RT, CT, ROWSTEP, PERM, PRE>(ahi, alo, str, wp, T, lane, acc, w);
+    else f8_gemm<RT, CT, ROWSTEP, PERM, PRE>(ahi, alo, str, wp, T, lane, acc, w);
+}
+
 // 16 x 16 output tile of this lane (sample l, channels col0 + 4 g ..): hi / lo halves into the operand planes
 template <int STR, bool NONNEG = true>
 __device__ __forceinline__ void f8_store_h(const f8_f4& t, int row, int col0, char* __restrict__ hi, char* __restrict__ lo, int lane,
@@ -200,7 +244,8 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     constexpr int ROWS = 32 * V, RT = 2 * V;
     constexpr int RS256 = 16 * STR256;           // bytes between row tiles of a K = 256 plane
     int dbg_i = 1;
-    long long dbg_t = 0, dbg_w = 0, dbg_t0 = 0;
+    long long dbg_t = 0;
+    long long* dbg_keep = reinterpret_cast<long long*>(flag + 2);      // (tile-start stamps of the cycle accounting: LDS, not two register pairs)
     constexpr float inv_v = 1.0f / (float)V;
     unsigned rmax = 0u;
     unsigned seen_s = 0u, seen_p = 0u, seen_n = 0u, seen_i = 0u, seen_4 = 0u;
@@ -378,8 +423,8 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     if (PK.dbg != nullptr && tid == 0 && (tile & 15) == 0) {
         atomicAdd(reinterpret_cast<unsigned long long*>(PK.dbg), 1ull);
         dbg_t = clock64();
-        dbg_t0 = dbg_t;
-        dbg_w = wall_clock64();
+        dbg_keep[0] = dbg_t;
+        dbg_keep[1] = wall_clock64();
     }
     // range guard: launch-wide maxima as they stand when this tile starts (scalar loads through the constant address space: the
     // table is only a hint here -- a stale smaller value costs an atomic, never a result)
@@ -528,7 +573,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     float* ksb = reinterpret_cast<float*>(mbuf);                    // [ROWS][KSTR] fp32 keys of the token branch
     {
         f8_f4 acc3[3][RT];
-        f8_gemm<RT, 3, RS256, true, true>(abuf, a256_lo, STR256, F8_WSLICE(PK.w16.kv1, wave, 3), 8, lane, acc3, wk3);
+        f8_gemm_rt<RT, 3, RS256, true, true>(abuf, a256_lo, STR256, F8_WSLICE(PK.w16.kv1, wave, 3), 8, lane, acc3, wk3);
         const float4 bk = f8_bias(PK.kv1.bias, wave * 16, lane), bv0 = f8_bias(PK.kv1.bias, 128 + wave * 32, lane),
                      bv1 = f8_bias(PK.kv1.bias, 128 + wave * 32 + 16, lane);
 #pragma unroll
@@ -550,7 +595,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     f8_f4 vp[2][RT];
     {
         f8_f4 acc3[3][RT];
-        f8_gemm<RT, 3, RS256, true, true>(abuf, a256_lo, STR256, F8_WSLICE(PK.w16.kv0, wave, 3), 8, lane, acc3, wk3);
+        f8_gemm_rt<RT, 3, RS256, true, true>(abuf, a256_lo, STR256, F8_WSLICE(PK.w16.kv0, wave, 3), 8, lane, acc3, wk3);
         const float4 bk = f8_bias(PK.kv0.bias, wave * 16, lane), bv0 = f8_bias(PK.kv0.bias, 128 + wave * 32, lane),
                      bv1 = f8_bias(PK.kv0.bias, 128 + wave * 32 + 16, lane);
         FM_SYNCL();                                                  // every wave is done reading p from ABUF
@@ -675,7 +720,7 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
         vsel[q] = x;
     }
     FM_SYNCL();
-    f8_gemm<RT, 2, RS256, true, true>(abuf, a256_lo, STR256, F8_WSLICE(PK.w16.fc_2, wave, 2), 8, lane, acc2, wk2);
+    f8_gemm_rt<RT, 2, RS256, true, true>(abuf, a256_lo, STR256, F8_WSLICE(PK.w16.fc_2, wave, 2), 8, lane, acc2, wk2);
     const float4 bi[2] = {f8_bias(PK.fc_2.bias, wave * 32, lane), f8_bias(PK.fc_2.bias, wave * 32 + 16, lane)};
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -906,8 +951,8 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     if (tid < npts)
         *reinterpret_cast<float4*>(PK.raw_c + (long long)(pbase + tid) * 4) = make_float4(rgb_out[0], rgb_out[1], rgb_out[2], sig[tid]);
     if (FM_DBG_SAMPLED) {        // dbg[62] / dbg[63]: shader cycles and 100 MHz ticks of the sampled tiles, first stamp to here: the clock INSIDE the launch
-        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + 62), (unsigned long long)(clock64() - dbg_t0));
-        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + 63), (unsigned long long)(wall_clock64() - dbg_w));
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + 62), (unsigned long long)(clock64() - dbg_keep[0]));
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.dbg + 63), (unsigned long long)(wall_clock64() - dbg_keep[1]));
     }
 #undef PK
 }
