@@ -23,6 +23,8 @@
 #include "k_mlp_fused_kernel.h"
 
 typedef float f8_f4 __attribute__((ext_vector_type(4)));
+typedef short f8_s4 __attribute__((ext_vector_type(4)));
+typedef short f8_s8 __attribute__((ext_vector_type(8)));
 
 #define F8_THREADS 512
 #define F8_PART_FLOATS (3 * 8 * 32)                        // [3 outputs][8 waves][32 samples] cross-wave partial sums
@@ -522,20 +524,26 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
             {
                 h8 xh[2], xl[2];
                 f8_load_x<2, 16 * STRVD, false>(wsp_hi, wsp_lo, aoffw, 0, xh, xl);
-                int roff[8];                                     // slot rows of this lane's 8 k values (padding clamped)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) roff[j] = min(8 * g4 + j, nU - 1) * STOK_STR;
+                // The A operand is T'^T: lane (channel l15, slot group g4) wants 8 SLOTS of one channel out of rows that hold 256
+                // channels of one slot.  ds_read_b64_tr_b16 does the transpose: the 16 lanes of a group each hand in the address
+                // of 4 consecutive halves of a [4 slots][16 channels] block (lane i: slot i / 4, channels 4 (i % 4) ..) and lane i
+                // receives channel i of the 4 slots (tools/ubench/tr16_semantics.hip) -- two reads per plane and fragment
+                // instead of eight 2-byte reads and their packing (slots past the list's end: the last row again, weight 0).
+                const int tq = l15 >> 2, tc = 8 * (l15 & 3);
+                const int ro0 = min(8 * g4 + tq, nU - 1) * STOK_STR + tc, ro1 = min(8 * g4 + 4 + tq, nU - 1) * STOK_STR + tc;
+                typedef __attribute__((address_space(3))) f8_s4* f8_lp;
 #pragma unroll
                 for (int r = 0; r < V; ++r)
 #pragma unroll
                     for (int c = 0; c < 2; ++c) {
-                        const char* rb = abuf + r * 32 * STOK_STR + 2 * (wave * 32 + c * 16 + l15);
-                        h8 ah, al;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            ah[j] = *reinterpret_cast<const _Float16*>(rb + roff[j]);
-                            al[j] = *reinterpret_cast<const _Float16*>(rb + roff[j] + 512);
-                        }
+                        const char* rb = abuf + r * 32 * STOK_STR + 2 * (wave * 32 + c * 16);
+                        const f8_s4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((f8_lp)(rb + ro0));
+                        const f8_s4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((f8_lp)(rb + ro1));
+                        const f8_s4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((f8_lp)(rb + ro0 + 512));
+                        const f8_s4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((f8_lp)(rb + ro1 + 512));
+                        const f8_s8 ahs = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const f8_s8 als = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        const h8 ah = __builtin_bit_cast(h8, ahs), al = __builtin_bit_cast(h8, als);
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             acc2[c][2 * r + h] = F8_MFMA(al, xh[h], acc2[c][2 * r + h]);
