@@ -215,6 +215,27 @@ __device__ __forceinline__ float4 f8_bias(const float* __restrict__ bias, int co
     return *reinterpret_cast<const float4*>(bias + col0 + 4 * (lane >> 4));
 }
 
+// one half-step of the fc_3 || view_fc loop: a3[c][H] (2 column tiles on ONE mean row tile) and va[0][R0 ..] (one column tile on NV row
+// tiles), term by term with the two products interleaved -- an accumulator recurs every 2 + NV MFMAs (fc_3's two accumulators
+// alone would issue dependent MFMAs two apart)
+template <int RT, int NV, int H, int R0, bool FIRST>
+__device__ __forceinline__ void f8_mfma_dual(const uint4 (&r3)[2][2], const uint4 (&ra)[1][2], const h8 (&mh)[1], const h8 (&ml)[1],
+                                             const h8 (&xh)[NV], const h8 (&xl)[NV], f8_f4 (&a3)[2][2], f8_f4 (&va)[1][RT]) {
+    const f8_f4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int wp = t == 0 ? 1 : 0;                     // weight plane: lo, hi, hi
+        const bool lo = t == 1;                            // activation plane: hi, lo, hi
+        const bool first = FIRST && t == 0;
+        a3[0][H] = F8_MFMA(*reinterpret_cast<const h8*>(&r3[0][wp]), lo ? ml[0] : mh[0], first ? zero : a3[0][H]);
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            va[0][R0 + r] = F8_MFMA(*reinterpret_cast<const h8*>(&ra[0][wp]), lo ? xl[r] : xh[r], first ? zero : va[0][R0 + r]);
+            if (r == 0) a3[1][H] = F8_MFMA(*reinterpret_cast<const h8*>(&r3[1][wp]), lo ? ml[0] : mh[0], first ? zero : a3[1][H]);
+        }
+    }
+}
+
 template <int V>
 __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P_arg) {
 #define PK P_arg
@@ -794,13 +815,11 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
                 f8_load_w<2>(w3l, tn, r3[PB ^ 1]);
                 f8_load_w<1>(wal, tn, ra[PB ^ 1]);
                 // (the two products interleaved term by term: 2 + V accumulators between two uses of one)
-                f8_mfma_half<2, 2, 1, 0, F>(r3[PB], mah, mal, a3);
-                f8_mfma_half<1, RT, V, 0, F>(ra[PB], xah, xal, va);
+                f8_mfma_dual<RT, V, 0, 0, F>(r3[PB], ra[PB], mah, mal, xah, xal, a3, va);
                 f8_interleave<2 + 2 * V + 6, 3 * (2 + V)>();
                 f8_load_x<1, RS256, true>(mhi, mlo, aoff, tn, mah, mal);
                 f8_load_x<V, RS256, true>(abuf, a256_lo, aoff, tn, xah, xal);
-                f8_mfma_half<2, 2, 1, 1, F>(r3[PB], mbh, mbl, a3);
-                f8_mfma_half<1, RT, V, V, F>(ra[PB], xbh, xbl, va);
+                f8_mfma_dual<RT, V, 1, V, F>(r3[PB], ra[PB], mbh, mbl, xbh, xbl, a3, va);
                 f8_interleave<2 + 2 * V, 3 * (2 + V)>();
             };
             step(std::true_type{}, std::integral_constant<int, 0>{}, 0);
