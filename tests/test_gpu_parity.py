@@ -706,14 +706,15 @@ def test_edge_cases_no_hits_single_ray_empty(hip, gpu, net):
     assert o0["rgb_map"].shape == (1, 0, 3) and o0["acc_map"].shape == (1, 0)
 
 
-@pytest.mark.parametrize("nc", [500, 1500])
+@pytest.mark.parametrize("nc", [300, 500, 1500])
 def test_dparf_candidate_grid_is_exact(hip, gpu, net, nc, monkeypatch):
     """the per-cell candidate lists of K4 are supersets of every point's 7 nearest centres: rendering with the grid
     equals rendering with the full N_c scan bit for bit (synthetic and the reference's ragged kmeans clusters)"""
     from transhuman_amd.config import get_cfg
     from transhuman_amd.networks.renderer import if_clight_renderer
     get_cfg().N_samples, get_cfg().num_class = 32, nc
-    assign = synth_assign(500) if nc == 500 else real_assign(1500)
+    # (round 6: the grid's cell follows the token density, 0.075 m cbrt(500 / N_c), lists in slots of 192 -- three densities)
+    assign = synth_assign(nc) if nc != 1500 else real_assign(1500)
     r = if_clight_renderer.Renderer(net, vertex_can=can64().numpy(), pc2voxel_ind=assign)
     b = synth.batch_to(synth.make_batch(96, 96, 3, seed=0, focal=260.0), gpu)
     frame = r.prepare_frame(b)

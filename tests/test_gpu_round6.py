@@ -161,3 +161,33 @@ def test_sigma_grid_256_every_valid_voxel(hip, gpu):
     c32 = D.oracle_sigma_points(bc, sd, assign, pts[pick], torch.device("cpu"), torch.float32)
     assert float((o32[pick] - c32).abs().max()) < 5e-5
     assert float((g[pick] - c32).abs().max()) < BAR
+
+
+def test_fused_cycles_counters(hip, gpu):
+    """th_fused_cycles (ABI 11): the fused kernel's own cycle accounting -- every 16th tile is sampled, the phases add up to the tile,
+    and shader cycles per 100 MHz tick give a plausible clock"""
+    net = make_net(12).to(gpu)
+    assign = synth_assign(300)
+    r = _renderer(net, 300, 64, assign)
+    b = synth.batch_to(synth.make_batch(192, 192, 3, seed=0, all_rays=True), gpu)
+    r.render_fast(b, is_train=False)                       # (weights uploaded, graphs captured)
+    cnt = torch.zeros(64, dtype=torch.int64, device=gpu)
+    hip.fused_cycles(cnt)
+    try:
+        r.render_fast(b, is_train=False)
+        torch.cuda.synchronize()
+    finally:
+        hip.fused_cycles(None)
+    c = cnt.cpu().numpy().astype(np.float64)
+    tiles = (r.last_stats["valid_samples"] + 31) // 32
+    assert tiles > 64 and abs(c[0] - (tiles + 15) // 16) <= 1, (c[0], tiles)
+    per_tile, phases = c[62] / c[0], c[1:62].sum() / c[0]
+    ghz = c[62] / (c[63] * 10.0)
+    print(f"{int(c[0])} sampled tiles of {tiles}: {per_tile:.0f} cycles per tile ({phases:.0f} between barriers), {ghz:.2f} GHz inside the launch")
+    assert 40e3 < per_tile < 400e3 and 0.9 * per_tile < phases + 3000 and phases <= per_tile
+    assert 1.0 < ghz < 2.6
+    # switched off again: nothing is counted
+    before = cnt.clone()
+    r.render_fast(b, is_train=False)
+    torch.cuda.synchronize()
+    assert torch.equal(before, cnt)
