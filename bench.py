@@ -354,7 +354,7 @@ def run_extras(dev, net, args, H, W, V):
         r = Renderer(net, vertex_can=body.astype(np.float64) * 1.02 + 0.001, pc2voxel_ind=assign)
         b = synth.batch_to(bc, dev)
         seq = r.render_sequence(itertools.repeat(b))
-        ms, out = time_steps(lambda: next(seq), 3, warmup=2)
+        ms, out = time_steps(lambda: next(seq), 8, warmup=3)        # (8 frames: the first few of a sequence fill its pipeline)
         img = torch.cat([out["rgb_map"][0], out["acc_map"][0][:, None], out["depth_map"][0][:, None]], dim=1)
         hit = torch.nonzero(out["acc_map"][0] > 0).reshape(-1).cpu().numpy()
         idx = np.sort(np.concatenate([rs.choice(hit, n_hit_rays, replace=False), rs.choice(H * W, 64, replace=False)]))

@@ -146,6 +146,20 @@ __global__ __launch_bounds__(256) void dpgrid_fill_kernel(const float* __restric
         float dx = qx - centres[3 * i], dy = qy - centres[3 * i + 1], dz = qz - centres[3 * i + 2];
         dsq[i] = dx * dx + dy * dy + dz * dz;
     }
+    // A cell whose centre is further than `skip` from EVERY token centre holds no sample of the hull (samples lie within 0.1 m of a
+    // posed vertex, a vertex within its cluster's radius of the cluster mean): no list -- a point that falls into it anyway takes the
+    // full scan (count -1), exact like every other.  Most cells of the body's bounding box are such air: at N_c = 1500 (32 k cells)
+    // the seven selection rounds over 1500 distances per cell made this kernel 0.30 ms per frame.
+    {
+        float mn = 3e38f;
+        for (int i = lane; i < nc; i += 64) mn = fminf(mn, dsq[i]);
+        for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o));
+        const float skip = 0.30f + 0.8660254f * g.g;
+        if (mn > skip * skip) {
+            if (lane == 0) cell_count[cell] = -1;
+            return;
+        }
+    }
     // 7th smallest squared distance: seven rounds of (min over values after the previous pick, by (value, index))
     float pv = -1.f;
     int pi = -1;
