@@ -448,6 +448,152 @@ __global__ __launch_bounds__(64) void attn2_kernel(const float* __restrict__ qkv
     }
 }
 
+// ---- attention, third form (round 6): attn2's arithmetic, K / V^T tiles shared by four waves through LDS ---------------------------
+// attn2_kernel (one wave = 16 queries per workgroup) streams the whole K / V^T planes of its (view, head) from L2 per wave: at
+// N = 1500 that is 650 MB per layer and the launch takes 172 us (3.8 TB/s: the L2's rate for this pattern); the LDS-staged
+// attn_kernel converts and transposes every tile inside every workgroup (134 us).  Here one workgroup = 4 waves = 64 queries; a
+// 64-key tile of the PRE-SPLIT planes (the qkv GEMM's epilogue writes them in fragment order) is copied into LDS by LDS-DMA, one
+// plane per wave (K hi, K lo, V^T hi, V^T lo: 8 KB = 8 wave instructions each), double-buffered, ONE barrier per tile; every wave
+// reads its fragments with ds_read_b128 and runs attn2's transposed products / online softmax in registers.  A quarter of the L2
+// traffic, no conversion, no 2-byte LDS stores.  LDS rows are 128 B (8 slots of 16 B); slot s of row r sits at s ^ (r & 7): the
+// 16 lanes a ds_read_b128 services per cycle (16 rows, two slot columns) then hit 16 different positions of the bank row
+// (LDS-DMA writes lane-linear, so the swizzle is applied to the SOURCE address a lane fetches).
+#define AT3_PLANE (64 * 128)           // bytes of one tile plane
+__global__ __launch_bounds__(256) void attn3_kernel(const float* __restrict__ qkv, const _Float16* __restrict__ Kp,
+                                                    const _Float16* __restrict__ Vp, int N, int Npad, int dim,
+                                                    float scale, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) char tiles[2][4 * AT3_PLANE];      // [buffer][K hi | K lo | V^T hi | V^T lo]
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.y, view = blockIdx.z, heads = gridDim.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int ld = 3 * dim;
+    const float* base = qkv + (long long)view * N * ld;
+    const long long plane = (long long)Npad * 64;
+    const _Float16* kp = Kp + ((long long)view * heads + head) * 2 * plane;
+    const _Float16* vp = Vp + ((long long)view * heads + head) * 2 * plane;
+
+    // this wave's share of a tile copy: plane `wave` (0: K hi, 1: K lo, 2: V^T hi, 3: V^T lo), 8 x 1 KiB
+    typedef __attribute__((address_space(1))) const void* at_gptr;
+    typedef __attribute__((address_space(3))) void* at_lptr;
+    auto stage = [&](int k0, int buf) {
+        char* dst = tiles[buf] + wave * AT3_PLANE;
+        const _Float16* src = (wave < 2 ? kp : vp) + (long long)(wave & 1) * plane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int L = i * 64 + lane, r = L >> 3, sl = (L & 7) ^ (r & 7);          // LDS slot L holds logical slot sl of row r
+            const _Float16* gsrc = wave < 2 ? src + (long long)(k0 + r) * 64 + 8 * sl               // K row = key k0 + r
+                                            : src + (long long)r * Npad + k0 + 8 * sl;              // V^T row = d
+            __builtin_amdgcn_global_load_lds((at_gptr)gsrc, (at_lptr)(dst + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // Q^T fragments (B operand: column = query c, k = d = 32 s2 + 8 g + j)
+    at_h8 qh[2], ql[2];
+    {
+        const int qi = q0 + c;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = 0.f;
+            if (qi < N) {
+                const float* src = base + (long long)qi * ld + head * 64 + 32 * s2 + 8 * g;
+                float4 a = *reinterpret_cast<const float4*>(src), b4 = *reinterpret_cast<const float4*>(src + 4);
+                v8[0] = a.x; v8[1] = a.y; v8[2] = a.z; v8[3] = a.w; v8[4] = b4.x; v8[5] = b4.y; v8[6] = b4.z; v8[7] = b4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                _Float16 x, y;
+                at_split(v8[e], x, y);
+                qh[s2][e] = x; ql[s2][e] = y;
+            }
+        }
+    }
+    f32x4 oacc[4];              // O^T tiles: d = 16 jd + 4 g + r, column = query c
+#pragma unroll
+    for (int j = 0; j < 4; ++j) oacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -3.0e38f, lrun = 0.f;
+    const int foff = c * 128;                         // this lane's row inside a 16-row block of a tile plane
+    const int sw = c & 7;
+
+    stage(0, 0);
+    int buf = 0;
+    for (int k0 = 0; k0 < N; k0 += AT_K, buf ^= 1) {
+        __builtin_amdgcn_s_waitcnt(0x0070);           // vmcnt(0): this wave's plane of the tile has landed
+        __syncthreads();                              // ... and everybody's; everybody is done with the other buffer
+        if (k0 + AT_K < N) stage(k0 + AT_K, buf ^ 1);
+        const char* T = tiles[buf];
+        f32x4 sacc[4];          // S^T tiles: key = k0 + 16 nt + 4 g + r, column = query c
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            sacc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int o = nt * 16 * 128 + foff + (((4 * s2 + g) ^ sw) << 4);
+                const at_h8 kh = *reinterpret_cast<const at_h8*>(T + o);
+                const at_h8 kl = *reinterpret_cast<const at_h8*>(T + AT3_PLANE + o);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[s2], sacc[nt], 0, 0, 0);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[s2], sacc[nt], 0, 0, 0);
+                sacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[s2], sacc[nt], 0, 0, 0);
+            }
+        }
+        float m = -3.0e38f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + nt * 16 + 4 * g + r;
+                const float sv = (key < N) ? sacc[nt][r] * scale : -3.0e38f;
+                sacc[nt][r] = sv;
+                m = fmaxf(m, sv);
+            }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float mnew = fmaxf(mrun, m);
+        const float corr = expf(mrun - mnew);
+        mrun = mnew;
+        float ls = 0.f;
+        at_h8 ph[2], pl[2];     // P^T fragments (B operand) of the two 32-key blocks (attn2_kernel's key order)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + nt * 16 + 4 * g + r;
+                const float pv = (key < N) ? expf(sacc[nt][r] - mnew) : 0.f;
+                ls += pv;
+                _Float16 x, y;
+                at_split(pv, x, y);
+                ph[nt >> 1][4 * (nt & 1) + r] = x;
+                pl[nt >> 1][4 * (nt & 1) + r] = y;
+            }
+        ls += __shfl_xor(ls, 16);
+        ls += __shfl_xor(ls, 32);
+        lrun = lrun * corr + ls;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) oacc[j] *= corr;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int o = j * 16 * 128 + foff + (((4 * s2 + g) ^ sw) << 4);
+                const at_h8 vh = *reinterpret_cast<const at_h8*>(T + 2 * AT3_PLANE + o);
+                const at_h8 vl = *reinterpret_cast<const at_h8*>(T + 3 * AT3_PLANE + o);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[s2], oacc[j], 0, 0, 0);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[s2], oacc[j], 0, 0, 0);
+                oacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[s2], oacc[j], 0, 0, 0);
+            }
+    }
+    const int qi = q0 + c;
+    if (qi < N) {
+        const float inv = 1.0f / lrun;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(out + ((long long)view * N + qi) * dim + head * 64 + j * 16 + 4 * g) =
+                make_float4(oacc[j][0] * inv, oacc[j][1] * inv, oacc[j][2] * inv, oacc[j][3] * inv);
+    }
+}
+
 static int vit_npad(int N) { return (N + 63) / 64 * 64; }
 
 // zero fill of the K / V^T planes as a KERNEL, not hipMemsetAsync: this forward is also replayed as a hipGraph (hip.vit_forward(
@@ -489,7 +635,10 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
     static const char* attn_env = getenv("TH_ATTN_FORM");               // "lds" | "reg": A/B switch
     // (transposed register-fed form, late round 2: 0.77 / 0.95 / 1.19 / 2.06 ms at N_c = 500 / 800 / 1000 / 1500 against 0.93 / 1.16 /
     // 1.27 / 1.76 ms LDS-staged)
-    const bool attn_lds = attn_env ? attn_env[0] == 'l' : N > 1100;
+    // (round 6: from N ~ 700 on the third form -- attn2's arithmetic on K / V^T tiles shared through LDS, attn3_kernel; "lds": the
+    // round-2 form that converts inside the workgroup, "reg" / "tile": force the register-fed / the tiled form)
+    const bool attn_lds = attn_env ? attn_env[0] == 'l' : false;
+    const bool attn_tile = attn_env ? attn_env[0] == 't' : N > 700;
     TH_REQUIRE(Q != nullptr, "workspace carve failed");
     long long n = (long long)T * dim;
     hipLaunchKernelGGL(add_kernel, dim3(th_cdiv(n, 256)), dim3(256), 0, s, x, pe, n, X);
@@ -527,7 +676,8 @@ int th_vit_launch(const ThVitPacked& W, const float* x, const float* pe, int V, 
         } else {
             if (!(h3 && fuse_split))
                 hipLaunchKernelGGL(kv_split_kernel, dim3(Npad / 64, heads, V), dim3(256), 0, s, Q, N, Npad, dim, Kp, Vp);
-            hipLaunchKernelGGL(attn2_kernel, dim3(th_cdiv(N, 16), heads, V), dim3(64), 0, s, Q, Kp, Vp, N, Npad, dim, scale, Y);
+            if (attn_tile) hipLaunchKernelGGL(attn3_kernel, dim3(th_cdiv(N, 64), heads, V), dim3(256), 0, s, Q, Kp, Vp, N, Npad, dim, scale, Y);
+            else hipLaunchKernelGGL(attn2_kernel, dim3(th_cdiv(N, 16), heads, V), dim3(64), 0, s, Q, Kp, Vp, N, Npad, dim, scale, Y);
         }
         if (h3) {
             TH_TRY(th_gemm_h3(Y, dim, T, B.proj, nullptr, nullptr, 0.f, TH_ACT_NONE | TH_GEMM_ACCUM, X, dim, range, s));
