@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TH_ABI_VERSION 11
+#define TH_ABI_VERSION 12
 
 typedef struct th_ctx th_ctx;
 typedef void* th_stream;
@@ -320,6 +320,18 @@ int th_bn_act(th_ctx* ctx, const float* x, const float* residual, int N, int C, 
 int th_bn_act_eval(th_ctx* ctx, const float* x, const float* residual, int N, int C, int HW, const float* gamma,
                    const float* beta, float eps, const float* running_mean, const float* running_var, int relu,
                    float* y, th_stream stream);
+/* ABI 12 -- a convolution followed by a train-mode BatchNorm (every conv -> bn site of encoder.py:114-126) in TWO launches
+ * instead of three: th_conv2d_stats is th_conv2d whose epilogue also leaves, per output channel, the sum and the sum of
+ * squares of the values it stored as th_conv2d_stats_partials(...) float2 partials (`stats`: [cout][partials] float2, device,
+ * 8-byte aligned); th_bn_act_stats is th_bn_act reading those instead of running its own statistics pass over y (the
+ * partials of a channel are added in float64 in a fixed order: deterministic).  Same results as th_conv2d + th_bn_act up
+ * to the rounding of the statistics (fp32 partial sums over <= 128 pixels). */
+int th_conv2d_stats_partials(int N, int cin, int H, int W, int cout, int ks, int stride);
+int th_conv2d_stats(th_ctx* ctx, const float* x, int N, int cin, int H, int W, const void* packed, float inv_scale,
+                    int cout, int ks, int stride, float* y, void* stats, size_t stats_bytes, th_stream stream);
+int th_bn_act_stats(th_ctx* ctx, const float* x, const float* residual, int N, int C, int HW, const void* stats,
+                    int n_partials, const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, int relu, float* y, th_stream stream);
 
 /* ---- K3: TransHE (ViT-tiny) ---------------------------------------------- */
 /* VisionTransformer.forward, vision_transformer.py:371-383.  x [V,N,dim]

@@ -41,7 +41,7 @@ def test_library_exports_every_declared_symbol(lib):
 def test_binding_table_matches_header(lib):
     from transhuman_amd import hip
     assert sorted(hip.SYMBOLS) == header_functions()
-    assert lib.th_abi_version() == 11
+    assert lib.th_abi_version() == 12
 
 
 def test_workspace_queries_are_pure_host_calls(lib):

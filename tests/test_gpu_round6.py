@@ -191,3 +191,53 @@ def test_fused_cycles_counters(hip, gpu):
     r.render_fast(b, is_train=False)
     torch.cuda.synchronize()
     assert torch.equal(before, cnt)
+
+
+@pytest.mark.parametrize("cin,cout,ks,stride,H,W", [(3, 64, 7, 2, 512, 512), (3, 64, 7, 2, 61, 90), (64, 64, 3, 1, 128, 128),
+                                                     (64, 64, 3, 1, 37, 45), (64, 128, 3, 2, 33, 47), (128, 128, 3, 1, 19, 70),
+                                                     (64, 128, 1, 2, 31, 33)])
+def test_conv_epilogue_statistics_equal_the_statistics_pass(hip, gpu, cin, cout, ks, stride, H, W):
+    """th_conv2d_stats / th_bn_act_stats (ABI 12): the convolution's output is bit-identical with and without the statistics
+    epilogue, the partial sums add up to the channel sums of what was stored (ragged tiles contribute nothing for the pixels
+    outside the image), and the BatchNorm that reads them equals the one with its own statistics pass -- output, running mean,
+    running variance."""
+    import copy
+    torch.manual_seed(cin + cout + H)
+    conv = torch.nn.Conv2d(cin, cout, ks, stride, ks // 2, bias=False).to(gpu)
+    x = (torch.randn(3, cin, H, W, device=gpu) * 1.5 + 0.3).contiguous()
+    y0 = hip.conv2d(x, conv)
+    y1, (sbuf, npart) = hip.conv2d(x, conv, stats=True)
+    assert torch.equal(y0, y1)
+    assert sbuf.shape == (cout, npart, 2)
+    s = sbuf.double().sum(1).cpu()
+    ref_s = y0.double().sum((0, 2, 3)).cpu()
+    ref_q = (y0.double() ** 2).sum((0, 2, 3)).cpu()
+    n = y0.numel() // cout
+    assert float((s[:, 0] - ref_s).abs().max()) < 2e-6 * n * float(y0.abs().max())
+    assert float((s[:, 1] - ref_q).abs().max()) < 2e-6 * float(ref_q.max())
+    r = torch.randn_like(y0)
+    for res, relu in ((None, True), (r, True), (r, False)):
+        bn1 = torch.nn.BatchNorm2d(cout).to(gpu).train()
+        with torch.no_grad():
+            bn1.weight.uniform_(0.5, 1.5); bn1.bias.uniform_(-0.5, 0.5)
+        bn2 = copy.deepcopy(bn1)
+        a = hip.bn_act(y1, bn1, residual=res, relu=relu, conv_stats=(sbuf, npart))
+        b = hip.bn_act(y0, bn2, residual=res, relu=relu)
+        assert float((a - b).abs().max()) < 2e-6
+        assert float((bn1.running_mean - bn2.running_mean).abs().max()) < 1e-7
+        assert float((bn1.running_var - bn2.running_var).abs().max()) < 1e-6 * float(bn2.running_var.max())
+
+
+def test_stem_statistics_switch(hip, gpu, monkeypatch):
+    """TH_BN_STATS_PASS=1 keeps the separate statistics pass: same latents as the fused epilogue form to rounding"""
+    import copy
+    from transhuman_amd.networks.encoder import SpatialEncoder
+    torch.manual_seed(5)
+    a = SpatialEncoder().to(gpu).train()
+    b = copy.deepcopy(a)
+    x = torch.rand(3, 3, 128, 96, device=gpu)
+    la = a.trunk(x, fused_bn=True)
+    monkeypatch.setenv("TH_BN_STATS_PASS", "1")
+    lb = b.trunk(x, fused_bn=True)
+    for u, v in zip(la, lb):
+        assert float((u - v).abs().max()) < 2e-5

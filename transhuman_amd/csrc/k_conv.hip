@@ -107,7 +107,8 @@ __device__ __forceinline__ int cv_chan(int e, int lane) { return (e & 3) + 8 * (
 template <int CIN, int COUT, int S, int KS, int TR, int WC>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                         float inv_scale, float* __restrict__ y, int H, int W, int Ho,
-                                                        int Wo, unsigned* __restrict__ range) {
+                                                        int Wo, unsigned* __restrict__ range,
+                                                        float2* __restrict__ stats, int NP) {
     constexpr int PAD = KS / 2;
     constexpr int IR = (TR - 1) * S + KS, IC = 31 * S + KS;
     constexpr int STRB = 2 * CIN + 16;
@@ -259,11 +260,32 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
                 }
             }
     }
+    // ---- BatchNorm statistics of the tile (th_conv2d_stats): per output channel the sum and the sum of squares of the
+    // values just stored, over this wave's pixels, as one float2 partial per (channel, wave-tile) -- K11's apply pass adds
+    // the partials of a channel in float64 in a fixed order.  Saves the statistics pass its launch and its read of y.
+    if (stats != nullptr) {
+        const int pidx = ((n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WR + wave / WC;
+#pragma unroll
+        for (int c = 0; c < CTW; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int r = 0; r < RTW; ++r) {
+                    const float v = (ox < Wo && oy0 + rbase + r < Ho) ? acc[c][r][e] * inv_scale : 0.f;
+                    sm += v;
+                    sq = fmaf(v, v, sq);
+                }
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+                if ((lane & 31) == 0) stats[(long long)((cbase + c) * 32 + cv_chan(e, lane)) * NP + pidx] = make_float2(sm, sq);
+            }
+    }
 }
 
 template <int CIN, int COUT, int S, int KS, int TR, int WC>
 static int conv_launch_t(const float* x, const uint4* wp, float inv_scale, float* y, int N, int H, int W, int Ho, int Wo,
-                         unsigned* range,
+                         unsigned* range, float2* stats, int* np_out,
                          hipStream_t s) {
     constexpr int IR = (TR - 1) * S + KS, IC = 31 * S + KS, STRB = 2 * CIN + 16;
     constexpr size_t lds = (size_t)2 * IR * IC * STRB;
@@ -273,7 +295,10 @@ static int conv_launch_t(const float* x, const uint4* wp, float inv_scale, float
     if (th_lds_attr_needed(&attr_done))
         TH_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(th_cdiv(Wo, 32), th_cdiv(Ho, TR), N);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo, range);
+    const int NP = (int)(grid.x * grid.y * grid.z) * (4 / WC);
+    if (np_out) *np_out = NP;
+    if (x == nullptr) return 0;                            // (size query)
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo, range, stats, NP);
     TH_LAUNCH_CHECK();
     return 0;
 }
@@ -292,7 +317,8 @@ static int conv_launch_t(const float* x, const uint4* wp, float inv_scale, float
 
 __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict__ x, const uint4* __restrict__ wp,
                                                          float inv_scale, float* __restrict__ y, int H, int W, int Ho,
-                                                         int Wo, unsigned* __restrict__ range) {
+                                                         int Wo, unsigned* __restrict__ range,
+                                                         float2* __restrict__ stats, int NP) {
     constexpr int PLANE = C1_TR * 32 * C1_STRB;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* xhi = lds;
@@ -366,17 +392,31 @@ __global__ __launch_bounds__(256) void conv1_mfma_kernel(const float* __restrict
 #pragma unroll
         for (int e = 0; e < 16; ++e) yn[((long long)(ct * 32 + cv_chan(e, lane)) * Ho + oy) * Wo + ox] = acc[e] * inv_scale;
     }
+    if (stats != nullptr) {                                              // (see conv_mfma_kernel)
+        const int pidx = ((n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * C1_TR + rt;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = (ox < Wo && oy < Ho) ? acc[e] * inv_scale : 0.f;
+            float sm = v, sq = v * v;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) { sm += __shfl_xor(sm, o); sq += __shfl_xor(sq, o); }
+            if ((lane & 31) == 0) stats[(long long)(ct * 32 + cv_chan(e, lane)) * NP + pidx] = make_float2(sm, sq);
+        }
+    }
 }
 
 static int conv1_launch(const float* x, const uint4* wp, float inv_scale, float* y, int N, int H, int W, int Ho, int Wo,
-                        unsigned* range,
+                        unsigned* range, float2* stats, int* np_out,
                         hipStream_t s) {
     constexpr size_t lds = (size_t)2 * C1_TR * 32 * C1_STRB + 3 * C1_IR * C1_IC * 4 + 16 * C1_KB * 4;
     static unsigned long long attr_done = 0ull;
     if (th_lds_attr_needed(&attr_done))
         TH_HIP(hipFuncSetAttribute((const void*)conv1_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid(th_cdiv(Wo, 32), th_cdiv(Ho, C1_TR), N);
-    hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo, range);
+    const int NP = (int)(grid.x * grid.y * grid.z) * C1_TR;
+    if (np_out) *np_out = NP;
+    if (x == nullptr) return 0;
+    hipLaunchKernelGGL(conv1_mfma_kernel, grid, dim3(256), lds, s, x, wp, inv_scale, y, H, W, Ho, Wo, range, stats, NP);
     TH_LAUNCH_CHECK();
     return 0;
 }
@@ -434,20 +474,20 @@ int th_maxpool3x3s2_launch(const float* x, int planes, int H, int W, float* y, h
 
 // the shapes of the ResNet18 stem (bias-free, padding KS/2)
 int th_conv2d_launch(const float* x, int N, int CIN, int H, int W, const void* packed, float inv_scale, int COUT, int KS,
-                     int stride, float* y, hipStream_t s, unsigned int* range) {
+                     int stride, float* y, hipStream_t s, unsigned int* range, float2* stats, int* np_out) {
     const int PAD = KS / 2;
     const int Ho = (H + 2 * PAD - KS) / stride + 1, Wo = (W + 2 * PAD - KS) / stride + 1;
     const uint4* wp = (const uint4*)packed;
-    if (CIN == 3 && COUT == 64 && KS == 7 && stride == 2) return conv1_launch(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
+    if (CIN == 3 && COUT == 64 && KS == 7 && stride == 2) return conv1_launch(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, stats, np_out, s);
     if (CIN == 64 && COUT == 64 && KS == 3 && stride == 1)
 #define CV_TR64 4
-        return conv_launch_t<64, 64, 1, 3, CV_TR64, 2>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
+        return conv_launch_t<64, 64, 1, 3, CV_TR64, 2>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, stats, np_out, s);
     if (CIN == 64 && COUT == 128 && KS == 3 && stride == 2)
-        return conv_launch_t<64, 128, 2, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
+        return conv_launch_t<64, 128, 2, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, stats, np_out, s);
     if (CIN == 128 && COUT == 128 && KS == 3 && stride == 1)
-        return conv_launch_t<128, 128, 1, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
+        return conv_launch_t<128, 128, 1, 3, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, stats, np_out, s);
     if (CIN == 64 && COUT == 128 && KS == 1 && stride == 2)
-        return conv_launch_t<64, 128, 2, 1, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, s);
+        return conv_launch_t<64, 128, 2, 1, 2, 4>(x, wp, inv_scale, y, N, H, W, Ho, Wo, range, stats, np_out, s);
     TH_REQUIRE(false, "th_conv2d: shape not built (ResNet18 stem shapes only)");
     return 1;
 }

@@ -318,10 +318,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        long long count, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, float momentum,
                                                        float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                       int relu, float* __restrict__ y) {
+                                                       int relu, float* __restrict__ y,
+                                                       const float2* __restrict__ fpart, int NP) {
     const int c = blockIdx.x, ns = blockIdx.y, n = ns / splits, sp = ns - n * splits;
     __shared__ float ss[2];
-    if (threadIdx.x == 0 && part == nullptr) {
+    __shared__ double red[8];
+    if (fpart != nullptr) {
+        // statistics left by the producing convolution (th_conv2d_stats): NP float2 partials per channel, added here in
+        // float64 in a fixed order (thread t takes t, t + 256, ...; then lanes, then waves)
+        double s = 0.0, q = 0.0;
+        for (int k = threadIdx.x; k < NP; k += 256) {
+            const float2 v = fpart[(long long)c * NP + k];
+            s += (double)v.x;
+            q += (double)v.y;
+        }
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+        if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = s; red[2 * (threadIdx.x >> 6) + 1] = q; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && part == nullptr && fpart == nullptr) {
         // eval mode (nn.BatchNorm2d.eval(): the reference's Trainer.val, trainer.py:131): the running statistics ARE the
         // statistics, nothing is updated
         const float g = gamma ? gamma[c] : 1.f;
@@ -329,7 +344,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         ss[1] = run_mean[c];
     } else if (threadIdx.x == 0) {
         double s = 0.0, q = 0.0;
-        for (int k = 0; k < NS; ++k) { s += part[((long long)c * NS + k) * 2]; q += part[((long long)c * NS + k) * 2 + 1]; }
+        if (fpart != nullptr) {
+            s = (red[0] + red[2]) + (red[4] + red[6]);
+            q = (red[1] + red[3]) + (red[5] + red[7]);
+        } else {
+            for (int k = 0; k < NS; ++k) { s += part[((long long)c * NS + k) * 2]; q += part[((long long)c * NS + k) * 2 + 1]; }
+        }
         const double mean = s / (double)count;
         double var = q / (double)count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -384,18 +404,20 @@ size_t th_bn_ws(int N, int C, int HW) {
 
 int th_bn_act_launch(const float* x, const float* res, int N, int C, int HW, const float* gamma, const float* beta,
                      float eps, float momentum, float* run_mean, float* run_var, int relu, float* y, void* ws,
-                     size_t ws_bytes, hipStream_t s, int eval) {
+                     size_t ws_bytes, hipStream_t s, int eval, const void* conv_stats, int conv_np) {
     TH_REQUIRE(N > 0 && C > 0 && HW > 0, "empty tensor");
-    TH_REQUIRE(eval || ws_bytes >= th_bn_ws(N, C, HW), "workspace too small");
+    TH_REQUIRE(eval || conv_stats || ws_bytes >= th_bn_ws(N, C, HW), "workspace too small");
+    TH_REQUIRE(!conv_stats || (!eval && conv_np > 0), "convolution statistics: train mode, at least one partial");
     TH_REQUIRE(!eval || (run_mean && run_var), "eval-mode BatchNorm needs the running statistics");
     TH_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)res) & 15) == 0, "tensors must be 16-byte aligned");
     const int splits = (HW + BN_SPLIT_ELEMS - 1) / BN_SPLIT_ELEMS;
     const int NS = N * splits;
     TH_REQUIRE(NS <= 65535, "too many plane slices");
-    double* part = eval ? nullptr : (double*)ws;
-    if (!eval) hipLaunchKernelGGL(bn_stats_kernel, dim3(C, NS), dim3(256), 0, s, x, C, HW, splits, part, NS);
+    double* part = (eval || conv_stats) ? nullptr : (double*)ws;
+    if (part) hipLaunchKernelGGL(bn_stats_kernel, dim3(C, NS), dim3(256), 0, s, x, C, HW, splits, part, NS);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(C, NS), dim3(256), 0, s, x, res, C, HW, splits, part, NS,
-                       (long long)N * HW, gamma, beta, eps, momentum, run_mean, run_var, relu, y);
+                       (long long)N * HW, gamma, beta, eps, momentum, run_mean, run_var, relu, y,
+                       (const float2*)conv_stats, conv_np);
     TH_LAUNCH_CHECK();
     return 0;
 }

@@ -566,6 +566,34 @@ int th_conv2d(th_ctx* c, const float* x, int N, int cin, int H, int W, const voi
     return th_conv2d_launch(x, N, cin, H, W, packed, inv_scale, cout, ks, stride, y, (hipStream_t)stream, c->range_dev);
 }
 
+int th_conv2d_stats_partials(int N, int cin, int H, int W, int cout, int ks, int stride) {
+    int np = 0;
+    if (!th_conv2d_built(cin, cout, ks, stride) || N <= 0 || H <= 0 || W <= 0) return 0;
+    if (th_conv2d_launch(nullptr, N, cin, H, W, nullptr, 0.f, cout, ks, stride, nullptr, nullptr, nullptr, nullptr, &np)) return 0;
+    return np;
+}
+
+int th_conv2d_stats(th_ctx* c, const float* x, int N, int cin, int H, int W, const void* packed, float inv_scale, int cout,
+                    int ks, int stride, float* y, void* stats, size_t stats_bytes, th_stream stream) {
+    TH_REQUIRE(c && x && packed && y && stats, "null argument");
+    TH_REQUIRE(N > 0 && H > 0 && W > 0, "empty tensor");
+    const int np = th_conv2d_stats_partials(N, cin, H, W, cout, ks, stride);
+    TH_REQUIRE(np > 0, "th_conv2d_stats: shape not built");
+    TH_REQUIRE(stats_bytes >= (size_t)cout * np * sizeof(float2), "statistics buffer too small");
+    TH_REQUIRE(((uintptr_t)stats & 7) == 0, "statistics buffer must be 8-byte aligned");
+    return th_conv2d_launch(x, N, cin, H, W, packed, inv_scale, cout, ks, stride, y, (hipStream_t)stream, c->range_dev,
+                            (float2*)stats, nullptr);
+}
+
+int th_bn_act_stats(th_ctx* c, const float* x, const float* residual, int N, int C, int HW, const void* stats, int n_partials,
+                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, int relu, float* y, th_stream stream) {
+    TH_REQUIRE(c && x && y && stats && n_partials > 0, "null argument");
+    TH_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "running_mean / running_var go together");
+    return th_bn_act_launch(x, residual, N, C, HW, gamma, beta, eps, momentum, running_mean, running_var, relu, y, nullptr, 0,
+                            (hipStream_t)stream, 0, stats, n_partials);
+}
+
 int th_maxpool3x3s2(th_ctx* c, const float* x, int planes, int H, int W, float* y, th_stream stream) {
     TH_REQUIRE(c && x && y && planes > 0 && H > 0 && W > 0, "bad argument");
     return th_maxpool3x3s2_launch(x, planes, H, W, y, (hipStream_t)stream);

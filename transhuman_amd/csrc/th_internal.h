@@ -510,12 +510,13 @@ int th_conv_pack_launch(const float* w, int COUT, int CIN, int KS, void* out, si
                         hipStream_t s);
 bool th_conv2d_built(int CIN, int COUT, int KS, int stride);
 int th_conv2d_launch(const float* x, int N, int CIN, int H, int W, const void* packed, float inv_scale, int COUT, int KS,
-                     int stride, float* y, hipStream_t s, unsigned int* range = nullptr);
+                     int stride, float* y, hipStream_t s, unsigned int* range = nullptr, float2* stats = nullptr,
+                     int* np_out = nullptr);
 int th_maxpool3x3s2_launch(const float* x, int planes, int H, int W, float* y, hipStream_t s);
 size_t th_bn_ws(int N, int C, int HW);
 int th_bn_act_launch(const float* x, const float* res, int N, int C, int HW, const float* gamma, const float* beta,
                      float eps, float momentum, float* run_mean, float* run_var, int relu, float* y, void* ws,
-                     size_t ws_bytes, hipStream_t s, int eval = 0);
+                     size_t ws_bytes, hipStream_t s, int eval = 0, const void* conv_stats = nullptr, int conv_np = 0);
 int th_fold_color_launch(const float* W /*[N,384]*/, const float* b, const float* wc /*[128,3]*/, const float* bc,
                          int N, float* Wo /*[N,260]*/, float* bo /*[N]*/, hipStream_t s);
 int th_segmean_masked_launch(const float* rows, int V, int width, const uint8_t* viz, int nv, const int32_t* off,

@@ -177,6 +177,12 @@ SYMBOLS = {
                             C.c_void_p]),
     "th_bn_act_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "th_conv2d_stats_partials": (C.c_int, [C.c_int] * 7),
+    "th_conv2d_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int,
+                                  C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "th_bn_act_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_void_p]),
     "th_render_prepass_cancel": (C.c_int, [C.c_void_p]),
     "th_render_prepass_drop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "th_sigma_grid_workspace_bytes": (C.c_size_t, [C.POINTER(ThFrame), C.c_int]),
@@ -205,7 +211,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.th_abi_version() != 11:
+    if lib.th_abi_version() != 12:
         raise HipError("ABI version mismatch")
     _lib = lib
     return lib
@@ -773,9 +779,11 @@ def conv2d_supported(conv):
             bool(load_library().th_conv2d_supported(conv.in_channels, conv.out_channels, ks[0], st[0])))
 
 
-def conv2d(x, conv):
+def conv2d(x, conv, stats=False):
     """th_conv2d: y = conv(x) for a supported bias-free nn.Conv2d (NCHW fp32), fp16-split MFMA implicit GEMM.
-    The packed weight image is cached per module and rebuilt when the weight tensor changes."""
+    The packed weight image is cached per module and rebuilt when the weight tensor changes.
+    ``stats=True`` (th_conv2d_stats): also returns the per-channel BatchNorm partial sums the epilogue leaves, as
+    (y, (buffer, n_partials)) for bn_act(..., conv_stats=...)."""
     lib = load_library()
     assert x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()
     w = conv.weight
@@ -793,6 +801,12 @@ def conv2d(x, conv):
     pd = ks // 2
     Ho, Wo = (H + 2 * pd - ks) // st + 1, (W + 2 * pd - ks) // st + 1
     y = torch.empty((N, co, Ho, Wo), dtype=torch.float32, device=x.device)
+    if stats:
+        npart = int(lib.th_conv2d_stats_partials(N, ci, H, W, co, ks, st))
+        sbuf = torch.empty((co, npart, 2), dtype=torch.float32, device=x.device)
+        _check(lib.th_conv2d_stats(ctx(x.device), _p(x), N, ci, H, W, _p(ent[2]), ent[3], co, ks, st, _p(y), _p(sbuf),
+                                   sbuf.numel() * 4, _stream()))
+        return y, (sbuf, npart)
     _check(lib.th_conv2d(ctx(x.device), _p(x), N, ci, H, W, _p(ent[2]), ent[3], co, ks, st, _p(y), _stream()))
     return y
 
@@ -806,10 +820,11 @@ def maxpool3x3s2(x):
     return y
 
 
-def bn_act(x, bn, residual=None, relu=True):
+def bn_act(x, bn, residual=None, relu=True, conv_stats=None):
     """th_bn_act: train-mode nn.BatchNorm2d `bn` on x [N,C,H,W] (+ residual) (+ ReLU) in two launches; updates
     bn.running_mean / running_var like the module (num_batches_tracked is left to the caller).  A module in eval() mode
-    normalises with its running statistics in one launch (th_bn_act_eval)."""
+    normalises with its running statistics in one launch (th_bn_act_eval).  ``conv_stats`` = the (buffer, n_partials) of
+    conv2d(..., stats=True) that produced x: the statistics pass is skipped (th_bn_act_stats, one launch)."""
     lib = load_library()
     assert x.dim() == 4 and x.is_contiguous() and x.dtype == torch.float32
     N, Cc, H, W = x.shape
@@ -821,12 +836,20 @@ def bn_act(x, bn, residual=None, relu=True):
                                   None if bn.weight is None else _p(bn.weight), None if bn.bias is None else _p(bn.bias),
                                   float(bn.eps), _p(bn.running_mean), _p(bn.running_var), int(relu), _p(y), _stream()))
         return y
-    ws = _ws(lib.th_bn_workspace_bytes(N, Cc, H * W), x.device)
     y = torch.empty_like(x)
     track = bn.track_running_stats and bn.running_mean is not None
     assert bn.momentum is not None, "cumulative-average BatchNorm (momentum=None) is not handled here"
     mom = float(bn.momentum)
     r = None if residual is None else residual.contiguous()
+    if conv_stats is not None:
+        sbuf, npart = conv_stats
+        assert sbuf.shape == (Cc, npart, 2) and sbuf.dtype == torch.float32 and sbuf.device == x.device
+        _check(lib.th_bn_act_stats(ctx(x.device), _p(x), None if r is None else _p(r), N, Cc, H * W, _p(sbuf), npart,
+                                   None if bn.weight is None else _p(bn.weight), None if bn.bias is None else _p(bn.bias),
+                                   float(bn.eps), mom, _p(bn.running_mean) if track else None,
+                                   _p(bn.running_var) if track else None, int(relu), _p(y), _stream()))
+        return y
+    ws = _ws(lib.th_bn_workspace_bytes(N, Cc, H * W), x.device)
     _check(lib.th_bn_act(ctx(x.device), _p(x), None if r is None else _p(r), N, Cc, H * W,
                          None if bn.weight is None else _p(bn.weight), None if bn.bias is None else _p(bn.bias),
                          float(bn.eps), mom, _p(bn.running_mean) if track else None,

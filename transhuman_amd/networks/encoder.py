@@ -144,19 +144,26 @@ class SpatialEncoder(nn.Module):
         m = self.model
         stock_conv = os.environ.get("TH_STOCK_CONV") == "1"
 
-        def conv(mod, t):        # K12 for the stem's shapes, the stock module otherwise
-            if not stock_conv and hip.conv2d_supported(mod):
-                return hip.conv2d(t.contiguous(), mod)
-            return mod(t)
+        fuse_stats = os.environ.get("TH_BN_STATS_PASS") != "1"
 
-        x = hip.bn_act(conv(m.conv1, x), m.bn1, relu=True)
+        def conv_bn(mod, bn, t, residual=None, relu=True):
+            # K12 for the stem's shapes (its epilogue leaves the BatchNorm partial sums when the module is in train():
+            # conv -> bn is two launches, TH_BN_STATS_PASS=1 keeps the separate statistics pass), the stock module otherwise
+            if not stock_conv and hip.conv2d_supported(mod):
+                if bn.training and fuse_stats:
+                    y, st = hip.conv2d(t.contiguous(), mod, stats=True)
+                    return hip.bn_act(y, bn, residual=residual, relu=relu, conv_stats=st)
+                return hip.bn_act(hip.conv2d(t.contiguous(), mod), bn, residual=residual, relu=relu)
+            return hip.bn_act(mod(t), bn, residual=residual, relu=relu)
+
+        x = conv_bn(m.conv1, m.bn1, x)
         lat = [x]
         x = m.maxpool(x) if stock_conv else hip.maxpool3x3s2(x)
         for layer in (m.layer1, m.layer2):
             for blk in layer:
-                idt = x if blk.downsample is None else hip.bn_act(conv(blk.downsample[0], x), blk.downsample[1], relu=False)
-                y = hip.bn_act(conv(blk.conv1, x), blk.bn1, relu=True)
-                x = hip.bn_act(conv(blk.conv2, y), blk.bn2, residual=idt, relu=True)
+                idt = x if blk.downsample is None else conv_bn(blk.downsample[0], blk.downsample[1], x, relu=False)
+                y = conv_bn(blk.conv1, blk.bn1, x)
+                x = conv_bn(blk.conv2, blk.bn2, y, residual=idt)
             lat.append(x)
         counters = [b.num_batches_tracked for b in self._bn_sites()
                     if b.training and b.track_running_stats and b.num_batches_tracked is not None]
@@ -165,7 +172,7 @@ class SpatialEncoder(nn.Module):
         return lat
 
     # ---- the stem as a hipGraph ------------------------------------------------------------------------------------------
-    # The HIP stem is 31 dependent launches (10 convolutions, 20 BatchNorm passes, the pooling) of 10 - 100 us each: for a frame
+    # The HIP stem is 21 dependent launches (10 convolutions, 10 BatchNorm passes, the pooling) of 10 - 100 us each: for a frame
     # pipeline that is 0.35 ms of host time per frame (a third of what a rank of an 8-rank job can spend) and 31 launch latencies
     # on the side stream's dependent chain.  Frames of one shape run the same launches on the same parameter storage, so the
     # chain is captured once per instance and replayed: one graph launch per frame.  GRAPH_RING instances rotate (static input
