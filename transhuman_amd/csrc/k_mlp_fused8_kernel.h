@@ -451,13 +451,19 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
     }
     // range guard: launch-wide maxima as they stand when this tile starts (scalar loads through the constant address space: the
     // table is only a hint here -- a stale smaller value costs an atomic, never a result)
-    const unsigned* rtab = PK.range;
-    // (uniform values: moved to scalar registers)
-    seen_s = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_S]) : 0u;
-    seen_p = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_P]) : 0u;
-    seen_n = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_N]) : 0u;
-    seen_i = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_INTER]) : 0u;
-    seen_4 = PK.range ? (unsigned)__builtin_amdgcn_readfirstlane((int)rtab[zoff + TH_RANGE_F4]) : 0u;
+    // All five requested at once (one 16-byte + one 4-byte vector load: coherent with the other workgroups' atomics -- through the
+    // scalar cache a workgroup saw the table as it stood when its CU first read it, i.e. zeros after a reset, and every lane of
+    // every tile raised atomics: 2.5 x the tile's cycles in render_fast) and moved to scalar registers BEHIND the first barrier.
+    // As `readfirstlane(rtab[i])` they had compiled into five load / s_waitcnt vmcnt(0) pairs in a row: five serial L2 round trips
+    // in front of every other request of the tile.
+    fm_u4 rv4 = {0u, 0u, 0u, 0u};
+    unsigned rv1 = 0u;
+    static_assert(TH_RANGE_S == 1 && TH_RANGE_P == 2 && TH_RANGE_N == 3 && TH_RANGE_INTER == 4 && TH_RANGE_F4 == 5, "range slots 1..5");
+    if (PK.range != nullptr) {
+        const unsigned* rtab = PK.range + zoff;
+        rv4 = (fm_u4){rtab[1], rtab[2], rtab[3], rtab[4]};
+        rv1 = rtab[5];
+    }
     TexPre tex_pre = tex_fetch(), tex_pre2;
 
     // ================= token branch: s = relu(fc_0 h); ks|vs = kv1(s) =================
@@ -575,6 +581,14 @@ __global__ __launch_bounds__(F8_THREADS, 2) void mlp_fused8_kernel(FusedParams P
             }
         }
         FM_SYNCL();                                   // every wave is done reading the T' rows: ABUF may take s
+        {                                             // (the range table's words have long arrived)
+            asm volatile("" : "+v"(rv4), "+v"(rv1));
+            seen_s = (unsigned)__builtin_amdgcn_readfirstlane((int)rv4[0]);
+            seen_p = (unsigned)__builtin_amdgcn_readfirstlane((int)rv4[1]);
+            seen_n = (unsigned)__builtin_amdgcn_readfirstlane((int)rv4[2]);
+            seen_i = (unsigned)__builtin_amdgcn_readfirstlane((int)rv4[3]);
+            seen_4 = (unsigned)__builtin_amdgcn_readfirstlane((int)rv1);
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             f8_f4 pe2[2];
