@@ -20,6 +20,19 @@ __global__ __launch_bounds__(256) void composite_kernel(const float4* __restrict
     int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ray >= ps.R) return;
     const int S = ps.S;
+    // A ray that misses the hull has no live sample (the hull stage raises ray_hit with every mask bit it sets): every weight is
+    // 0 and the outputs are exact zeros (no white background either, see below) -- written without the 64 exponentials and the
+    // scan.  4/5 of the headline frame's rays: 265 -> 90 us.
+    if (ray_hit != nullptr && mask != nullptr && ray_hit[ray] == 0) {
+        if (wout)
+            for (int s = lane; s < S; s += 64) wout[(long long)ray * S + s] = 0.f;
+        if (lane == 0) {
+            rgb[3 * ray] = 0.f; rgb[3 * ray + 1] = 0.f; rgb[3 * ray + 2] = 0.f;
+            acc[ray] = 0.f;
+            depth[ray] = 0.f;
+        }
+        return;
+    }
     float dx = ps.ray_d[3 * ray], dy = ps.ray_d[3 * ray + 1], dz = ps.ray_d[3 * ray + 2];
     float nd = dx * dx + dy * dy;
     nd = __fsqrt_rn(nd + dz * dz);                       // torch.norm(rays_d)
