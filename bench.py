@@ -474,7 +474,11 @@ def run_extras(dev, net, args, H, W, V):
         extra["C5_mesh"] = {"grid": g, "ms_per_frame": ms, "sigma_grid_ms": sig_ms, "voxels_per_s": g ** 3 / ms * 1e3,
                             "valid_voxels": int(mr.last_stats["valid_samples"]), "mesh_vertices": int(mesh.vertices.shape[0]),
                             "mesh_triangles": int(mesh.faces.shape[0]), "mesh_th": 0.5,
-                            "gpu_vs_oracle": {"voxels": int(len(pick)), "max_abs_sigma": float(d.max())}}
+                            "gpu_vs_oracle": {"voxels": int(len(pick)), "max_abs_sigma": float(d.max()),
+                                              "max_abs_sigma_oracle": float(np.abs(ref.reshape(-1).numpy()).max()),
+                                              "note": "sigma is the RAW density (tens to hundreds here), not alpha: the 1e-4 bar is on "
+                                                      "rgb / alpha; every valid voxel of the grid against the device oracle: "
+                                                      "tests/test_gpu_round6.py"}}
     finally:
         cfg.mesh_th = old_th
     return extra
