@@ -1,7 +1,9 @@
 // NOT PART OF THE BUILD.  Round-6 experiment, kept as the record of what was measured (LOG.md):
 //   * built in one sitting on top of mlp_fused8_kernel's helpers, 255 VGPRs, no scratch, 77.7 KB of LDS: two workgroups per CU;
-//   * token branch bit-identical with the 8-wave kernel, pixel branch after one fix (see `blend`), 16 % of the samples still
-//     differed in sigma and some rows in rgb when it was stopped (second T' pass / RGB branch not debugged);
+//   * token branch, pixel rows and the token keys bit-identical with the 8-wave kernel (phase dumps: FH_DUMP_AT / FH_DUMPF_AT /
+//     FH_DUMPSUM_AT, macros that lived in k_mlp_fused8_kernel.h while this was debugged); the PIXEL KEYS (kv0) come out wrong on
+//     0.6 % of the rows -- only when two workgroups share a CU (TH_FH_LDS=83000, one per CU: bit-identical), the operand rows
+//     intact before and after the product, the ISA around the barriers in order: not found when it was stopped;
 //   * 101 k cycles per HALF tile with two workgroups on the CU at 1.95 GHz = 51.9 us per 32 samples against the 8-wave kernel's
 //     96.8 k at 2.04 GHz = 47.5 us; frame 15.3 ms against 13.8 ms on the same box.  Why: (a) the two co-resident workgroups ran
 //     their GEMM phases TOGETHER (kv1 15.1 k cycles for half the rows = the 8-wave kernel's time for all of them): equal phase
@@ -170,12 +172,8 @@ __global__ __launch_bounds__(FH_THREADS, 2) void mlp_fusedh_kernel(FusedParams P
             const unsigned h0 = second ? hb0 : ha0, h1 = second ? hb1 : ha1;
             auto row = [&](unsigned off) __attribute__((always_inline)) {
                 const int wi = __builtin_amdgcn_readfirstlane((int)(8u + off / 1040u));
-#if defined(FH_DUMP) && FH_DUMP == 7
-                const unsigned id = (PK.tex_hdr + (long long)tile * 512 + (second ? pb : pa) * 128)[wi];
-#else
                 const unsigned id = wi < 64 ? (unsigned)__builtin_amdgcn_readlane((int)h0, wi)
                                             : (unsigned)__builtin_amdgcn_readlane((int)h1, wi - 64);
-#endif
                 return *reinterpret_cast<const float4*>(mbase + TX_ADDR(id));
             };
             r.a = row(o[0]);
@@ -200,10 +198,6 @@ __global__ __launch_bounds__(FH_THREADS, 2) void mlp_fusedh_kernel(FusedParams P
             lo = __builtin_elementwise_fma((f32x2){r.d.x, r.d.y}, W11, lo);
             hi = __builtin_elementwise_fma((f32x2){r.d.z, r.d.w}, W11, hi);
             const int row = wv + 4 * k;
-#if defined(FH_DUMP) && FH_DUMP == 8
-            if (!RGB && lane == 0 && row >= 16 && row < 32 && row - 16 < npts)
-                *reinterpret_cast<float4*>(PK.raw_c + (long long)(pbase + row - 16) * 4) = make_float4(w00, w01 + w10 + w11, r.a.x, lo[0]);
-#endif
             if constexpr (RGB) {
                 *reinterpret_cast<float4*>(abuf + row * 1040 + lane * 16) = make_float4(lo[0], lo[1], hi[0], hi[1]);
             } else {
@@ -421,36 +415,6 @@ __global__ __launch_bounds__(FH_THREADS, 2) void mlp_fusedh_kernel(FusedParams P
     FM_SB();
     FM_SYNCL();
     FH_DUMP_AT(2, abuf, a256_lo, STR256, 16)
-    FH_DUMP_AT(7, abuf, a256_lo, STR256, 16)
-#if defined(FH_DUMP) && FH_DUMP == 8
-    return;
-#endif
-#ifdef FH_DUMP
-    if (FH_DUMP == 6) {                           // the same four values by a scalar walk through K5t's hand-over
-        if (tid < npts) {
-            const int v = V > 1 ? 1 : 0, smp = 16 * half + tid;
-            const unsigned* rec = PK.tex_rec + ((long long)(tile * V + v) * 32 + smp) * 8;
-            const unsigned* hb = PK.tex_hdr + (long long)tile * 512;
-            const int np = (int)(hb[0] >> 16);
-            const int sh = np == 1 ? 2 : np == 2 ? 1 : 0;
-            const unsigned* hp = hb + ((smp >> 3) >> sh) * 128;
-            const int ch_[4] = {0, 77, 150, 255};
-            float o_[4];
-            for (int q = 0; q < 4; ++q) {
-                float acc = 0.f;
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned id = hp[8 + rec[4 + j] / 1040u];
-                    const float w = __builtin_bit_cast(float, rec[j]);
-                    const float x = PK.tex_map[(size_t)id * 256 + ch_[q]];
-                    acc = j == 0 ? x * w : fmaf(x, w, acc);
-                }
-                o_[q] = fmaxf(acc + PK.ar0.bias[ch_[q]], 0.f);
-            }
-            *reinterpret_cast<float4*>(PK.raw_c + (long long)(pbase + tid) * 4) = make_float4(o_[0], o_[1], o_[2], o_[3]);
-        }
-        return;
-    }
-#endif
     f8_f4 vp[4][RT];
     {
         f8_f4 kk[2][RT];
@@ -470,6 +434,8 @@ __global__ __launch_bounds__(FH_THREADS, 2) void mlp_fusedh_kernel(FusedParams P
             }
         }
         FM_SYNCL();                                                  // every wave is done reading p from ABUF
+        FH_DUMP_AT(8, abuf, a256_lo, STR256, 16)
+        FH_DUMPSUM_AT(9, abuf, a256_lo, STR256, 16)
         float* kpb = reinterpret_cast<float*>(abuf);                // [ROWS][KSTR]
 #pragma unroll
         for (int vw = 0; vw < 2; ++vw)
@@ -480,6 +446,8 @@ __global__ __launch_bounds__(FH_THREADS, 2) void mlp_fusedh_kernel(FusedParams P
     }
     FM_SYNCL();
 
+    FH_DUMPF_AT(5, reinterpret_cast<const float*>(abuf), KSTR, 16, 0, 41, 77, 127)
+    FH_DUMPF_AT(6, ksb, KSTR, 16, 0, 41, 77, 127)
     // ================= cross-view attention (cross_transformer.py:128-149) =================
     {
         const float* kpb = reinterpret_cast<const float*>(abuf);
@@ -535,6 +503,7 @@ __global__ __launch_bounds__(FH_THREADS, 2) void mlp_fusedh_kernel(FusedParams P
 #pragma unroll
         for (int c = 0; c < 4; ++c) bn[c] = f8_bias(PK.fc_1.bias, (2 * wave + (c >> 1)) * 32 + (c & 1) * 16, lane);
         FM_SYNCL();
+        FH_DUMPF_AT(7, probs, FH_PSTR, -1, 0, 3, 4, 8)
         {
             const float* pr = probs + l15 * FH_PSTR;
             const float4 q0 = *reinterpret_cast<const float4*>(pr), q1 = *reinterpret_cast<const float4*>(pr + 4);
